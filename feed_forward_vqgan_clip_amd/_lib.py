@@ -1,0 +1,121 @@
+"""ctypes binding of libffvc_hip.so (C ABI declared in include/ffvc.h).
+
+The library is the product: if it is missing or a call fails we raise — there is
+no CPU / eager fallback anywhere in this package (the oracle under oracle/ is test
+infrastructure only and is never imported from here).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libffvc_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
+OP_KMAJOR, OP_TRANS, OP_CONV3X3 = 0, 1, 2
+F_BIAS_ALONG_M = 1
+F_WRITE_PREACT = 2
+F_MUL_ACT_GRAD = 4
+F_ATOMIC_OUT = 8
+F_RES_F32 = 16
+F_OUT_F32 = 32
+F_TR_SAFE = 64
+F_UPSAMPLE2X = 128
+
+
+class GemmDesc(Structure):
+    """Mirror of `ffvc_gemm_desc` (include/ffvc.h)."""
+
+    _fields_ = [
+        ("x", c_void_p),
+        ("w", c_void_p),
+        ("y", c_void_p),
+        ("bias", c_void_p),
+        ("residual", c_void_p),
+        ("aux", c_void_p),
+        ("M", c_int32),
+        ("N", c_int32),
+        ("K", c_int32),
+        ("x_mode", c_int32),
+        ("w_mode", c_int32),
+        ("in_dtype", c_int32),
+        ("act", c_int32),
+        ("flags", c_int32),
+        ("split_k", c_int32),
+        ("alpha", c_float),
+        ("ldx", c_int64),
+        ("ldw", c_int64),
+        ("ldaux", c_int64),
+        ("kseg", c_int32),
+        ("xkso", c_int64),
+        ("wkso", c_int64),
+        ("y_mi", c_int32),
+        ("y_so", c_int64),
+        ("y_sm", c_int64),
+        ("r_mi", c_int32),
+        ("r_so", c_int64),
+        ("r_sm", c_int64),
+        ("batch", c_int32),
+        ("batch_inner", c_int32),
+        ("xbo", c_int64),
+        ("xbi", c_int64),
+        ("wbo", c_int64),
+        ("wbi", c_int64),
+        ("ybo", c_int64),
+        ("ybi", c_int64),
+        ("rbo", c_int64),
+        ("rbi", c_int64),
+        ("abo", c_int64),
+        ("abi", c_int64),
+        ("conv_H", c_int32),
+        ("conv_W", c_int32),
+        ("conv_Cin", c_int32),
+    ]
+
+
+_lib = None
+
+# name -> (restype, argtypes).  tests/test_abi.py checks every symbol declared in
+# include/ffvc.h appears here and is exported by the shared object.
+_SIGNATURES = {
+    "ffvc_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ffvc_last_error": (c_char_p, []),
+    "ffvc_version": (c_int, []),
+    "ffvc_device_info": (c_int, [POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "ffvc_probe_tr16": (c_int, [c_void_p, c_void_p]),
+}
+
+
+class FFVCError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once). Raises FFVCError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FFVCError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C feed_forward_vqgan_clip_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ffvc_last_error()
+        raise FFVCError(f"{what} failed (status {status}): {msg.decode() if msg else '?'}")
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)

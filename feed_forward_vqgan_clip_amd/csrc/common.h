@@ -1,0 +1,164 @@
+// common.h — shared device/host helpers for libffvc_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ffvc.h"
+
+#define FFVC_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// ---- error plumbing -------------------------------------------------------
+void ffvc_set_error(const char* fmt, ...);
+
+#define FFVC_CHECK_ARG(cond, ...)      \
+  do {                                 \
+    if (!(cond)) {                     \
+      ffvc_set_error(__VA_ARGS__);     \
+      return FFVC_E_BADARG;            \
+    }                                  \
+  } while (0)
+
+#define FFVC_LAUNCH_CHECK()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      ffvc_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,      \
+                     hipGetErrorString(e__));                            \
+      return (int)e__;                                                   \
+    }                                                                    \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+// Storage-type traits: T = uint16_t (bf16 bits) or float.
+template <typename T>
+struct ElemTraits;
+template <>
+struct ElemTraits<uint16_t> {
+  static constexpr int kDtype = FFVC_BF16;
+  static constexpr int kPerChunk = 8;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float load(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+  __device__ static __forceinline__ void store(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+};
+template <>
+struct ElemTraits<float> {
+  static constexpr int kDtype = FFVC_F32;
+  static constexpr int kPerChunk = 4;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+
+// Load / store 4 consecutive elements as floats (8 B for bf16, 16 B for f32).
+__device__ __forceinline__ f32x4_t load4(const uint16_t* p) {
+  u32x2_t v = *(const u32x2_t*)p;
+  f32x4_t r;
+  r[0] = __uint_as_float(v[0] << 16);
+  r[1] = __uint_as_float(v[0] & 0xffff0000u);
+  r[2] = __uint_as_float(v[1] << 16);
+  r[3] = __uint_as_float(v[1] & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ f32x4_t load4(const float* p) { return *(const f32x4_t*)p; }
+__device__ __forceinline__ void store4(uint16_t* p, f32x4_t v) {
+  u32x2_t o;
+  o[0] = pack_bf16x2(v[0], v[1]);
+  o[1] = pack_bf16x2(v[2], v[3]);
+  *(u32x2_t*)p = o;
+}
+__device__ __forceinline__ void store4(float* p, f32x4_t v) { *(f32x4_t*)p = v; }
+
+// Load / store 8 consecutive elements as floats.
+struct f32x8 {
+  float v[8];
+};
+__device__ __forceinline__ f32x8 load8(const uint16_t* p) {
+  u32x4_t u = *(const u32x4_t*)p;
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __uint_as_float(u[i] << 16);
+    r.v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+  }
+  return r;
+}
+__device__ __forceinline__ f32x8 load8(const float* p) {
+  f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 4);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[i] = a[i];
+    r.v[4 + i] = b[i];
+  }
+  return r;
+}
+__device__ __forceinline__ void store8(uint16_t* p, const f32x8& r) {
+  u32x4_t u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = pack_bf16x2(r.v[2 * i], r.v[2 * i + 1]);
+  *(u32x4_t*)p = u;
+}
+__device__ __forceinline__ void store8(float* p, const f32x8& r) {
+  f32x4_t a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = r.v[i];
+    b[i] = r.v[4 + i];
+  }
+  *(f32x4_t*)p = a;
+  *(f32x4_t*)(p + 4) = b;
+}
+
+// ---- wave / block reductions ---------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations ----------------------------------------------------------
+__device__ __forceinline__ float act_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_quickgelu(float x) { return x * sigmoidf_(1.702f * x); }
+__device__ __forceinline__ float act_quickgelu_grad(float x) {
+  const float s = sigmoidf_(1.702f * x);
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+__device__ __forceinline__ float act_swish(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float act_swish_grad(float x) {
+  const float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

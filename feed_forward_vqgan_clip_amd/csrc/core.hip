@@ -1,0 +1,54 @@
+// core.hip — error plumbing, device info and hardware probes of libffvc_hip.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ffvc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ffvc_last_error(void) { return g_err; }
+
+extern "C" int ffvc_version(void) { return 100; }
+
+extern "C" int ffvc_device_info(int32_t* n_cu, int32_t* clock_khz, int64_t* hbm_bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    ffvc_set_error("hipGetDevice: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) {
+    ffvc_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return 0;
+}
+
+// Each lane supplies the address of 4 consecutive shorts (lane l -> lds[4l..4l+3], lds[i] = i);
+// the dump shows which source element lands in (lane, j).
+__global__ void probe_tr16_kernel(int16_t* out) {
+  __shared__ __attribute__((aligned(16))) int16_t lds[256];
+  for (int i = threadIdx.x; i < 256; i += 64) lds[i] = (int16_t)i;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + threadIdx.x * 4));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = r[j];
+}
+
+extern "C" int ffvc_probe_tr16(int16_t* out, void* stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,581 @@
+// gemm.hip — the one MFMA contraction kernel family of libffvc_hip (gfx950).
+//
+// y[m,n] (+)= act(alpha * sum_k X[m,k] W[n,k] + bias) (+ residual), see include/ffvc.h.
+//
+// Design (MI355X-first, not a port of anything):
+//   * 128x128 output tile per 256-thread workgroup (4 waves as 2(M) x 2(N), 64x64 per wave,
+//     2x2 v_mfma_f32_32x32x16_bf16 tiles -> 64 accumulator VGPRs per lane).
+//   * K step = 128 bytes per operand row (64 bf16 / 32 f32): K-major operands are fetched as
+//     full 128-B lines, transposed operands as 256/512-B row segments.
+//   * register-staged global->LDS pipeline: tile t+1 is in flight in VGPRs while tile t is
+//     consumed from LDS (one LDS buffer, two barriers per K step; 3-4 workgroups per CU hide
+//     the barrier bubbles).
+//   * LDS images are padded so every fragment read is bank-conflict free:
+//       K-major  : [128 rows][128 B + 16 B pad]  read with ds_read_b128 (row stride 144 B = 9
+//                  16-B slots, 9 coprime with 16 -> the 16 lanes of a b128 lane group hit 16
+//                  distinct slots)
+//       TRANS bf16: [64 k][256 B + 64 B pad]      read with ds_read_b64_tr_b16 (hardware
+//                  transpose; the 4 k-rows of a 16-lane group land on 4 disjoint 64-B bank ranges)
+//       TRANS f32 : [32 k][512 B]                 read with ds_read_b32 (lanes contiguous)
+//   * MFMA roles are swapped on purpose: A := W fragment (rows n), B := X fragment (cols m), so
+//     each lane ends up with 4 CONSECUTIVE n for one m -> 8/16-byte epilogue stores into the
+//     row-major y with bias/activation/residual fused.
+//   * the fp32 instantiation uses v_mfma_f32_32x32x2_f32 (exact fp32, "parity mode") through
+//     the very same staging/fragment code: a 16-byte chunk is 8 bf16 (one MFMA) or 4 f32 (four).
+//   * workgroup id -> tile map is XCD-aware (consecutive ids round-robin over the 8 XCDs, so
+//     each XCD gets a contiguous run of tiles that share operand panels in its private L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int NTHREADS = 256;
+constexpr int RS_KMAJOR = 144;       // bytes: 128 B of K + 16 B pad
+constexpr int TILE_BYTES = 20480;    // max over the three LDS images
+
+template <typename T>
+struct GemmTraits;
+template <>
+struct GemmTraits<uint16_t> {
+  static constexpr int BK = 64;
+  static constexpr int EPC = 8;
+  static constexpr int RS_TRANS = 320;   // 128 cols * 2 B + 64 B pad
+  static constexpr int TR_CHUNKS_PER_ROW = 16;
+};
+template <>
+struct GemmTraits<float> {
+  static constexpr int BK = 32;
+  static constexpr int EPC = 4;
+  static constexpr int RS_TRANS = 512;
+  static constexpr int TR_CHUNKS_PER_ROW = 32;
+};
+
+__device__ __forceinline__ u32x4_t zero4() {
+  u32x4_t z = {0u, 0u, 0u, 0u};
+  return z;
+}
+
+// Guarded element-wise gather of one 16-byte chunk (edges only).
+template <typename T>
+__device__ __forceinline__ u32x4_t load_partial(const T* p, int valid) {
+  constexpr int EPC = GemmTraits<T>::EPC;
+  union {
+    u32x4_t v;
+    T e[EPC];
+  } u;
+  u.v = zero4();
+#pragma unroll
+  for (int i = 0; i < EPC; ++i)
+    if (i < valid) u.e[i] = p[i];
+  return u.v;
+}
+
+// ---------------------------------------------------------------------------
+// Operand staging: global -> 4 x 16 B registers per thread -> LDS image.
+// ---------------------------------------------------------------------------
+template <typename T, int MODE>
+struct Stager;
+
+// K-major: tile [128 rows][BK], chunk q of thread t: row = (t>>3) + 32q, kc = t&7.
+template <typename T>
+struct Stager<T, FFVC_OP_KMAJOR> {
+  static constexpr int EPC = GemmTraits<T>::EPC;
+  const T* rowp[4];
+  bool rvalid[4];
+  int kc;
+  int kseg;
+  int64_t kso;
+  __device__ __forceinline__ void init(const T* base, int64_t ld, int row0, int rows, int kseg_,
+                                       int64_t kso_, int tid) {
+    kc = (tid & 7) * EPC;
+    kseg = kseg_;
+    kso = kso_;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = row0 + (tid >> 3) + 32 * q;
+      rvalid[q] = r < rows;
+      rowp[q] = base + (int64_t)(rvalid[q] ? r : 0) * ld;
+    }
+  }
+  __device__ __forceinline__ void load(u32x4_t (&reg)[4], int k0, int kend) {
+    const int k = k0 + kc;
+    const int64_t koff = kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) + kc : (int64_t)k;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (rvalid[q] && k + EPC <= kend)
+        reg[q] = *(const u32x4_t*)(rowp[q] + koff);
+      else if (rvalid[q] && k < kend)
+        reg[q] = load_partial<T>(rowp[q] + koff, kend - k);
+      else
+        reg[q] = zero4();
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* s, const u32x4_t (&reg)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(u32x4_t*)(s + ((tid >> 3) + 32 * q) * RS_KMAJOR + (tid & 7) * 16) = reg[q];
+  }
+};
+
+// Transposed: tile [BK k-rows][128 cols]; global rows are contiguous along the tile's 128 cols.
+template <typename T>
+struct Stager<T, FFVC_OP_TRANS> {
+  static constexpr int EPC = GemmTraits<T>::EPC;
+  static constexpr int CPR = GemmTraits<T>::TR_CHUNKS_PER_ROW;  // 16-B chunks per tile row
+  static constexpr int RPP = NTHREADS / CPR;                     // k-rows covered per pass
+  const T* colp;
+  int64_t ld;
+  int nvalid;  // how many of this thread's EPC columns are in range (<=0: none)
+  int krow;
+  __device__ __forceinline__ void init(const T* base, int64_t ld_, int row0, int rows, int, int64_t,
+                                       int tid) {
+    const int c = row0 + (tid % CPR) * EPC;
+    nvalid = rows - c;
+    colp = base + (nvalid > 0 ? c : 0);
+    ld = ld_;
+    krow = tid / CPR;
+  }
+  __device__ __forceinline__ void load(u32x4_t (&reg)[4], int k0, int kend) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + krow + RPP * q;
+      const T* p = colp + (int64_t)k * ld;
+      if (k < kend && nvalid >= EPC)
+        reg[q] = *(const u32x4_t*)p;
+      else if (k < kend && nvalid > 0)
+        reg[q] = load_partial<T>(p, nvalid);
+      else
+        reg[q] = zero4();
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* s, const u32x4_t (&reg)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(u32x4_t*)(s + (tid / CPR + RPP * q) * GemmTraits<T>::RS_TRANS + (tid % CPR) * 16) = reg[q];
+  }
+};
+
+// Implicit im2col of an NHWC tensor for a 3x3 / pad 1 / stride 1 conv, optional fused nearest 2x
+// upsample of the input.  Same LDS image as K-major (rows = output pixels).
+template <typename T>
+struct Stager<T, FFVC_OP_CONV3X3> {
+  static constexpr int EPC = GemmTraits<T>::EPC;
+  const T* base;
+  int pix[4];  // b * Hin * Win
+  int oy[4], ox[4];
+  bool rvalid[4];
+  int H, W, Win, Cin, ups, kc;
+  __device__ __forceinline__ void init(const T* base_, int64_t, int row0, int rows, int H_, int W_,
+                                       int Cin_, int ups_, int tid) {
+    base = base_;
+    H = H_;
+    W = W_;
+    Cin = Cin_;
+    ups = ups_;
+    Win = W_ >> ups_;
+    const int Hin = H_ >> ups_;
+    kc = (tid & 7) * EPC;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = row0 + (tid >> 3) + 32 * q;
+      rvalid[q] = r < rows;
+      const int rr = rvalid[q] ? r : 0;
+      const int b = rr / (H * W);
+      const int rem = rr - b * (H * W);
+      oy[q] = rem / W;
+      ox[q] = rem - oy[q] * W;
+      pix[q] = b * Hin * Win;
+    }
+  }
+  __device__ __forceinline__ void load(u32x4_t (&reg)[4], int k0, int /*kend*/) {
+    const int tap = k0 / Cin;
+    const int ci = k0 - tap * Cin + kc;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int iy = oy[q] + kh - 1, ix = ox[q] + kw - 1;
+      const bool ok = rvalid[q] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      if (ok) {
+        const int64_t off = ((int64_t)(pix[q] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci;
+        reg[q] = *(const u32x4_t*)(base + off);
+      } else {
+        reg[q] = zero4();
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* s, const u32x4_t (&reg)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(u32x4_t*)(s + ((tid >> 3) + 32 * q) * RS_KMAJOR + (tid & 7) * 16) = reg[q];
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Fragment reads: one 16-byte chunk per lane = 8 bf16 (k = 16s+8h+e) or 4 f32 (k = 8s+4h+e)
+// for tile row `row` (tile-local, already includes lane&31).
+// ---------------------------------------------------------------------------
+template <typename T, int MODE, bool TRSAFE>
+struct FragReader;
+
+template <typename T, bool TRSAFE>
+struct FragReader<T, FFVC_OP_KMAJOR, TRSAFE> {
+  static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
+    return *(const u32x4_t*)(s + row * RS_KMAJOR + (2 * sub + (lane >> 5)) * 16);
+  }
+};
+template <typename T, bool TRSAFE>
+struct FragReader<T, FFVC_OP_CONV3X3, TRSAFE> : FragReader<T, FFVC_OP_KMAJOR, TRSAFE> {};
+
+template <>
+struct FragReader<uint16_t, FFVC_OP_TRANS, false> {
+  // ds_read_b64_tr_b16: within a 16-lane group, lane 4j+q supplies 4 consecutive bf16 of k-row j
+  // (columns 4q..4q+3); lane c receives column c of that 4x16 block (rows j = 0..3).
+  static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
+    constexpr int RS = GemmTraits<uint16_t>::RS_TRANS;
+    const int c = lane & 15;
+    const int rowbase = row - (lane & 31);
+    const int i = rowbase + 16 * ((lane >> 4) & 1) + (c & 3) * 4;
+    const int k = 16 * sub + 8 * (lane >> 5) + (c >> 2);
+    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+    const unsigned char* a0 = s + k * RS + i * 2;
+    s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+    s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * RS));
+    union {
+      s16x4_t h[2];
+      u32x4_t v;
+    } u;
+    u.h[0] = r0;
+    u.h[1] = r1;
+    return u.v;
+  }
+};
+template <>
+struct FragReader<uint16_t, FFVC_OP_TRANS, true> {
+  static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
+    constexpr int RS = GemmTraits<uint16_t>::RS_TRANS;
+    union {
+      uint16_t e[8];
+      u32x4_t v;
+    } u;
+    const int kb = 16 * sub + 8 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u.e[e] = *(const uint16_t*)(s + (kb + e) * RS + row * 2);
+    return u.v;
+  }
+};
+template <bool TRSAFE>
+struct FragReader<float, FFVC_OP_TRANS, TRSAFE> {
+  static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
+    constexpr int RS = GemmTraits<float>::RS_TRANS;
+    const int kb = 8 * sub + 4 * (lane >> 5);
+    u32x4_t v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = *(const uint32_t*)(s + (kb + e) * RS + row * 4);
+    return v;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b);
+template <>
+__device__ __forceinline__ void mma_chunk<uint16_t>(f32x16_t& acc, const u32x4_t& a,
+                                                    const u32x4_t& b) {
+  union {
+    u32x4_t u;
+    bf16x8_t h;
+  } ua, ub;
+  ua.u = a;
+  ub.u = b;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0,
+                                               0, 0);
+}
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+  if (act == FFVC_ACT_GELU) return act_gelu(v);
+  if (act == FFVC_ACT_QUICKGELU) return act_quickgelu(v);
+  return v;
+}
+__device__ __forceinline__ float apply_act_grad(int act, float pre) {
+  if (act == FFVC_ACT_GELU) return act_gelu_grad(pre);
+  if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad(pre);
+  return 1.0f;
+}
+
+template <typename T, int XMODE, int WMODE, bool TRSAFE>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, int tiles_n,
+                                                        int n_tiles, int ksplit_len, int vec_ok) {
+  using Tr = GemmTraits<T>;
+  constexpr int BK = Tr::BK;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  unsigned char* sX = smem;
+  unsigned char* sW = smem + TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // XCD-aware bijective remap of the workgroup id (8 XCDs, round-robin dispatch).
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+
+  const int k_begin = blockIdx.z * ksplit_len;
+  const int k_end = min(p.K, k_begin + ksplit_len);
+
+  const T* xb = (const T*)p.x + zo * p.xbo + zi * p.xbi;
+  const T* wb = (const T*)p.w + zo * p.wbo + zi * p.wbi;
+
+  Stager<T, XMODE> sx;
+  Stager<T, WMODE> sw;
+  if constexpr (XMODE == FFVC_OP_CONV3X3)
+    sx.init(xb, 0, m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0,
+            tid);
+  else
+    sx.init(xb, p.ldx, m0, p.M, p.kseg, p.xkso, tid);
+  sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid);
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  u32x4_t rx[4], rw[4];
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk > 0) {
+    sx.load(rx, k_begin, k_end);
+    sw.load(rw, k_begin, k_end);
+    sx.store(sX, rx, tid);
+    sw.store(sW, rw, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      sx.load(rx, k_begin + (kt + 1) * BK, k_end);
+      sw.load(rw, k_begin + (kt + 1) * BK, k_end);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      u32x4_t fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = FragReader<T, WMODE, TRSAFE>::read(sW, wn * 64 + t * 32 + l31, sub, lane);
+        fb[t] = FragReader<T, XMODE, TRSAFE>::read(sX, wm * 64 + t * 32 + l31, sub, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) mma_chunk<T>(acc[a][b], fa[a], fb[b]);
+    }
+    __syncthreads();
+    if (more) {
+      sx.store(sX, rx, tid);
+      sw.store(sW, rw, tid);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane holds, per (nt, mt, q), 4 consecutive n for one m --------------------
+  const int flags = p.flags;
+  const bool out_f32 = flags & FFVC_F_OUT_F32;
+  const bool res_f32 = flags & FFVC_F_RES_F32;
+  const bool atomic_out = flags & FFVC_F_ATOMIC_OUT;
+  const int64_t ybz = zo * p.ybo + zi * p.ybi;
+  const int64_t rbz = zo * p.rbo + zi * p.rbi;
+  const int64_t abz = zo * p.abo + zi * p.abi;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + wm * 64 + mt * 32 + l31;
+    if (m >= p.M) continue;
+    const int64_t yrow = ybz + (p.y_mi ? (int64_t)(m / p.y_mi) * p.y_so + (int64_t)(m % p.y_mi) * p.y_sm
+                                       : (int64_t)m * p.y_sm);
+    const int64_t rrow = rbz + (p.r_mi ? (int64_t)(m / p.r_mi) * p.r_so + (int64_t)(m % p.r_mi) * p.r_sm
+                                       : (int64_t)m * p.r_sm);
+    const int64_t arow = abz + (int64_t)m * p.ldaux;
+    const float bias_m = (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) ? p.bias[m] : 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
+        if (n >= p.N) continue;
+        f32x4_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
+        const bool full = vec_ok && (n + 3 < p.N);
+        if (full) {
+          if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
+            const f32x4_t bv = *(const f32x4_t*)(p.bias + n);
+            v += bv;
+          }
+          if (flags & FFVC_F_MUL_ACT_GRAD) {
+            const f32x4_t pre = load4((const T*)p.aux + arow + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad(p.act, pre[j]);
+          } else if (p.act != FFVC_ACT_NONE) {
+            if (flags & FFVC_F_WRITE_PREACT) store4((T*)p.aux + arow + n, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(p.act, v[j]);
+          }
+          if (p.residual) {
+            const f32x4_t rv = res_f32 ? load4((const float*)p.residual + rrow + n)
+                                       : load4((const T*)p.residual + rrow + n);
+            v += rv;
+          }
+          if (atomic_out) {
+            float* yp = (float*)p.y + yrow + n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(yp + j, v[j]);
+          } else if (out_f32) {
+            store4((float*)p.y + yrow + n, v);
+          } else {
+            store4((T*)p.y + yrow + n, v);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (n + j >= p.N) continue;
+            float u = v[j];
+            if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) u += p.bias[n + j];
+            if (flags & FFVC_F_MUL_ACT_GRAD) {
+              u *= apply_act_grad(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
+            } else if (p.act != FFVC_ACT_NONE) {
+              if (flags & FFVC_F_WRITE_PREACT) ElemTraits<T>::store((T*)p.aux + arow + n + j, u);
+              u = apply_act(p.act, u);
+            }
+            if (p.residual)
+              u += res_f32 ? ((const float*)p.residual)[rrow + n + j]
+                           : ElemTraits<T>::load((const T*)p.residual + rrow + n + j);
+            if (atomic_out)
+              atomicAdd((float*)p.y + yrow + n + j, u);
+            else if (out_f32)
+              ((float*)p.y)[yrow + n + j] = u;
+            else
+              ElemTraits<T>::store((T*)p.y + yrow + n + j, u);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int XMODE, int WMODE, bool TRSAFE>
+int launch(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
+  constexpr int BK = GemmTraits<T>::BK;
+  const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
+  const int n_tiles = tiles_m * tiles_n;
+  int split = d.split_k < 1 ? 1 : d.split_k;
+  int ksteps = ceil_div(d.K, BK);
+  if (split > ksteps) split = ksteps < 1 ? 1 : ksteps;
+  const int ksplit_len = ceil_div(ksteps, split) * BK;
+  split = ceil_div(d.K, ksplit_len);
+  if (split < 1) split = 1;
+  dim3 grid(n_tiles, d.batch, split);
+  hipLaunchKernelGGL((gemm_kernel<T, XMODE, WMODE, TRSAFE>), grid, dim3(NTHREADS), 0, st, d, tiles_n,
+                     n_tiles, ksplit_len, vec_ok);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int dispatch(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
+  const bool safe = d.flags & FFVC_F_TR_SAFE;
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR)
+    return launch<T, FFVC_OP_KMAJOR, FFVC_OP_KMAJOR, false>(d, st, vec_ok);
+  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR)
+    return launch<T, FFVC_OP_CONV3X3, FFVC_OP_KMAJOR, false>(d, st, vec_ok);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS)
+    return safe ? launch<T, FFVC_OP_TRANS, FFVC_OP_TRANS, true>(d, st, vec_ok)
+                : launch<T, FFVC_OP_TRANS, FFVC_OP_TRANS, false>(d, st, vec_ok);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS)
+    return safe ? launch<T, FFVC_OP_KMAJOR, FFVC_OP_TRANS, true>(d, st, vec_ok)
+                : launch<T, FFVC_OP_KMAJOR, FFVC_OP_TRANS, false>(d, st, vec_ok);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR)
+    return safe ? launch<T, FFVC_OP_TRANS, FFVC_OP_KMAJOR, true>(d, st, vec_ok)
+                : launch<T, FFVC_OP_TRANS, FFVC_OP_KMAJOR, false>(d, st, vec_ok);
+  ffvc_set_error("ffvc_gemm: unsupported operand modes x=%d w=%d", d.x_mode, d.w_mode);
+  return FFVC_E_UNSUPPORTED;
+}
+
+inline bool mult(int64_t v, int64_t m) { return (v % m) == 0; }
+
+}  // namespace
+
+extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
+  FFVC_CHECK_ARG(dp != nullptr, "ffvc_gemm: null descriptor");
+  ffvc_gemm_desc d = *dp;
+  FFVC_CHECK_ARG(d.x && d.w && d.y, "ffvc_gemm: null operand pointer");
+  FFVC_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ffvc_gemm: bad dims M=%d N=%d K=%d", d.M, d.N, d.K);
+  FFVC_CHECK_ARG(d.in_dtype == FFVC_BF16 || d.in_dtype == FFVC_F32, "ffvc_gemm: bad dtype %d",
+                 d.in_dtype);
+  if (d.batch < 1) d.batch = 1;
+  if (d.batch_inner < 1) d.batch_inner = 1;
+  FFVC_CHECK_ARG(d.batch <= 65535, "ffvc_gemm: batch %d > 65535", d.batch);
+  if (d.split_k < 1) d.split_k = 1;
+  FFVC_CHECK_ARG(d.split_k == 1 || (d.flags & FFVC_F_ATOMIC_OUT),
+                 "ffvc_gemm: split_k>1 needs FFVC_F_ATOMIC_OUT");
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_ATOMIC_OUT) || (d.flags & FFVC_F_OUT_F32),
+                 "ffvc_gemm: atomic output must be fp32");
+  FFVC_CHECK_ARG(!((d.flags & (FFVC_F_WRITE_PREACT | FFVC_F_MUL_ACT_GRAD)) && !d.aux),
+                 "ffvc_gemm: aux pointer required by flags");
+  const int es = d.in_dtype == FFVC_BF16 ? 2 : 4;
+  const int epc = 16 / es;
+  const int bk = 128 / es;
+  if (d.kseg == d.K) d.kseg = 0;
+  if (d.kseg) {
+    FFVC_CHECK_ARG(d.x_mode != FFVC_OP_TRANS && d.w_mode != FFVC_OP_TRANS,
+                   "ffvc_gemm: kseg only for K-major operands");
+    FFVC_CHECK_ARG(mult(d.kseg, bk) && mult(d.K, d.kseg), "ffvc_gemm: kseg=%d must divide K and be a multiple of %d",
+                   d.kseg, bk);
+    FFVC_CHECK_ARG(mult(d.xkso, epc) && mult(d.wkso, epc), "ffvc_gemm: unaligned k-segment stride");
+  }
+  if (d.x_mode == FFVC_OP_CONV3X3) {
+    FFVC_CHECK_ARG(d.conv_Cin > 0 && mult(d.conv_Cin, bk), "ffvc_gemm: conv Cin=%d must be a multiple of %d",
+                   d.conv_Cin, bk);
+    FFVC_CHECK_ARG(d.K == 9 * d.conv_Cin, "ffvc_gemm: conv K must be 9*Cin");
+    FFVC_CHECK_ARG(d.conv_H > 0 && d.conv_W > 0 && mult(d.M, (int64_t)d.conv_H * d.conv_W),
+                   "ffvc_gemm: conv M must be B*H*W");
+    if (d.flags & FFVC_F_UPSAMPLE2X)
+      FFVC_CHECK_ARG(!(d.conv_H & 1) && !(d.conv_W & 1), "ffvc_gemm: upsampled conv needs even H,W");
+    FFVC_CHECK_ARG(d.kseg == 0, "ffvc_gemm: kseg unsupported for conv");
+  } else {
+    FFVC_CHECK_ARG(mult(d.ldx, epc), "ffvc_gemm: ldx=%lld must be a multiple of %d", (long long)d.ldx, epc);
+  }
+  FFVC_CHECK_ARG(mult(d.ldw, epc), "ffvc_gemm: ldw=%lld must be a multiple of %d", (long long)d.ldw, epc);
+  FFVC_CHECK_ARG(mult((int64_t)(uintptr_t)d.x, 16) && mult((int64_t)(uintptr_t)d.w, 16),
+                 "ffvc_gemm: operand base pointers must be 16-byte aligned");
+  FFVC_CHECK_ARG(mult(d.xbo, epc) && mult(d.xbi, epc) && mult(d.wbo, epc) && mult(d.wbi, epc),
+                 "ffvc_gemm: operand batch strides must be multiples of %d", epc);
+  if (d.y_sm == 0 && d.y_mi == 0) d.y_sm = d.N;
+  // vectorised epilogue only when every row offset keeps 16-byte (fp32) / 8-byte (bf16) alignment
+  int vec_ok = mult(d.y_sm, 4) && mult(d.y_so, 4) && mult(d.ybo, 4) && mult(d.ybi, 4) &&
+               mult((int64_t)(uintptr_t)d.y, 16);
+  if (d.residual)
+    vec_ok = vec_ok && mult(d.r_sm, 4) && mult(d.r_so, 4) && mult(d.rbo, 4) && mult(d.rbi, 4) &&
+             mult((int64_t)(uintptr_t)d.residual, 16);
+  if (d.aux)
+    vec_ok = vec_ok && mult(d.ldaux, 4) && mult(d.abo, 4) && mult(d.abi, 4) &&
+             mult((int64_t)(uintptr_t)d.aux, 16);
+  if (d.bias && !(d.flags & FFVC_F_BIAS_ALONG_M)) vec_ok = vec_ok && mult((int64_t)(uintptr_t)d.bias, 16);
+  hipStream_t st = (hipStream_t)stream;
+  if (d.in_dtype == FFVC_BF16) return dispatch<uint16_t>(d, st, vec_ok);
+  return dispatch<float>(d, st, vec_ok);
+}

@@ -1,0 +1,179 @@
+"""GPU parity of ffvc_gemm (every operand mode / dtype / epilogue) against fp64 torch math.
+
+Tolerances: with fp32 output the only error is accumulation order (<= 2e-5 rel for bf16
+inputs rounded beforehand, 2e-5 for fp32 MFMA); with bf16 output one extra rounding (2^-8).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from feed_forward_vqgan_clip_amd import kernels as K  # noqa: E402
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+def _mk(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+DT = [torch.bfloat16, torch.float32]
+
+
+def test_probe_tr16(cuda):
+    t = K.probe_tr16()
+    # documented semantic: lane 16g+c, elem j <- source lane 16g + 4j + (c>>2), elem (c&3); source lane s holds 4s..4s+3
+    exp = torch.empty(64, 4, dtype=torch.int16)
+    for lane in range(64):
+        g, c = lane // 16, lane % 16
+        for j in range(4):
+            src_lane = 16 * g + 4 * j + (c >> 2)
+            exp[lane, j] = 4 * src_lane + (c & 3)
+    print("tr16 probe lanes 0..19:\n", t[:20])
+    assert torch.equal(t, exp), f"ds_read_b64_tr_b16 semantic differs:\n{t}"
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K_", [(300, 200, 136), (128, 128, 64), (1024, 512, 1024), (65, 3, 72)])
+def test_nt_bias_f32out(cuda, dt, M, N, K_):
+    x, w = _mk((M, K_), dt, cuda, 1), _mk((N, K_), dt, cuda, 2)
+    b = _mk((N,), torch.float32, cuda, 3)
+    y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_, bias=b)
+    ref = x.double() @ w.double().T + b.double()
+    assert _rel(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_nt_act_preact_residual(cuda, dt):
+    M, N, K_ = 384, 256, 192
+    x, w = _mk((M, K_), dt, cuda, 1, 0.5), _mk((N, K_), dt, cuda, 2, 0.2)
+    b = _mk((N,), torch.float32, cuda, 3)
+    res = _mk((M, N), torch.float32, cuda, 4)
+    for act, fn in [(K.ACT_GELU, lambda t: F.gelu(t)), (K.ACT_QUICKGELU, lambda t: t * torch.sigmoid(1.702 * t))]:
+        y = torch.empty(M, N, dtype=dt, device=cuda)
+        aux = torch.empty(M, N, dtype=dt, device=cuda)
+        K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_, bias=b, residual=res, aux=aux, ldaux=N, act=act,
+               flags=K.F_WRITE_PREACT)
+        pre = x.double() @ w.double().T + b.double()
+        ref = fn(pre) + res.double()
+        tol = 1e-2 if dt == torch.bfloat16 else 2e-5
+        assert _rel(aux, pre) < tol
+        assert _rel(y, ref) < tol
+        # backward-of-activation epilogue: dy @ w2 * act'(pre)
+        dy, w2 = _mk((M, K_), dt, cuda, 5), _mk((N, K_), dt, cuda, 6, 0.2)
+        g = torch.empty(M, N, dtype=dt, device=cuda)
+        K.gemm(dy, w2, g, M, N, K_, ldx=K_, ldw=K_, aux=aux, ldaux=N, act=act, flags=K.F_MUL_ACT_GRAD)
+        p = aux.double().requires_grad_(True)
+        fn(p).sum().backward()
+        gref = (dy.double() @ w2.double().T) * p.grad
+        assert _rel(g, gref) < tol
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("safe", [False, True])
+@pytest.mark.parametrize("M,N,K_", [(256, 384, 1000), (128, 128, 64), (200, 72, 130)])
+def test_tn_wgrad(cuda, dt, safe, M, N, K_):
+    # y[m,n] = sum_k xt[k,m] wt[k,n]  (both operands stored reduction-major)
+    xt, wt = _mk((K_, M), dt, cuda, 1), _mk((K_, N), dt, cuda, 2)
+    y = torch.zeros(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(xt, wt, y, M, N, K_, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
+           flags=K.F_TR_SAFE if safe else 0)
+    ref = xt.double().T @ wt.double()
+    assert _rel(y, ref) < 2e-5
+    # split-K with atomics accumulates on top of existing contents
+    y2 = torch.ones(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(xt, wt, y2, M, N, K_, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
+           flags=K.F_ATOMIC_OUT | (K.F_TR_SAFE if safe else 0), split_k=4)
+    assert _rel(y2, ref + 1.0) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("safe", [False, True])
+def test_nn_and_tk(cuda, dt, safe):
+    M, N, K_ = 192, 320, 200
+    fl = K.F_TR_SAFE if safe else 0
+    x, wt = _mk((M, K_), dt, cuda, 1), _mk((K_, N), dt, cuda, 2)
+    y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(x, wt, y, M, N, K_, ldx=K_, ldw=N, w_mode=K.OP_TRANS, flags=fl)
+    assert _rel(y, x.double() @ wt.double()) < 2e-5
+    xt, w = _mk((K_, M), dt, cuda, 3), _mk((N, K_), dt, cuda, 4)
+    K.gemm(xt, w, y, M, N, K_, ldx=M, ldw=K_, x_mode=K.OP_TRANS, flags=fl)
+    assert _rel(y, xt.double().T @ w.double().T) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_batched_maps_kseg(cuda, dt):
+    # token-mix form: out[b][o, d] = sum_t W[o,t] xn[b][t,d] + bias[o] + res[b][o,d]
+    B, T, D, O = 3, 64, 96, 160
+    Wm, xn = _mk((O, T), dt, cuda, 1), _mk((B, T, D), dt, cuda, 2)
+    bias = _mk((O,), torch.float32, cuda, 3)
+    res = _mk((B, O, D), torch.float32, cuda, 4)
+    out = torch.empty(B, O, D, dtype=torch.float32, device=cuda)
+    K.gemm(Wm, xn, out, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, bias=bias, flags=K.F_BIAS_ALONG_M,
+           residual=res, batch=B, wb=(T * D, 0), yb=(O * D, 0), rb=(O * D, 0))
+    ref = torch.einsum("ot,btd->bod", Wm.double(), xn.double()) + bias.double()[None, :, None] + res.double()
+    assert _rel(out, ref) < 2e-5
+    # segmented-K wgrad of the same op: dW[o,t] = sum_{b,d} dy[b][o,d] xn[b][t,d]
+    bk = 64 if dt == torch.bfloat16 else 32
+    D2 = 2 * bk
+    dy, x2 = _mk((B, O, D2), dt, cuda, 5), _mk((B, T, D2), dt, cuda, 6)
+    dW = torch.zeros(O, T, dtype=torch.float32, device=cuda)
+    K.gemm(dy, x2, dW, O, T, B * D2, ldx=D2, ldw=D2, kseg=D2, xkso=O * D2, wkso=T * D2,
+           flags=K.F_ATOMIC_OUT, split_k=3)
+    assert _rel(dW, torch.einsum("bod,btd->ot", dy.double(), x2.double())) < 2e-5
+    # two-level batch + output row map (attention-like head split): y[b, t, h, :] = q[b,t,h,:] @ k[b,s,h,:]^T
+    Bq, H, Tq, dh = 2, 3, 50, 64
+    qkv = _mk((Bq, Tq, 3 * H * dh), dt, cuda, 7)
+    S = torch.empty(Bq * H, Tq, 64, dtype=torch.float32, device=cuda).fill_(-7.0)
+    q = qkv[:, :, :H * dh]
+    kk = qkv[:, :, H * dh:2 * H * dh]
+    K.gemm(q, kk, S, Tq, Tq, dh, ldx=3 * H * dh, ldw=3 * H * dh, batch=Bq * H, batch_inner=H,
+           xb=(Tq * 3 * H * dh, dh), wb=(Tq * 3 * H * dh, dh), yb=(H * Tq * 64, Tq * 64), y_map=(0, 0, 64),
+           alpha=0.125)
+    ref = torch.einsum("bthd,bshd->bhts", q.reshape(Bq, Tq, H, dh).double(), kk.reshape(Bq, Tq, H, dh).double()) * 0.125
+    assert _rel(S.view(Bq, H, Tq, 64)[..., :Tq], ref) < 2e-5
+    assert (S.view(Bq, H, Tq, 64)[..., Tq:] == -7.0).all()
+    # y_map with split rows: m -> (m // mi) * so + (m % mi) * sm  (ViT patch rows into [n, 1+p, :])
+    n_img, P, Wd = 4, 9, 128
+    xp, wp = _mk((n_img * P, 64), dt, cuda, 8), _mk((Wd, 64), dt, cuda, 9)
+    pos = _mk((P + 1, Wd), torch.float32, cuda, 10)
+    tok = torch.zeros(n_img, P + 1, Wd, dtype=torch.float32, device=cuda)
+    K.gemm(xp, wp, tok[:, 1:], n_img * P, Wd, 64, ldx=64, ldw=64, y_map=(P, (P + 1) * Wd, Wd),
+           residual=pos[1:], r_map=(P, 0, Wd))
+    ref = (xp.double() @ wp.double().T).view(n_img, P, Wd) + pos[1:].double()
+    assert _rel(tok[:, 1:], ref) < 2e-5
+    assert (tok[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("ups", [False, True])
+def test_conv3x3(cuda, dt, ups):
+    B, Hin, Win, Cin, Cout = 2, 6, 10, 128, 192
+    x = _mk((B, Hin, Win, Cin), dt, cuda, 1)
+    w = _mk((Cout, 3, 3, Cin), dt, cuda, 2, 0.05)
+    b = _mk((Cout,), torch.float32, cuda, 3)
+    H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
+    res = _mk((B, H, W, Cout), dt, cuda, 4)
+    y = torch.empty(B, H, W, Cout, dtype=dt, device=cuda)
+    K.gemm(x, w, y, B * H * W, Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=b, residual=res,
+           conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if ups else 0)
+    xn = x.double().permute(0, 3, 1, 2)
+    if ups:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xn, w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    assert _rel(y, ref) < (1e-2 if dt == torch.bfloat16 else 2e-5)
+
+
+def test_bad_args_raise(cuda):
+    x = torch.zeros(8, 8, dtype=torch.bfloat16, device=cuda)
+    y = torch.zeros(8, 8, dtype=torch.bfloat16, device=cuda)
+    from feed_forward_vqgan_clip_amd._lib import FFVCError
+    with pytest.raises(FFVCError):
+        K.gemm(x, x, y, 8, 8, 8, ldx=7, ldw=8)
+    with pytest.raises(FFVCError):
+        K.gemm(x, x, y, 8, 8, 8, ldx=8, ldw=8, split_k=2)
