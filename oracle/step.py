@@ -1,0 +1,122 @@
+"""Oracle (CPU fp32) restatement of the train-step glue of main.py.  TEST INFRASTRUCTURE ONLY.
+
+Autograd rules, VQ, synth, cutouts, loss and the composed step (main.py:715-837), written as
+pure functions.  Randomness of the reference (noise `U(0,.1)*N(0,1)`, main.py:202,223-225) is
+made explicit: callers pass `facs` and `noise` tensors.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import clip as oclip
+from . import vqgan as ovq
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # main.py:81
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)   # main.py:82
+
+
+class _ReplaceGrad(torch.autograd.Function):       # main.py:105-116
+    @staticmethod
+    def forward(ctx, x_forward, x_backward):
+        ctx.shape = x_backward.shape
+        return x_forward
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g.sum_to_size(ctx.shape)
+
+
+class _ClampWithGrad(torch.autograd.Function):     # main.py:118-132
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.lo, ctx.hi = lo, hi
+        ctx.save_for_backward(x)
+        return x.clamp(lo, hi)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        # pass the gradient unless it would push an out-of-range value further out
+        return g * (g * (x - x.clamp(ctx.lo, ctx.hi)) >= 0), None, None
+
+
+replace_grad = _ReplaceGrad.apply
+clamp_with_grad = _ClampWithGrad.apply
+
+
+def vq_indices(x, codebook):
+    """argmin_j ||x - c_j||^2 as written at main.py:135-136 (first index on ties)."""
+    d = x.pow(2).sum(dim=-1, keepdim=True) + codebook.pow(2).sum(dim=1) - 2 * x @ codebook.T
+    return d.argmin(-1)
+
+
+def vector_quantize(x, codebook):
+    """main.py:134-138: nearest code, straight-through gradient. x: (..., C)."""
+    x_q = codebook[vq_indices(x, codebook)]        # == one_hot(idx) @ codebook (main.py:137)
+    return replace_grad(x_q, x)
+
+
+def synth(vq_sd, z, cfg=ovq.F16_16384, decode_fn=None):
+    """main.py:140-143. z: (B,C,S,S) -> RGB (B,3,16S,16S) in [0,1]."""
+    z_q = vector_quantize(z.movedim(1, 3), vq_sd["quantize.embedding.weight"]).movedim(3, 1)
+    dec = decode_fn(z_q) if decode_fn is not None else ovq.decode(vq_sd, z_q, cfg)
+    return clamp_with_grad(dec.add(1).div(2), 0, 1)
+
+
+def tv_loss(y):                                    # main.py:423-428
+    return 0.5 * ((y[:, :, 1:, :] - y[:, :, :-1, :]).abs().mean() + (y[:, :, :, 1:] - y[:, :, :, :-1]).abs().mean())
+
+
+def make_cutouts(x, *, cut_size, cutn, facs=None, noise=None, pool=True, pool_size=None):
+    """main.py:212-229 with augs=['R'] (Resize -> bilinear to cut_size, main.py:145-152,199-200).
+
+    facs: (cutn*B,1,1,1) in [0, 0.1) and noise: like the output — the reference draws them
+    unseeded (main.py:223-225); None disables the noise branch (noise_fac = 0).
+    """
+    pool_size = pool_size or cut_size
+    if pool:
+        c = (F.adaptive_avg_pool2d(x, pool_size) + F.adaptive_max_pool2d(x, pool_size)) / 2   # :217
+        batch = c.repeat(cutn, 1, 1, 1)                                                        # :218
+    else:
+        batch = x.repeat(cutn, 1, 1, 1)
+    batch = F.interpolate(batch, (cut_size, cut_size), mode="bilinear")                        # augs=['R']
+    if facs is not None:
+        batch = batch + facs * noise                                                           # :224-225
+    return batch
+
+
+def spherical_loss(embed, target_feats, cutn, coef=1.0):
+    """main.py:801-811 for repeat=1: mean(2*asin(||H-E||/2)^2)."""
+    H = F.normalize(target_feats.repeat(cutn, 1), dim=-1)
+    E = F.normalize(embed, dim=1)
+    return coef * H.sub(E).norm(dim=-1).div(2).arcsin().pow(2).mul(2).mean()
+
+
+def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_size, z_min, z_max,
+                    facs=None, noise=None, vq_cfg=ovq.F16_16384, clip_heads=(None, None),
+                    pool_size=None, text_feats=None, decode_fn=None):
+    """Forward half of one training step (main.py:729-811,831) with repeat=1, noise_dim=0,
+    l2/tv/diversity coefficients 0.  Returns (loss, dict of intermediates)."""
+    if text_feats is None:
+        with torch.no_grad():
+            text_feats = oclip.encode_text(clip_sd, tokens, clip_heads[1]).float()     # main.py:733,737
+    z = mapper_fn(mapper_sd, text_feats).contiguous()                                   # :754-757
+    z = clamp_with_grad(z, z_min, z_max)                                                # :763
+    xr = synth(vq_sd, z, vq_cfg, decode_fn)                                             # :767
+    x = make_cutouts(xr, cut_size=cut_size, cutn=cutn, facs=facs, noise=noise, pool_size=pool_size)  # :796
+    mean = torch.tensor(CLIP_MEAN, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+    std = torch.tensor(CLIP_STD, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+    x = (x - mean) / std                                                                # :797
+    embed = oclip.encode_image(clip_sd, x, clip_heads[0]).float()                       # :799
+    loss = spherical_loss(embed, text_feats, cutn)                                      # :801-811
+    return loss, {"text_feats": text_feats, "z": z, "xr": xr, "embed": embed}
+
+
+def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam defaults (main.py:591) on lists of tensors, in place. `step` is 1-based."""
+    b1, b2 = betas
+    for p, g, (m, v) in zip(params, grads, state):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
