@@ -80,6 +80,40 @@ _lib = None
 # include/ffvc.h appears here and is exported by the shared object.
 _SIGNATURES = {
     "ffvc_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ffvc_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                   c_int, c_float, c_void_p]),
+    "ffvc_layernorm_bwd_blocks": (c_int, [c_int64]),
+    "ffvc_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ffvc_groupnorm_ws_bytes": (c_int64, [c_int, c_int, c_int]),
+    "ffvc_groupnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "ffvc_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_softmax_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_int, c_int,
+                                 c_void_p]),
+    "ffvc_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "ffvc_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "ffvc_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "ffvc_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "ffvc_clamp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
+    "ffvc_clamp_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                               c_void_p]),
+    "ffvc_sumpool2x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_rownorm_sq": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ffvc_vq_argmin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "ffvc_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ffvc_eot_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ffvc_cutouts_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
+    "ffvc_cutouts_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                 c_float, c_float, c_void_p]),
+    "ffvc_spherical_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                    c_void_p]),
+    "ffvc_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float,
+                          c_float, c_int, c_float, c_void_p]),
+    "ffvc_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ffvc_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ffvc_last_error": (c_char_p, []),
     "ffvc_version": (c_int, []),
     "ffvc_device_info": (c_int, [POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),

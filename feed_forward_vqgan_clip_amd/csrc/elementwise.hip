@@ -1,0 +1,608 @@
+// elementwise.hip — HBM-bound glue kernels of the train step (main.py:715-837): casts and
+// transposes, bias-gradient column sums, clamp-with-grad, VQ argmin + gather (STE), cutout
+// pooling + noise + CLIP normalisation written straight into ViT patch layout, spherical loss,
+// fused Adam.  All arithmetic fp32; coalesced 8/16-byte accesses; grid-stride loops capped at
+// ~8 workgroups per CU.
+#include "common.h"
+
+#define DISPATCH_DT(code, T, ...)   \
+  do {                              \
+    if ((code) == FFVC_BF16) {      \
+      using T = uint16_t;           \
+      __VA_ARGS__;                  \
+    } else {                        \
+      using T = float;              \
+      __VA_ARGS__;                  \
+    }                               \
+  } while (0)
+
+namespace {
+
+inline int ew_grid(int64_t n, int per_block) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+// ------------------------------- cast --------------------------------------
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void cast_kernel(const ST* __restrict__ s, DT* __restrict__ d, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    store4(d + i * 4, load4(s + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    ElemTraits<DT>::store(d + i, ElemTraits<ST>::load(s + i));
+  }
+}
+
+// ------------------------- batched 2-D transpose ---------------------------
+// dst[b][c][r] = src[b][r][c] with dtype conversion (weight shadows W^T, mixer rearrange).
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ s, DT* __restrict__ d, int rows,
+                                                        int cols, int64_t sb, int64_t db) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? ElemTraits<ST>::load(s + b * sb + (int64_t)r * cols + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) ElemTraits<DT>::store(d + b * db + (int64_t)c * rows + r, tile[tx][i]);
+  }
+}
+
+// ---------------------------- column sums ----------------------------------
+// out[c] (+)= scale * sum_r x[r, c]   (bias gradients; reduction of LayerNorm partials)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                     int cols, int64_t ld, int rows_per_block) {
+  // block = 64 columns x 4 row-lanes; gridDim.y strips of rows, atomics combine strips
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ry = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + ry; r < r1; r += 4) a += ElemTraits<T>::load(x + r * ld + c);
+  red[ry][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(out + c, t);
+  }
+}
+
+// -------------------------- clamp with grad --------------------------------
+// main.py:118-132: y = clamp(x*mul + add, lo, hi); backward passes g unless it pushes an
+// out-of-range value further out: dx = mul * g * [g * (u - clamp(u)) >= 0], u = x*mul + add.
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void clamp_fwd_kernel(const XT* __restrict__ x, YT* __restrict__ y, int64_t n,
+                                                        float mul, float add, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float u = ElemTraits<XT>::load(x + i) * mul + add;
+    ElemTraits<YT>::store(y + i, fminf(fmaxf(u, lo), hi));
+  }
+}
+template <typename XT, typename GT>
+__global__ __launch_bounds__(256) void clamp_bwd_kernel(const XT* __restrict__ x, const GT* __restrict__ g,
+                                                        XT* __restrict__ dx, int64_t n, float mul, float add,
+                                                        float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float u = ElemTraits<XT>::load(x + i) * mul + add;
+    const float gv = ElemTraits<GT>::load(g + i);
+    const float c = fminf(fmaxf(u, lo), hi);
+    ElemTraits<XT>::store(dx + i, (gv * (u - c) >= 0.f) ? gv * mul : 0.f);
+  }
+}
+
+// ------------------- 2x2 sum pool (backward of nearest 2x upsample) --------
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2_kernel(const T* __restrict__ s, T* __restrict__ d, int B, int H, int W,
+                                                       int C) {
+  // s: [B, 2H, 2W, C] -> d: [B, H, W, C]; 4 channels per thread
+  const int c4 = C >> 2;
+  const int64_t n = (int64_t)B * H * W * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    int64_t p = i / c4;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    const T* base = s + (((int64_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+    f32x4_t a = load4(base);
+    a += load4(base + C);
+    a += load4(base + (int64_t)2 * W * C);
+    a += load4(base + (int64_t)2 * W * C + C);
+    store4(d + (((int64_t)b * H + y) * W + x) * C + c, a);
+  }
+}
+
+// ------------------------------- VQ ----------------------------------------
+// row squared norms (||c_j||^2 once for the frozen codebook, ||x_i||^2 per step)
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                      int dim) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    float a = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+      const float v = x[r * dim + i];
+      a += v * v;
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[r] = a;
+  }
+}
+// idx[i] = argmin_j (xn[i] + cn[j]) - 2 * dot[i, j]   — same fp32 expression order as
+// main.py:135 `x.pow(2).sum + codebook.pow(2).sum - 2 * x @ codebook.T`; first index wins ties (:136).
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ dot, const float* __restrict__ xn,
+                                                        const float* __restrict__ cn, int64_t* __restrict__ idx,
+                                                        int64_t rows, int ncodes, int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    const float x2 = xn[r];
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < ncodes; j += 64) {
+      const float d = (x2 + cn[j]) - 2.0f * dot[r * ld + j];
+      if (d < best) {
+        best = d;
+        bi = j;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob < best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (lane == 0) idx[r] = bi;
+  }
+}
+// out[r, :] = table[idx[r], :] (+ pos[r % period, :])  — codebook gather (== one_hot @ codebook,
+// main.py:137), token embedding + positional embedding (cloob.py:526-528).
+template <typename DT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
+                                                          const int64_t* __restrict__ idx, const float* __restrict__ pos,
+                                                          int period, DT* __restrict__ out, int64_t rows, int dim) {
+  const int64_t n = rows * dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    float v = table[idx[r] * dim + c];
+    if (pos) v += pos[(r % period) * dim + c];
+    ElemTraits<DT>::store(out + i, v);
+  }
+}
+// out[b, :] = x[b, argmax_t tok[b, t], :]   (EOT pooling, cloob.py:536)
+template <typename XT>
+__global__ __launch_bounds__(64) void eot_gather_kernel(const XT* __restrict__ x, const int64_t* __restrict__ tok,
+                                                        float* __restrict__ out, int L, int dim) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int64_t best = INT64_MIN;
+  int bi = 0x7fffffff;
+  for (int t = lane; t < L; t += 64) {
+    const int64_t v = tok[(int64_t)b * L + t];
+    if (v > best) {
+      best = v;
+      bi = t;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int64_t ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+  }
+  for (int c = lane; c < dim; c += 64) out[(int64_t)b * dim + c] = ElemTraits<XT>::load(x + ((int64_t)b * L + bi) * dim + c);
+}
+
+// ------------------------------ cutouts ------------------------------------
+// main.py:212-229 (pool branch, augs=['R'] at pool_size == cut_size) fused with :797:
+//   c = (AdaptiveAvgPool(x) + AdaptiveMaxPool(x)) / 2 ; repeat cutn (cut-major) ;
+//   + facs[n] * noise[n] ; (v - mean[ch]) / std[ch]
+// and written directly as ViT patch rows: out[n, py*gw+px, ch*P*P + ky*P + kx] (the im2col of the
+// stride-P patch-embedding conv, cloob.py:224,237), so the patch GEMM reads it K-major.
+// xr is NHWC fp32 [B, H, W, 3]; noise is NCHW [cutn*B, 3, cut, cut] fp32 or NULL.
+__device__ __forceinline__ int apool_start(int o, int in, int out) { return (int)(((int64_t)o * in) / out); }
+__device__ __forceinline__ int apool_end(int o, int in, int out) { return (int)((((int64_t)(o + 1)) * in + out - 1) / out); }
+
+template <typename OT>
+__global__ __launch_bounds__(256) void cutouts_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ noise,
+                                                          const float* __restrict__ facs, OT* __restrict__ out, int B,
+                                                          int H, int W, int cut, int cutn, int P, float m0, float m1,
+                                                          float m2, float s0, float s1, float s2) {
+  const int gw = cut / P;
+  const int64_t n = (int64_t)B * 3 * cut * cut;
+  const int64_t per_img = (int64_t)3 * cut * cut;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % cut);
+    int64_t t = i / cut;
+    const int oy = (int)(t % cut);
+    t /= cut;
+    const int ch = (int)(t % 3);
+    const int b = (int)(t / 3);
+    const int y0 = apool_start(oy, H, cut), y1 = apool_end(oy, H, cut);
+    const int x0 = apool_start(ox, W, cut), x1 = apool_end(ox, W, cut);
+    float sum = 0.f, mx = -INFINITY;
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const float v = xr[(((int64_t)b * H + y) * W + x) * 3 + ch];
+        sum += v;
+        mx = fmaxf(mx, v);
+      }
+    const float pooled = (sum / (float)((y1 - y0) * (x1 - x0)) + mx) * 0.5f;
+    const float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+    const float istd = 1.0f / (ch == 0 ? s0 : (ch == 1 ? s1 : s2));
+    const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+    const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)ch * P * P + ky * P + kx;
+    for (int c = 0; c < cutn; ++c) {
+      const int64_t nimg = (int64_t)c * B + b;
+      float v = pooled;
+      if (noise) v += facs[nimg] * noise[nimg * per_img + ((int64_t)ch * cut + oy) * cut + ox];
+      ElemTraits<OT>::store(out + nimg * per_img + prow, (v - mean) * istd);
+    }
+  }
+}
+
+// dxr[b, y, x, ch] = sum over cuts and over the pooling windows containing (y, x) of
+//   g/std * (0.5/|win| + 0.5*[argmax == (y,x)])    (first max in row-major order, torch semantics)
+template <typename GT>
+__global__ __launch_bounds__(256) void cutouts_bwd_kernel(const float* __restrict__ xr, const GT* __restrict__ gout,
+                                                          float* __restrict__ dxr, int B, int H, int W, int cut,
+                                                          int cutn, int P, float s0, float s1, float s2) {
+  const int gw = cut / P;
+  const int64_t n = (int64_t)B * H * W * 3;
+  const int64_t per_img = (int64_t)3 * cut * cut;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % 3);
+    int64_t t = i / 3;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const float istd = 1.0f / (ch == 0 ? s0 : (ch == 1 ? s1 : s2));
+    float acc = 0.f;
+    const int oyc = (int)(((int64_t)y * cut) / H), oxc = (int)(((int64_t)x * cut) / W);
+    for (int oy = max(0, oyc - 1); oy <= min(cut - 1, oyc + 1); ++oy) {
+      const int y0 = apool_start(oy, H, cut), y1 = apool_end(oy, H, cut);
+      if (y < y0 || y >= y1) continue;
+      for (int ox = max(0, oxc - 1); ox <= min(cut - 1, oxc + 1); ++ox) {
+        const int x0 = apool_start(ox, W, cut), x1 = apool_end(ox, W, cut);
+        if (x < x0 || x >= x1) continue;
+        // locate the (first) argmax of this window
+        float mx = -INFINITY;
+        int ay = y0, ax = x0;
+        for (int yy = y0; yy < y1; ++yy)
+          for (int xx = x0; xx < x1; ++xx) {
+            const float v = xr[(((int64_t)b * H + yy) * W + xx) * 3 + ch];
+            if (v > mx) {
+              mx = v;
+              ay = yy;
+              ax = xx;
+            }
+          }
+        float w = 0.5f / (float)((y1 - y0) * (x1 - x0));
+        if (ay == y && ax == x) w += 0.5f;
+        const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+        const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)ch * P * P + ky * P + kx;
+        float g = 0.f;
+        for (int c = 0; c < cutn; ++c) g += ElemTraits<GT>::load(gout + ((int64_t)c * B + b) * per_img + prow);
+        acc += g * w;
+      }
+    }
+    dxr[i] = acc * istd;
+  }
+}
+
+// --------------------------- spherical loss --------------------------------
+// main.py:801-811: H = normalize(feats[n % B]); E = normalize(embed[n]);
+// loss = coef * mean_n 2*asin(|H-E|/2)^2.  One wave per row; writes per-row terms, a second tiny
+// kernel sums them deterministically.  The backward kernel emits d loss / d embed.
+__global__ __launch_bounds__(256) void sph_loss_rows_kernel(const float* __restrict__ embed, const float* __restrict__ feats,
+                                                            float* __restrict__ rowloss, float* __restrict__ dembed,
+                                                            int N, int B, int D, float coef) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+    const float* e = embed + (int64_t)n * D;
+    const float* h = feats + (int64_t)(n % B) * D;
+    float ee = 0.f, hh = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      ee += e[i] * e[i];
+      hh += h[i] * h[i];
+    }
+    const float en = fmaxf(sqrtf(wave_sum(ee)), 1e-12f), hn = fmaxf(sqrtf(wave_sum(hh)), 1e-12f);
+    float dd = 0.f, eg = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      const float df = h[i] / hn - e[i] / en;
+      dd += df * df;
+    }
+    const float d = sqrtf(wave_sum(dd));
+    const float a = asinf(d * 0.5f);
+    if (lane == 0) rowloss[n] = 2.0f * a * a;
+    if (dembed) {
+      // dl/dd = 2 a / sqrt(1 - d^2/4);  dd/dE = -(H-E)/d;  then through E = e/|e|
+      const float dl = (d > 0.f) ? (2.0f * a / sqrtf(fmaxf(1.0f - 0.25f * d * d, 1e-20f))) / d : 0.f;
+      const float k = coef / (float)N * dl;
+      for (int i = lane; i < D; i += 64) {
+        const float E = e[i] / en;
+        const float gE = -k * (h[i] / hn - E);
+        eg += gE * E;
+      }
+      eg = wave_sum(eg);
+      for (int i = lane; i < D; i += 64) {
+        const float E = e[i] / en;
+        const float gE = -k * (h[i] / hn - E);
+        dembed[(int64_t)n * D + i] = (gE - E * eg) / en;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ v, float* __restrict__ out, int n,
+                                                        float scale) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+
+// ------------------------------- Adam --------------------------------------
+// torch.optim.Adam defaults (main.py:591) over a flat fp32 bucket; optionally refreshes the
+// low-precision weight shadow the GEMMs read (same layout) in the same pass.
+template <typename ST>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, ST* __restrict__ shadow,
+                                                   int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                                                   float bc2_sqrt, float gscale) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4_t pv = load4(p + i * 4), gv = load4(g + i * 4), mv = load4(m + i * 4), vv = load4(v + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * gscale;
+      mv[j] = b1 * mv[j] + (1.0f - b1) * gg;
+      vv[j] = b2 * vv[j] + (1.0f - b2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pv[j] -= (lr / bc1) * (mv[j] / denom);
+    }
+    store4(p + i * 4, pv);
+    store4(m + i * 4, mv);
+    store4(v + i * 4, vv);
+    if (shadow) store4(shadow + i * 4, pv);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.0f - b1) * gg;
+    const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+    const float pp = p[i] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = pp;
+    if (shadow) ElemTraits<ST>::store(shadow + i, pp);
+  }
+}
+
+// sum of squares of a flat buffer -> out[0] (+=), for global-norm gradient clipping (main.py:833-834)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += x[i] * x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// y = a*x + b*y elementwise over fp32 (gradient accumulation / scaling plumbing)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float a,
+                                                    float b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+}  // namespace
+
+extern "C" int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(src && dst && n > 0, "ffvc_cast: bad args");
+  FFVC_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "ffvc_cast: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(src_dtype, ST, DISPATCH_DT(dst_dtype, DT,
+              hipLaunchKernelGGL((cast_kernel<ST, DT>), dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, st,
+                                 (const ST*)src, (DT*)dst, n)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int batch, int rows, int cols,
+                              int64_t src_batch_stride, int64_t dst_batch_stride, void* stream) {
+  FFVC_CHECK_ARG(src && dst && batch > 0 && batch <= 65535 && rows > 0 && cols > 0, "ffvc_transpose: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64), batch);
+  FFVC_CHECK_ARG(grid.y <= 65535, "ffvc_transpose: too many rows");
+  DISPATCH_DT(src_dtype, ST, DISPATCH_DT(dst_dtype, DT,
+              hipLaunchKernelGGL((transpose_kernel<ST, DT>), grid, dim3(256), 0, st, (const ST*)src, (DT*)dst, rows,
+                                 cols, src_batch_stride, dst_batch_stride)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, int64_t ld, int accumulate,
+                           void* stream) {
+  FFVC_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "ffvc_colsum: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), st);
+    if (e != hipSuccess) {
+      ffvc_set_error("ffvc_colsum: memset failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  int strips = (int)((rows + 511) / 512);
+  if (strips > 512) strips = 512;
+  const int rpb = (int)((rows + strips - 1) / strips);
+  dim3 grid(ceil_div(cols, 64), ceil_div(rows, rpb));
+  DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, cols,
+                                           ld, rpb));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_clamp_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, float mul, float add, float lo,
+                              float hi, void* stream) {
+  FFVC_CHECK_ARG(x && y && n > 0, "ffvc_clamp_fwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(x_dtype, XT, DISPATCH_DT(y_dtype, YT,
+              hipLaunchKernelGGL((clamp_fwd_kernel<XT, YT>), dim3(ew_grid(n, 1024)), dim3(256), 0, st, (const XT*)x,
+                                 (YT*)y, n, mul, add, lo, hi)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_clamp_bwd(const void* x, int x_dtype, const void* g, int g_dtype, void* dx, int64_t n, float mul,
+                              float add, float lo, float hi, void* stream) {
+  FFVC_CHECK_ARG(x && g && dx && n > 0, "ffvc_clamp_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(x_dtype, XT, DISPATCH_DT(g_dtype, GT,
+              hipLaunchKernelGGL((clamp_bwd_kernel<XT, GT>), dim3(ew_grid(n, 1024)), dim3(256), 0, st, (const XT*)x,
+                                 (const GT*)g, (XT*)dx, n, mul, add, lo, hi)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_sumpool2x2(const void* src, void* dst, int dtype, int B, int H, int W, int C, void* stream) {
+  FFVC_CHECK_ARG(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "ffvc_sumpool2x2: bad args (C=%d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * H * W * (C / 4);
+  DISPATCH_DT(dtype, T, hipLaunchKernelGGL((sumpool2_kernel<T>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
+                                           (const T*)src, (T*)dst, B, H, W, C));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_rownorm_sq(const float* x, float* out, int64_t rows, int dim, void* stream) {
+  FFVC_CHECK_ARG(x && out && rows > 0 && dim > 0, "ffvc_rownorm_sq: bad args");
+  hipLaunchKernelGGL(rownorm_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, out, rows, dim);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_vq_argmin(const float* dot, const float* xnorm, const float* cnorm, int64_t* idx, int64_t rows,
+                              int ncodes, int64_t ld, void* stream) {
+  FFVC_CHECK_ARG(dot && xnorm && cnorm && idx && rows > 0 && ncodes > 0 && ld >= ncodes, "ffvc_vq_argmin: bad args");
+  hipLaunchKernelGGL(vq_argmin_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, dot, xnorm, cnorm,
+                     idx, rows, ncodes, ld);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_gather_rows(const float* table, const int64_t* idx, const float* pos, int period, void* out,
+                                int out_dtype, int64_t rows, int dim, void* stream) {
+  FFVC_CHECK_ARG(table && idx && out && rows > 0 && dim > 0, "ffvc_gather_rows: bad args");
+  FFVC_CHECK_ARG(!pos || period > 0, "ffvc_gather_rows: pos needs period");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(out_dtype, DT, hipLaunchKernelGGL((gather_rows_kernel<DT>), dim3(ew_grid(rows * dim, 1024)), dim3(256), 0,
+                                                st, table, idx, pos, period > 0 ? period : 1, (DT*)out, rows, dim));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_eot_gather(const void* x, int x_dtype, const int64_t* tokens, float* out, int B, int L, int dim,
+                               void* stream) {
+  FFVC_CHECK_ARG(x && tokens && out && B > 0 && L > 0 && dim > 0, "ffvc_eot_gather: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(x_dtype, XT, hipLaunchKernelGGL((eot_gather_kernel<XT>), dim3(B), dim3(64), 0, st, (const XT*)x, tokens,
+                                              out, L, dim));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_cutouts_fwd(const float* xr, const float* noise, const float* facs, void* out, int out_dtype, int B,
+                                int H, int W, int cut, int cutn, int patch, float mean_r, float mean_g, float mean_b,
+                                float std_r, float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(xr && out, "ffvc_cutouts_fwd: null pointer");
+  FFVC_CHECK_ARG(B > 0 && H > 0 && W > 0 && cut > 0 && cutn > 0 && patch > 0 && cut % patch == 0,
+                 "ffvc_cutouts_fwd: bad geometry cut=%d patch=%d", cut, patch);
+  FFVC_CHECK_ARG((noise == nullptr) == (facs == nullptr), "ffvc_cutouts_fwd: noise and facs go together");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * 3 * cut * cut;
+  DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((cutouts_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, xr,
+                                                noise, facs, (OT*)out, B, H, W, cut, cutn, patch, mean_r, mean_g,
+                                                mean_b, std_r, std_g, std_b));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr, int B, int H, int W, int cut,
+                                int cutn, int patch, float std_r, float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(xr && gout && dxr, "ffvc_cutouts_bwd: null pointer");
+  FFVC_CHECK_ARG(B > 0 && H > 0 && W > 0 && cut > 0 && cutn > 0 && patch > 0 && cut % patch == 0 && H >= cut && W >= cut,
+                 "ffvc_cutouts_bwd: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * H * W * 3;
+  DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((cutouts_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, xr,
+                                              (const GT*)gout, dxr, B, H, W, cut, cutn, patch, std_r, std_g, std_b));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, float* loss, float* dembed,
+                                   int N, int B, int D, float coef, void* stream) {
+  FFVC_CHECK_ARG(embed && feats && rowloss && loss && N > 0 && B > 0 && D > 0 && N % B == 0,
+                 "ffvc_spherical_loss: bad args N=%d B=%d", N, B);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sph_loss_rows_kernel, dim3(ew_grid(N, 4)), dim3(256), 0, st, embed, feats, rowloss, dembed, N, B, D,
+                     coef);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, rowloss, loss, N, coef / (float)N);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n,
+                         float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+  FFVC_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "ffvc_adam: bad args");
+  FFVC_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0 && ((uintptr_t)shadow % 16) == 0,
+                 "ffvc_adam: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  const int grid = ew_grid(n / 4 + 1, 256);
+  if (shadow && shadow_dtype == FFVC_BF16)
+    hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (uint16_t*)shadow, n, lr, beta1,
+                       beta2, eps, bc1, bc2s, grad_scale);
+  else
+    hipLaunchKernelGGL((adam_kernel<float>), dim3(grid), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2,
+                       eps, bc1, bc2s, grad_scale);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(x && out && n > 0, "ffvc_sumsq: bad args");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n, 2048)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream) {
+  FFVC_CHECK_ARG(x && y && n > 0, "ffvc_axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}

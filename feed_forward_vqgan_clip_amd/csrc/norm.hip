@@ -1,0 +1,690 @@
+// norm.hip — HBM-bound normalisation kernels: LayerNorm, GroupNorm(+swish) on NHWC, row softmax.
+// All statistics, reductions and transcendental math are fp32 (fp64 for the GroupNorm moment
+// combine); storage is bf16 or fp32 per tensor.  One wavefront (64 lanes) owns one row /
+// pixel-strip, 16-byte vector accesses, no LDS round trip for row reductions (wave shuffles).
+#include "common.h"
+
+#define DISPATCH_DT(code, T, ...)   \
+  do {                              \
+    if ((code) == FFVC_BF16) {      \
+      using T = uint16_t;           \
+      __VA_ARGS__;                  \
+    } else {                        \
+      using T = float;              \
+      __VA_ARGS__;                  \
+    }                               \
+  } while (0)
+
+namespace {
+
+constexpr int LN_MAXE = 32;  // elements cached per lane -> dim <= 2048
+
+template <int VEC, typename T>
+__device__ __forceinline__ void ld_vec(const T* p, float* out) {
+  if constexpr (VEC == 4) {
+    f32x4_t v = load4(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = v[j];
+  } else {
+    out[0] = ElemTraits<T>::load(p);
+  }
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void st_vec(T* p, const float* in) {
+  if constexpr (VEC == 4) {
+    f32x4_t v = {in[0], in[1], in[2], in[3]};
+    store4(p, v);
+  } else {
+    ElemTraits<T>::store(p, in[0]);
+  }
+}
+
+// ------------------------------- LayerNorm ---------------------------------
+// y = (x - mean) * rstd * gamma + beta over the last dim (mlp_mixer_pytorch.py:11,14,37;
+// cloob.py:170-176; vitgan.py:14,21).  mean/rstd are saved for the backward.
+template <int VEC, typename XT, typename YT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, YT* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t rows, int dim, float eps) {
+  constexpr int NIT = LN_MAXE / VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const XT* xr = x + row * dim;
+    float v[LN_MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        ld_vec<VEC>(xr + idx, &v[k * VEC]);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += v[k * VEC + j];
+      }
+    }
+    const float mu = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float d = v[k * VEC + j] - mu;
+          q += d * d;
+        }
+      }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / dim + eps);
+    YT* yr = y + row * dim;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        float o[VEC], g[VEC], b[VEC];
+        ld_vec<VEC>(gamma + idx, g);
+        ld_vec<VEC>(beta + idx, b);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = (v[k * VEC + j] - mu) * rs * g[j] + b[j];
+        st_vec<VEC>(yr + idx, o);
+      }
+    }
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma.
+// Each workgroup owns a strip of rows and emits one partial row of dgamma / dbeta
+// (part_g/part_b: [gridDim.x, dim], reduced afterwards by ffvc_colsum); NULL skips them.
+template <int VEC, typename DYT, typename XT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, const XT* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const XT* __restrict__ dres,
+                                                     XT* __restrict__ dx, float* __restrict__ part_g,
+                                                     float* __restrict__ part_b, int64_t rows, int dim,
+                                                     int rows_per_block) {
+  constexpr int NIT = LN_MAXE / VEC;
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool want_p = part_g != nullptr;
+  float ag[LN_MAXE], ab[LN_MAXE];
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) ag[i] = ab[i] = 0.f;
+  if (want_p) {
+    for (int i = threadIdx.x; i < 2 * dim; i += 256) ln_smem[i] = 0.f;
+    __syncthreads();
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  for (int64_t row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXE], xh[LN_MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        float d[VEC], xv[VEC], gm[VEC];
+        ld_vec<VEC>(dy + row * dim + idx, d);
+        ld_vec<VEC>(x + row * dim + idx, xv);
+        ld_vec<VEC>(gamma + idx, gm);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float h = (xv[j] - mu) * rs;
+          xh[k * VEC + j] = h;
+          g[k * VEC + j] = d[j] * gm[j];
+          s1 += g[k * VEC + j];
+          s2 += g[k * VEC + j] * h;
+          ag[k * VEC + j] += d[j] * h;
+          ab[k * VEC + j] += d[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / dim;
+    s2 = wave_sum(s2) / dim;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = rs * (g[k * VEC + j] - s1 - xh[k * VEC + j] * s2);
+        if (dres) {
+          float r[VEC];
+          ld_vec<VEC>(dres + row * dim + idx, r);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] += r[j];
+        }
+        st_vec<VEC>(dx + row * dim + idx, o);
+      }
+    }
+  }
+  if (want_p) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          atomicAdd(&ln_smem[idx + j], ag[k * VEC + j]);
+          atomicAdd(&ln_smem[dim + idx + j], ab[k * VEC + j]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < dim; i += 256) {
+      part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
+      part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
+    }
+  }
+}
+
+// ------------------------------ GroupNorm ----------------------------------
+// NHWC tensor [B, HW, C], G groups of C/G consecutive channels, eps 1e-6, affine, optional
+// fused swish (taming Normalize + nonlinearity).
+// Pass 1: per (chunk, image) partial sum / sum-of-squares per group in fp64 -> ws[B][NCH][G][2].
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws, int HW,
+                                                       int C, int G, int rows_per_chunk) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;  // 8 bf16 / 4 f32 channels per thread-load
+  __shared__ float s_sum[1024], s_sq[1024];
+  const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+  const int cpr = C / EPC;           // 16-B columns per pixel
+  const int rpp = 256 / cpr;         // pixels per pass
+  const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
+  for (int i = threadIdx.x; i < C; i += 256) s_sum[i] = s_sq[i] = 0.f;
+  __syncthreads();
+  float a1[EPC], a2[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) a1[j] = a2[j] = 0.f;
+  const int p0 = chunk * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+  if (rr < rpp) {
+    for (int p = p0 + rr; p < p1; p += rpp) {
+      const T* px = x + ((int64_t)b * HW + p) * C + cc * EPC;
+      if constexpr (EPC == 8) {
+        f32x8 v = load8(px);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          a1[j] += v.v[j];
+          a2[j] += v.v[j] * v.v[j];
+        }
+      } else {
+        f32x4_t v = load4(px);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a1[j] += v[j];
+          a2[j] += v[j] * v[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      atomicAdd(&s_sum[cc * EPC + j], a1[j]);
+      atomicAdd(&s_sq[cc * EPC + j], a2[j]);
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = 0; c < cpg; ++c) {
+      t1 += (double)s_sum[g * cpg + c];
+      t2 += (double)s_sq[g * cpg + c];
+    }
+    double* o = ws + (((int64_t)b * nch + chunk) * G + g) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
+// Combine the chunk partials of image b (every block does it redundantly: NCH <= 64, G = 32).
+__device__ __forceinline__ void gn_finalize(const double* ws, int b, int nch, int G, int64_t n, float eps,
+                                            float* s_mean, float* s_rstd) {
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = 0; c < nch; ++c) {
+      const double* o = ws + (((int64_t)b * nch + c) * G + g) * 2;
+      t1 += o[0];
+      t2 += o[1];
+    }
+    const double mu = t1 / (double)n;
+    double var = t2 / (double)n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    s_mean[g] = (float)mu;
+    s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const double* __restrict__ ws,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int HW,
+                                                       int C, int G, int nch, float eps, int swish,
+                                                       int rows_per_block) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.y;
+  const int cpg = C / G;
+  gn_finalize(ws, b, nch, G, (int64_t)HW * cpg, eps, s_mean, s_rstd);
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int g = threadIdx.x; g < G; g += 256) {
+      mean[b * G + g] = s_mean[g];
+      rstd[b * G + g] = s_rstd[g];
+    }
+  const int cpr = C / EPC, rpp = 256 / cpr;
+  const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
+  if (rr >= rpp) return;
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    const int c = cc * EPC + j, g = c / cpg;
+    sc[j] = gamma[c] * s_rstd[g];
+    sh[j] = beta[c] - s_mean[g] * sc[j];
+  }
+  const int p0 = blockIdx.x * rows_per_block, p1 = min(HW, p0 + rows_per_block);
+  for (int p = p0 + rr; p < p1; p += rpp) {
+    const int64_t off = ((int64_t)b * HW + p) * C + cc * EPC;
+    if constexpr (EPC == 8) {
+      f32x8 v = load8(x + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = v.v[j] * sc[j] + sh[j];
+        v.v[j] = swish ? act_swish(u) : u;
+      }
+      store8(y + off, v);
+    } else {
+      f32x4_t v = load4(x + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = v[j] * sc[j] + sh[j];
+        v[j] = swish ? act_swish(u) : u;
+      }
+      store4(y + off, v);
+    }
+  }
+}
+
+// Backward pass 1: per group S1 = sum dxh, S2 = sum dxh * xh, with dxh = dy * swish'(u) * gamma.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, double* __restrict__ ws,
+                                                           int HW, int C, int G, int swish, int rows_per_chunk) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;
+  __shared__ float s_1[1024], s_2[1024];
+  const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+  const int cpg = C / G;
+  const int cpr = C / EPC, rpp = 256 / cpr;
+  const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
+  for (int i = threadIdx.x; i < C; i += 256) s_1[i] = s_2[i] = 0.f;
+  __syncthreads();
+  if (rr < rpp) {
+    float gm[EPC], bt[EPC], mu[EPC], rs[EPC], a1[EPC], a2[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const int c = cc * EPC + j, g = c / cpg;
+      gm[j] = gamma[c];
+      bt[j] = beta[c];
+      mu[j] = mean[b * G + g];
+      rs[j] = rstd[b * G + g];
+      a1[j] = a2[j] = 0.f;
+    }
+    const int p0 = chunk * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+    for (int p = p0 + rr; p < p1; p += rpp) {
+      const int64_t off = ((int64_t)b * HW + p) * C + cc * EPC;
+      float dv[EPC], xv[EPC];
+      if constexpr (EPC == 8) {
+        f32x8 a = load8(dy + off), c2 = load8(x + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dv[j] = a.v[j];
+          xv[j] = c2.v[j];
+        }
+      } else {
+        f32x4_t a = load4(dy + off), c2 = load4(x + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dv[j] = a[j];
+          xv[j] = c2[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        const float xh = (xv[j] - mu[j]) * rs[j];
+        float d = dv[j];
+        if (swish) d *= act_swish_grad(xh * gm[j] + bt[j]);
+        d *= gm[j];
+        a1[j] += d;
+        a2[j] += d * xh;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      atomicAdd(&s_1[cc * EPC + j], a1[j]);
+      atomicAdd(&s_2[cc * EPC + j], a2[j]);
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = 0; c < cpg; ++c) {
+      t1 += (double)s_1[g * cpg + c];
+      t2 += (double)s_2[g * cpg + c];
+    }
+    double* o = ws + (((int64_t)b * nch + chunk) * G + g) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
+// Backward pass 2: dx = rstd * (dxh - S1/n - xh * S2/n) (+ dres).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const double* __restrict__ ws, const T* __restrict__ dres,
+                                                           T* __restrict__ dx, int HW, int C, int G, int nch,
+                                                           int swish, int rows_per_block) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;
+  __shared__ float s_1[64], s_2[64];
+  const int b = blockIdx.y;
+  const int cpg = C / G;
+  const double n = (double)HW * cpg;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = 0; c < nch; ++c) {
+      const double* o = ws + (((int64_t)b * nch + c) * G + g) * 2;
+      t1 += o[0];
+      t2 += o[1];
+    }
+    s_1[g] = (float)(t1 / n);
+    s_2[g] = (float)(t2 / n);
+  }
+  __syncthreads();
+  const int cpr = C / EPC, rpp = 256 / cpr;
+  const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
+  if (rr >= rpp) return;
+  float gm[EPC], bt[EPC], mu[EPC], rs[EPC], m1[EPC], m2[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    const int c = cc * EPC + j, g = c / cpg;
+    gm[j] = gamma[c];
+    bt[j] = beta[c];
+    mu[j] = mean[b * G + g];
+    rs[j] = rstd[b * G + g];
+    m1[j] = s_1[g];
+    m2[j] = s_2[g];
+  }
+  const int p0 = blockIdx.x * rows_per_block, p1 = min(HW, p0 + rows_per_block);
+  for (int p = p0 + rr; p < p1; p += rpp) {
+    const int64_t off = ((int64_t)b * HW + p) * C + cc * EPC;
+    float dv[EPC], xv[EPC], rv[EPC];
+    if constexpr (EPC == 8) {
+      f32x8 a = load8(dy + off), c2 = load8(x + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dv[j] = a.v[j];
+        xv[j] = c2.v[j];
+        rv[j] = 0.f;
+      }
+      if (dres) {
+        f32x8 r = load8(dres + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[j] = r.v[j];
+      }
+    } else {
+      f32x4_t a = load4(dy + off), c2 = load4(x + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dv[j] = a[j];
+        xv[j] = c2[j];
+        rv[j] = 0.f;
+      }
+      if (dres) {
+        f32x4_t r = load4(dres + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[j] = r[j];
+      }
+    }
+    float o[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      float d = dv[j];
+      if (swish) d *= act_swish_grad(xh * gm[j] + bt[j]);
+      d *= gm[j];
+      o[j] = rs[j] * (d - m1[j] - xh * m2[j]) + rv[j];
+    }
+    if constexpr (EPC == 8) {
+      f32x8 w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w.v[j] = o[j];
+      store8(dx + off, w);
+    } else {
+      f32x4_t w = {o[0], o[1], o[2], o[3]};
+      store4(dx + off, w);
+    }
+  }
+}
+
+// ------------------------------- softmax -----------------------------------
+// p[r, :cols] = softmax(scale * s[r, :cols] (+ causal mask)), columns [cols, ldp) zero-filled.
+// Causal: key j is visible to query i = r % q_len iff j <= i (cloob.py:510-516; x-transformers Decoder).
+constexpr int SM_MAXE = 16;  // cols <= 1024
+template <typename PT>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, PT* __restrict__ p,
+                                                          int64_t rows, int cols, int lds, int ldp, float scale,
+                                                          int causal, int q_len) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int limit = causal ? min(cols, (int)(row % q_len) + 1) : cols;
+    float v[SM_MAXE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SM_MAXE; ++k) {
+      const int j = k * 64 + lane;
+      v[k] = (j < limit) ? s[row * lds + j] * scale : -INFINITY;
+      mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_MAXE; ++k) {
+      const int j = k * 64 + lane;
+      v[k] = (j < limit) ? __expf(v[k] - mx) : 0.f;
+      sum += v[k];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int k = 0; k < SM_MAXE; ++k) {
+      const int j = k * 64 + lane;
+      if (j < ldp) ElemTraits<PT>::store(p + row * ldp + j, v[k] * inv);
+    }
+  }
+}
+
+// ds = scale * p * (dp - sum_j p_j dp_j); columns [cols, ldp) zero-filled.
+template <typename PT>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const PT* __restrict__ p, const float* __restrict__ dp,
+                                                          PT* __restrict__ ds, int64_t rows, int cols, int ldp,
+                                                          int lddp, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float pv[SM_MAXE], dv[SM_MAXE];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_MAXE; ++k) {
+      const int j = k * 64 + lane;
+      pv[k] = (j < cols) ? ElemTraits<PT>::load(p + row * ldp + j) : 0.f;
+      dv[k] = (j < cols) ? dp[row * lddp + j] : 0.f;
+      dot += pv[k] * dv[k];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < SM_MAXE; ++k) {
+      const int j = k * 64 + lane;
+      if (j < ldp) ElemTraits<PT>::store(ds + row * ldp + j, scale * pv[k] * (dv[k] - dot));
+    }
+  }
+}
+
+inline int grid_rows(int64_t rows) {
+  int64_t g = (rows + 3) / 4;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                                  int y_dtype, float* mean, float* rstd, int64_t rows, int dim, float eps,
+                                  void* stream) {
+  FFVC_CHECK_ARG(x && gamma && beta && y && mean && rstd, "ffvc_layernorm_fwd: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_fwd: dim=%d unsupported (max %d)", dim,
+                 64 * LN_MAXE);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_rows(rows);
+  const bool v4 = (dim % 4) == 0;
+  DISPATCH_DT(x_dtype, XT, DISPATCH_DT(y_dtype, YT, {
+                if (v4)
+                  hipLaunchKernelGGL((ln_fwd_kernel<4, XT, YT>), dim3(grid), dim3(256), 0, st, (const XT*)x, gamma,
+                                     beta, (YT*)y, mean, rstd, rows, dim, eps);
+                else
+                  hipLaunchKernelGGL((ln_fwd_kernel<1, XT, YT>), dim3(grid), dim3(256), 0, st, (const XT*)x, gamma,
+                                     beta, (YT*)y, mean, rstd, rows, dim, eps);
+              }));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_layernorm_bwd_blocks(int64_t rows) {
+  // number of partial rows ffvc_layernorm_bwd writes into part_g / part_b
+  int64_t nb = (rows + 127) / 128;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                                  const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
+                                  float* part_b, int64_t rows, int dim, void* stream) {
+  FFVC_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ffvc_layernorm_bwd: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
+  FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 128;
+  const int grid = ffvc_layernorm_bwd_blocks(rows);
+  const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
+  const bool v4 = (dim % 4) == 0;
+  DISPATCH_DT(dy_dtype, DYT, DISPATCH_DT(x_dtype, XT, {
+                if (v4)
+                  hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
+                                     (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
+                                     dim, rpb);
+                else
+                  hipLaunchKernelGGL((ln_bwd_kernel<1, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
+                                     (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
+                                     dim, rpb);
+              }));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+static int gn_chunks(int B, int HW, int* rows_per_chunk) {
+  int nch = 2048 / (B < 1 ? 1 : B);
+  if (nch > 64) nch = 64;
+  if (nch < 1) nch = 1;
+  int maxc = (HW + 63) / 64;
+  if (nch > maxc) nch = maxc;
+  if (nch < 1) nch = 1;
+  *rows_per_chunk = (HW + nch - 1) / nch;
+  nch = (HW + *rows_per_chunk - 1) / *rows_per_chunk;
+  return nch;
+}
+
+extern "C" int64_t ffvc_groupnorm_ws_bytes(int B, int HW, int G) {
+  int rpc;
+  const int nch = gn_chunks(B, HW, &rpc);
+  return (int64_t)B * nch * G * 2 * (int64_t)sizeof(double);
+}
+
+static int gn_check(int B, int HW, int C, int G, int dtype, const char* who) {
+  const int epc = dtype == FFVC_BF16 ? 8 : 4;
+  FFVC_CHECK_ARG(B > 0 && B <= 65535 && HW > 0 && C > 0 && G > 0 && G <= 64, "%s: bad dims B=%d HW=%d C=%d G=%d", who,
+                 B, HW, C, G);
+  FFVC_CHECK_ARG(C % G == 0 && C % epc == 0 && C <= 1024 && (C / epc) <= 256, "%s: C=%d unsupported (G=%d)", who, C, G);
+  return 0;
+}
+
+extern "C" int ffvc_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean,
+                                  float* rstd, void* ws, int B, int HW, int C, int G, float eps, int swish,
+                                  int dtype, void* stream) {
+  FFVC_CHECK_ARG(x && y && gamma && beta && mean && rstd && ws, "ffvc_groupnorm_fwd: null pointer");
+  if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_fwd")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  int rpc;
+  const int nch = gn_chunks(B, HW, &rpc);
+  const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)x, (double*)ws, HW, C, G, rpc);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta,
+                       (const double*)ws, mean, rstd, HW, C, G, nch, eps, swish, rpb);
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, const void* dres, void* dx, void* ws, int B,
+                                  int HW, int C, int G, int swish, int dtype, void* stream) {
+  FFVC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && ws, "ffvc_groupnorm_bwd: null pointer");
+  if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_bwd")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  int rpc;
+  const int nch = gn_chunks(B, HW, &rpc);
+  const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                       beta, mean, rstd, (double*)ws, HW, C, G, swish, rpc);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                       beta, mean, rstd, (const double*)ws, (const T*)dres, (T*)dx, HW, C, G, nch, swish, rpb);
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_softmax_fwd(const float* s, void* p, int p_dtype, int64_t rows, int cols, int lds, int ldp,
+                                float scale, int causal, int q_len, void* stream) {
+  FFVC_CHECK_ARG(s && p, "ffvc_softmax_fwd: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && cols > 0 && cols <= 64 * SM_MAXE && ldp >= cols && ldp <= 64 * SM_MAXE && lds >= cols,
+                 "ffvc_softmax_fwd: cols=%d ldp=%d lds=%d unsupported (max %d)", cols, ldp, lds, 64 * SM_MAXE);
+  FFVC_CHECK_ARG(!causal || q_len > 0, "ffvc_softmax_fwd: causal needs q_len");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(p_dtype, PT,
+              hipLaunchKernelGGL((softmax_fwd_kernel<PT>), dim3(grid_rows(rows)), dim3(256), 0, st, s, (PT*)p, rows,
+                                 cols, lds, ldp, scale, causal, q_len > 0 ? q_len : 1));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_softmax_bwd(const void* p, const float* dp, void* ds, int p_dtype, int64_t rows, int cols, int ldp,
+                                int lddp, float scale, void* stream) {
+  FFVC_CHECK_ARG(p && dp && ds, "ffvc_softmax_bwd: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && cols > 0 && ldp >= cols && ldp <= 64 * SM_MAXE && lddp >= cols,
+                 "ffvc_softmax_bwd: cols=%d ldp=%d unsupported", cols, ldp);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(p_dtype, PT,
+              hipLaunchKernelGGL((softmax_bwd_kernel<PT>), dim3(grid_rows(rows)), dim3(256), 0, st, (const PT*)p, dp,
+                                 (PT*)ds, rows, cols, ldp, lddp, scale));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}

@@ -102,3 +102,226 @@ def probe_tr16():
     _lib.check(_lib.load().ffvc_probe_tr16(out.data_ptr(), stream_ptr()), "ffvc_probe_tr16")
     torch.cuda.synchronize()
     return out.cpu().view(64, 4)
+
+
+# ---------------------------------------------------------------------------
+# norm / softmax
+# ---------------------------------------------------------------------------
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
+    """x: (..., dim) fp32|bf16 contiguous -> (y[out_dtype], mean, rstd)."""
+    _need_cuda(x, gamma, beta)
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _call("ffvc_layernorm_fwd", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+          dtype_code(out_dtype), mean.data_ptr(), rstd.data_ptr(), rows, dim, eps, stream_ptr())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False):
+    """-> (dx [x.dtype], dgamma|None, dbeta|None)."""
+    _need_cuda(dy, x, gamma)
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    dx = torch.empty_like(x)
+    if dres is not None and dres.dtype != x.dtype:
+        raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
+    pg = pb = None
+    if want_param_grads:
+        nb = _lib.load().ffvc_layernorm_bwd_blocks(rows)
+        pg = torch.empty(nb, dim, dtype=torch.float32, device=x.device)
+        pb = torch.empty(nb, dim, dtype=torch.float32, device=x.device)
+    _call("ffvc_layernorm_bwd", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
+          gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(pg), _ptr(pb), rows, dim,
+          stream_ptr())
+    if not want_param_grads:
+        return dx, None, None
+    dg = torch.empty(dim, dtype=torch.float32, device=x.device)
+    db = torch.empty(dim, dtype=torch.float32, device=x.device)
+    colsum(pg, dg)
+    colsum(pb, db)
+    return dx, dg, db
+
+
+def _gn_ws(B, HW, G, dev):
+    n = _lib.load().ffvc_groupnorm_ws_bytes(B, HW, G)
+    return torch.empty((n + 7) // 8, dtype=torch.float64, device=dev)
+
+
+def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True):
+    """x: NHWC (B, H, W, C) -> (y, mean[B,G], rstd[B,G])."""
+    _need_cuda(x, gamma, beta)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    ws = _gn_ws(B, HW, G, x.device)
+    _call("ffvc_groupnorm_fwd", x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+          rstd.data_ptr(), ws.data_ptr(), B, HW, C, G, eps, int(swish), dtype_code(x.dtype), stream_ptr())
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True):
+    _need_cuda(dy, x)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    ws = _gn_ws(B, HW, G, x.device)
+    _call("ffvc_groupnorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+          rstd.data_ptr(), _ptr(dres), dx.data_ptr(), ws.data_ptr(), B, HW, C, G, int(swish), dtype_code(x.dtype),
+          stream_ptr())
+    return dx
+
+
+def softmax_fwd(s, p, rows, cols, lds, ldp, scale=1.0, causal=False, q_len=0):
+    _call("ffvc_softmax_fwd", s.data_ptr(), p.data_ptr(), dtype_code(p.dtype), rows, cols, lds, ldp, scale, int(causal),
+          q_len, stream_ptr())
+    return p
+
+
+def softmax_bwd(p, dp, ds, rows, cols, ldp, lddp, scale=1.0):
+    _call("ffvc_softmax_bwd", p.data_ptr(), dp.data_ptr(), ds.data_ptr(), dtype_code(p.dtype), rows, cols, ldp, lddp,
+          scale, stream_ptr())
+    return ds
+
+
+# ---------------------------------------------------------------------------
+# glue
+# ---------------------------------------------------------------------------
+def cast(src, dtype):
+    if src.dtype == dtype:
+        return src
+    _need_cuda(src)
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _call("ffvc_cast", src.data_ptr(), dtype_code(src.dtype), dst.data_ptr(), dtype_code(dtype), src.numel(),
+          stream_ptr())
+    return dst
+
+
+def cast_into(src, dst):
+    _call("ffvc_cast", src.data_ptr(), dtype_code(src.dtype), dst.data_ptr(), dtype_code(dst.dtype), src.numel(),
+          stream_ptr())
+    return dst
+
+
+def transpose(src, out_dtype=None, out=None):
+    """src: (..., R, C) contiguous -> (..., C, R) (batched over leading dims)."""
+    _need_cuda(src)
+    R, C = src.shape[-2], src.shape[-1]
+    batch = src.numel() // (R * C)
+    if out is None:
+        out = torch.empty(*src.shape[:-2], C, R, dtype=out_dtype or src.dtype, device=src.device)
+    _call("ffvc_transpose", src.data_ptr(), dtype_code(src.dtype), out.data_ptr(), dtype_code(out.dtype), batch, R, C,
+          R * C, R * C, stream_ptr())
+    return out
+
+
+def colsum(x, out, accumulate=False, ld=None):
+    rows, cols = x.shape[0], x.shape[-1]
+    rows = x.numel() // cols
+    _call("ffvc_colsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), rows, cols, ld or cols, int(accumulate),
+          stream_ptr())
+    return out
+
+
+def clamp_fwd(x, out_dtype, mul, add, lo, hi):
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _call("ffvc_clamp_fwd", x.data_ptr(), dtype_code(x.dtype), y.data_ptr(), dtype_code(out_dtype), x.numel(), mul, add,
+          lo, hi, stream_ptr())
+    return y
+
+
+def clamp_bwd(x, g, mul, add, lo, hi):
+    dx = torch.empty_like(x)
+    _call("ffvc_clamp_bwd", x.data_ptr(), dtype_code(x.dtype), g.data_ptr(), dtype_code(g.dtype), dx.data_ptr(),
+          x.numel(), mul, add, lo, hi, stream_ptr())
+    return dx
+
+
+def sumpool2x2(src):
+    B, H2, W2, C = src.shape
+    dst = torch.empty(B, H2 // 2, W2 // 2, C, dtype=src.dtype, device=src.device)
+    _call("ffvc_sumpool2x2", src.data_ptr(), dst.data_ptr(), dtype_code(src.dtype), B, H2 // 2, W2 // 2, C, stream_ptr())
+    return dst
+
+
+def rownorm_sq(x):
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _call("ffvc_rownorm_sq", x.data_ptr(), out.data_ptr(), rows, dim, stream_ptr())
+    return out
+
+
+def vq_argmin(dot, xnorm, cnorm):
+    rows, ncodes = dot.shape
+    idx = torch.empty(rows, dtype=torch.int64, device=dot.device)
+    _call("ffvc_vq_argmin", dot.data_ptr(), xnorm.data_ptr(), cnorm.data_ptr(), idx.data_ptr(), rows, ncodes, ncodes,
+          stream_ptr())
+    return idx
+
+
+def gather_rows(table, idx, out_dtype, pos=None, period=0):
+    rows, dim = idx.numel(), table.shape[-1]
+    out = torch.empty(*idx.shape, dim, dtype=out_dtype, device=table.device)
+    _call("ffvc_gather_rows", table.data_ptr(), idx.data_ptr(), _ptr(pos), period, out.data_ptr(), dtype_code(out_dtype),
+          rows, dim, stream_ptr())
+    return out
+
+
+def eot_gather(x, tokens):
+    B, L, D = x.shape
+    out = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    _call("ffvc_eot_gather", x.data_ptr(), dtype_code(x.dtype), tokens.data_ptr(), out.data_ptr(), B, L, D, stream_ptr())
+    return out
+
+
+def cutouts_fwd(xr, cut, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
+    B, H, W, _ = xr.shape
+    g = cut // patch
+    out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=xr.device)
+    _call("ffvc_cutouts_fwd", xr.data_ptr(), _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, H, W, cut,
+          cutn, patch, mean[0], mean[1], mean[2], std[0], std[1], std[2], stream_ptr())
+    return out
+
+
+def cutouts_bwd(xr, gout, cut, cutn, patch, std):
+    B, H, W, _ = xr.shape
+    dxr = torch.empty_like(xr)
+    _call("ffvc_cutouts_bwd", xr.data_ptr(), gout.data_ptr(), dtype_code(gout.dtype), dxr.data_ptr(), B, H, W, cut, cutn,
+          patch, std[0], std[1], std[2], stream_ptr())
+    return dxr
+
+
+def spherical_loss(embed, feats, coef=1.0, want_grad=True):
+    N, D = embed.shape
+    B = feats.shape[0]
+    rowloss = torch.empty(N, dtype=torch.float32, device=embed.device)
+    loss = torch.empty((), dtype=torch.float32, device=embed.device)
+    dembed = torch.empty_like(embed) if want_grad else None
+    _call("ffvc_spherical_loss", embed.data_ptr(), feats.data_ptr(), rowloss.data_ptr(), loss.data_ptr(), _ptr(dembed), N,
+          B, D, coef, stream_ptr())
+    return loss, dembed
+
+
+def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
+          dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
+          stream_ptr())
+
+
+def sumsq(x, out):
+    _call("ffvc_sumsq", x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr())
+    return out
+
+
+def axpby(x, y, a, b):
+    _call("ffvc_axpby", x.data_ptr(), y.data_ptr(), x.numel(), a, b, stream_ptr())
+    return y

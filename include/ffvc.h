@@ -105,6 +105,88 @@ typedef struct ffvc_gemm_desc {
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Normalisation / softmax (HBM-bound; fp32 statistics; dtype codes per tensor)
+ * ------------------------------------------------------------------------- */
+
+/* LayerNorm over the last dim, eps as given (1e-5 everywhere on the path):
+ * mlp_mixer_pytorch.py:11,14,37; vitgan.py:14,21; cloob.py:170-176,203-204.  mean/rstd [rows] are saved. */
+int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                       float* mean, float* rstd, int64_t rows, int dim, float eps, void* stream);
+/* dx = LN'(dy) (+ dres, same dtype as x/dx).  If part_g/part_b are given they receive
+ * ffvc_layernorm_bwd_blocks(rows) partial rows of dgamma/dbeta (reduce with ffvc_colsum). */
+int ffvc_layernorm_bwd_blocks(int64_t rows);
+int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
+                       float* part_b, int64_t rows, int dim, void* stream);
+
+/* GroupNorm(G groups, affine) on NHWC [B, HW, C] with optional fused swish x*sigmoid(x):
+ * taming Normalize()/nonlinearity() [upstream taming-transformers 0.0.6, SURVEY.md App. A.1].
+ * ws: workspace of ffvc_groupnorm_ws_bytes(B, HW, G) bytes.  mean/rstd: [B, G] fp32. */
+int64_t ffvc_groupnorm_ws_bytes(int B, int HW, int G);
+int ffvc_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                       void* ws, int B, int HW, int C, int G, float eps, int swish, int dtype, void* stream);
+/* dx = GN'(swish'(.) * dy) (+ dres); gamma/beta gradients are not produced (decoder is frozen, main.py:88). */
+int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, const void* dres, void* dx, void* ws, int B, int HW, int C, int G,
+                       int swish, int dtype, void* stream);
+
+/* Row softmax of fp32 scores: p[r,:cols] = softmax(scale*s[r,:cols]); causal: key j visible to query
+ * (r % q_len) iff j <= query (cloob.py:510-516).  Columns [cols, ldp) are zero-filled.
+ * vitgan.py:91-92; cloob.py:199-200 (nn.MultiheadAttention); taming AttnBlock softmax(dim=2). */
+int ffvc_softmax_fwd(const float* s, void* p, int p_dtype, int64_t rows, int cols, int lds, int ldp, float scale,
+                     int causal, int q_len, void* stream);
+int ffvc_softmax_bwd(const void* p, const float* dp, void* ds, int p_dtype, int64_t rows, int cols, int ldp,
+                     int lddp, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Glue kernels of the train step (main.py:715-837)
+ * ------------------------------------------------------------------------- */
+int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* dst[b][c][r] = src[b][r][c] (+dtype conversion): einops Rearrange mlp_mixer_pytorch.py:31; W^T shadows for dgrad */
+int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int batch, int rows, int cols,
+                   int64_t src_batch_stride, int64_t dst_batch_stride, void* stream);
+/* out[c] (+)= sum_r x[r,c]: bias gradients of nn.Linear / Conv1d */
+int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, int64_t ld, int accumulate,
+                void* stream);
+/* ClampWithGrad (main.py:118-132) applied to u = x*mul + add: used at main.py:763 (mul=1, add=0,
+ * scalar codebook min/max) and main.py:142 ((x+1)/2 clamped to [0,1]: mul=.5, add=.5). */
+int ffvc_clamp_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, float mul, float add, float lo,
+                   float hi, void* stream);
+int ffvc_clamp_bwd(const void* x, int x_dtype, const void* g, int g_dtype, void* dx, int64_t n, float mul, float add,
+                   float lo, float hi, void* stream);
+/* backward of taming Upsample's F.interpolate(scale_factor=2, mode="nearest"): [B,2H,2W,C] -> [B,H,W,C] */
+int ffvc_sumpool2x2(const void* src, void* dst, int dtype, int B, int H, int W, int C, void* stream);
+/* vector_quantize (main.py:134-138): ||.||^2 of rows; argmin of (xn+cn)-2*dot (first index on ties);
+ * gather == one_hot(idx) @ codebook.  ffvc_gather_rows also serves token+positional embedding (cloob.py:526-528). */
+int ffvc_rownorm_sq(const float* x, float* out, int64_t rows, int dim, void* stream);
+int ffvc_vq_argmin(const float* dot, const float* xnorm, const float* cnorm, int64_t* idx, int64_t rows, int ncodes,
+                   int64_t ld, void* stream);
+int ffvc_gather_rows(const float* table, const int64_t* idx, const float* pos, int period, void* out, int out_dtype,
+                     int64_t rows, int dim, void* stream);
+/* out[b,:] = x[b, argmax_t tokens[b,t], :]  (EOT pooling, cloob.py:536) */
+int ffvc_eot_gather(const void* x, int x_dtype, const int64_t* tokens, float* out, int B, int L, int dim,
+                    void* stream);
+/* MakeCutouts pool branch + noise + CLIP mean/std normalisation (main.py:212-229,797), written as the
+ * K-major im2col rows of the ViT patch-embedding conv (cloob.py:224,237).  xr: NHWC fp32 [B,H,W,3] in [0,1];
+ * noise: NCHW fp32 [cutn*B,3,cut,cut] with facs [cutn*B] (both NULL = noise_fac 0);
+ * out: [cutn*B, (cut/patch)^2, 3*patch*patch]. */
+int ffvc_cutouts_fwd(const float* xr, const float* noise, const float* facs, void* out, int out_dtype, int B, int H,
+                     int W, int cut, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
+                     float std_g, float std_b, void* stream);
+int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr, int B, int H, int W, int cut,
+                     int cutn, int patch, float std_r, float std_g, float std_b, void* stream);
+/* Spherical distance loss (main.py:801-811), repeat=1: loss = coef*mean_n 2*asin(|H-E|/2)^2 with
+ * H = normalize(feats[n % B]), E = normalize(embed[n]); dembed (may be NULL) <- d loss / d embed. */
+int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, float* loss, float* dembed, int N,
+                        int B, int D, float coef, void* stream);
+/* torch.optim.Adam defaults (main.py:591) over a flat fp32 bucket, step is 1-based; optionally refreshes the
+ * low-precision weight shadow in the same pass; grad_scale folds 1/world_size or clip_grad_norm (main.py:833-834). */
+int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr,
+              float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream);            /* out[0] += sum x^2 */
+int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream); /* y = a*x + b*y */
+
 /* Library / device info */
 const char* ffvc_last_error(void);
 int ffvc_version(void);

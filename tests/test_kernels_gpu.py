@@ -1,0 +1,220 @@
+"""GPU parity of the norm / softmax / glue kernels against plain PyTorch fp32/fp64 math of the same op.
+Tolerances: fp32 storage 2e-5 rel (op order only); bf16 storage adds one 2^-8 rounding of the output."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from feed_forward_vqgan_clip_amd import kernels as K  # noqa: E402
+
+DT = [torch.bfloat16, torch.float32]
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+def _mk(shape, dtype, dev, seed, scale=1.0, shift=0.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale + shift).to(dtype).to(dev)
+
+
+def _tol(dt):
+    return 1.2e-2 if dt == torch.bfloat16 else 3e-5
+
+
+@pytest.mark.parametrize("xdt", DT)
+@pytest.mark.parametrize("ydt", DT)
+@pytest.mark.parametrize("rows,dim", [(515, 1024), (70, 768), (33, 12), (9, 256)])
+def test_layernorm(cuda, xdt, ydt, rows, dim):
+    x = _mk((rows, dim), xdt, cuda, 1, 2.0, 0.5)
+    g, b = _mk((dim,), torch.float32, cuda, 2), _mk((dim,), torch.float32, cuda, 3)
+    y, mean, rstd = K.layernorm_fwd(x, g, b, ydt)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (dim,), gd, bd, 1e-5)
+    assert _rel(y, ref) < _tol(ydt)
+    dy = _mk((rows, dim), ydt, cuda, 4)
+    dres = _mk((rows, dim), xdt, cuda, 5)
+    dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=True)
+    ref.backward(dy.double())
+    assert _rel(dx, xd.grad + dres.double()) < _tol(xdt)
+    assert _rel(dg, gd.grad) < 3e-5 and _rel(db, bd.grad) < 3e-5
+    dx2, _, _ = K.layernorm_bwd(dy, x, g, mean, rstd)
+    assert _rel(dx2, xd.grad) < _tol(xdt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("swish", [True, False])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 512), (3, 7, 9, 128), (1, 64, 64, 256), (2, 4, 4, 32)])
+def test_groupnorm(cuda, dt, swish, B, H, W, C):
+    x = _mk((B, H, W, C), dt, cuda, 1, 1.5, 0.3)
+    g, b = _mk((C,), torch.float32, cuda, 2, 0.5, 1.0), _mk((C,), torch.float32, cuda, 3, 0.2)
+    y, mean, rstd = K.groupnorm_fwd(x, g, b, swish=swish)
+    xd = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.group_norm(xd, 32, g.double(), b.double(), 1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    assert _rel(y, ref.permute(0, 2, 3, 1)) < _tol(dt)
+    dy, dres = _mk((B, H, W, C), dt, cuda, 4), _mk((B, H, W, C), dt, cuda, 5)
+    dx = K.groupnorm_bwd(dy, x, g, b, mean, rstd, dres=dres, swish=swish)
+    ref.backward(dy.double().permute(0, 3, 1, 2))
+    assert _rel(dx, xd.grad.permute(0, 2, 3, 1) + dres.double()) < _tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("T,ld", [(50, 64), (77, 80), (256, 256), (1000, 1024)])
+def test_softmax(cuda, dt, causal, T, ld):
+    R = 3 * T
+    s = _mk((R, ld), torch.float32, cuda, 1, 3.0)
+    p = torch.full((R, ld), 7.0, dtype=dt, device=cuda)
+    K.softmax_fwd(s, p, R, T, ld, ld, scale=0.37, causal=causal, q_len=T)
+    sd = (s[:, :T].double() * 0.37).requires_grad_(True)
+    sm = sd
+    if causal:
+        q = torch.arange(R, device=cuda) % T
+        mask = torch.arange(T, device=cuda)[None, :] > q[:, None]
+        sm = sd.masked_fill(mask, float("-inf"))
+    ref = sm.softmax(-1)
+    assert _rel(p[:, :T], ref) < _tol(dt)
+    assert (p[:, T:] == 0).all()
+    dp = _mk((R, ld), torch.float32, cuda, 2)
+    ds = torch.empty_like(p)
+    K.softmax_bwd(p, dp, ds, R, T, ld, ld, scale=0.37)
+    pd = p[:, :T].double()
+    dref = 0.37 * pd * (dp[:, :T].double() - (pd * dp[:, :T].double()).sum(-1, keepdim=True))
+    assert _rel(ds[:, :T], dref) < _tol(dt)
+
+
+def test_cast_transpose_colsum(cuda):
+    x = _mk((5, 70, 130), torch.float32, cuda, 1)
+    xb = K.cast(x, torch.bfloat16)
+    assert torch.equal(xb, x.bfloat16())
+    assert torch.equal(K.cast(xb, torch.float32), xb.float())
+    odd = _mk((1027,), torch.float32, cuda, 2)
+    assert torch.equal(K.cast(odd, torch.bfloat16), odd.bfloat16())
+    t = K.transpose(x, torch.bfloat16)
+    assert torch.equal(t, x.transpose(1, 2).contiguous().bfloat16())
+    t2 = K.transpose(xb)
+    assert torch.equal(t2, xb.transpose(1, 2).contiguous())
+    for dt in DT:
+        m = _mk((3000, 200), dt, cuda, 3)
+        out = torch.ones(200, dtype=torch.float32, device=cuda)
+        K.colsum(m, out, accumulate=True)
+        assert _rel(out, m.double().sum(0) + 1.0) < 3e-5
+        K.colsum(m, out)
+        assert _rel(out, m.double().sum(0)) < 3e-5
+
+
+def test_clamp_with_grad(cuda):
+    x = _mk((4, 37, 11), torch.float32, cuda, 1, 2.0)
+    g = _mk((4, 37, 11), torch.float32, cuda, 2)
+    y = K.clamp_fwd(x, torch.float32, 0.5, 0.5, 0.0, 1.0)
+    u = x * 0.5 + 0.5
+    assert torch.allclose(y, u.clamp(0, 1))
+    dx = K.clamp_bwd(x, g, 0.5, 0.5, 0.0, 1.0)
+    ref = 0.5 * g * ((g * (u - u.clamp(0, 1))) >= 0)
+    assert torch.allclose(dx, ref)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_sumpool(cuda, dt):
+    x = _mk((2, 6, 10, 64), dt, cuda, 1)
+    y = K.sumpool2x2(x)
+    ref = F.avg_pool2d(x.double().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1) * 4
+    assert _rel(y, ref) < _tol(dt)
+
+
+def test_vq_and_gather(cuda):
+    x, cb = _mk((300, 64), torch.float32, cuda, 1), _mk((1000, 64), torch.float32, cuda, 2)
+    xn, cn = K.rownorm_sq(x), K.rownorm_sq(cb)
+    assert _rel(xn, x.double().pow(2).sum(-1)) < 1e-6
+    dot = torch.empty(300, 1000, dtype=torch.float32, device=cuda)
+    K.gemm(x, cb, dot, 300, 1000, 64, ldx=64, ldw=64)
+    idx = K.vq_argmin(dot, xn, cn)
+    d = x.double().pow(2).sum(-1, keepdim=True) + cb.double().pow(2).sum(1) - 2 * x.double() @ cb.double().T
+    assert (idx == d.argmin(-1)).float().mean() > 0.995
+    # exact tie -> first index
+    cb2 = cb.clone()
+    cb2[500] = cb2[3]
+    K.gemm(x, cb2, dot, 300, 1000, 64, ldx=64, ldw=64)
+    idx2 = K.vq_argmin(dot, xn, K.rownorm_sq(cb2))
+    assert (idx2 != 500).all()
+    zq = K.gather_rows(cb, idx, torch.float32)
+    assert torch.equal(zq, cb[idx])
+    pos = _mk((7, 64), torch.float32, cuda, 3)
+    tok = torch.randint(0, 1000, (6, 7), device=cuda)
+    e = K.gather_rows(cb, tok, torch.bfloat16, pos=pos, period=7)
+    assert torch.equal(e, (cb[tok] + pos).bfloat16())
+    tok[:, 0] = 999
+    tok[2, 5] = 999  # tie: first wins
+    tok[3, 0] = 5
+    tok[3, 4] = 999
+    xx = _mk((6, 7, 64), torch.float32, cuda, 4)
+    out = K.eot_gather(xx, tok)
+    assert torch.equal(out, xx[torch.arange(6, device=cuda), tok.argmax(-1)])
+
+
+@pytest.mark.parametrize("odt", DT)
+@pytest.mark.parametrize("H,cut,P", [(256, 224, 32), (40, 32, 8), (64, 64, 16)])
+def test_cutouts(cuda, odt, H, cut, P):
+    B, cutn = 2, 3
+    g = torch.Generator().manual_seed(1)
+    xr = torch.rand(B, H, H, 3, generator=g).to(cuda)
+    noise = torch.randn(cutn * B, 3, cut, cut, generator=g).to(cuda)
+    facs = (torch.rand(cutn * B, generator=g) * 0.1).to(cuda)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    out = K.cutouts_fwd(xr, cut, cutn, P, mean, std, odt, noise=noise, facs=facs)
+    xd = xr.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    c = (F.adaptive_avg_pool2d(xd, cut) + F.adaptive_max_pool2d(xd, cut)) / 2
+    batch = c.repeat(cutn, 1, 1, 1) + facs.double().view(-1, 1, 1, 1) * noise.double()
+    m = torch.tensor(mean, device=cuda, dtype=torch.float64).view(1, 3, 1, 1)
+    s = torch.tensor(std, device=cuda, dtype=torch.float64).view(1, 3, 1, 1)
+    ref = (batch - m) / s
+    gw = cut // P
+    ref_p = ref.view(cutn * B, 3, gw, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(cutn * B, gw * gw, 3 * P * P)
+    assert _rel(out, ref_p) < _tol(odt)
+    gout = _mk(tuple(out.shape), odt, cuda, 5)
+    dxr = K.cutouts_bwd(xr, gout, cut, cutn, P, std)
+    ref_p.backward(gout.double())
+    assert _rel(dxr, xd.grad.permute(0, 2, 3, 1)) < 3e-5
+
+
+def test_spherical_loss(cuda):
+    N, B, D = 24, 8, 512
+    e = _mk((N, D), torch.float32, cuda, 1)
+    f = _mk((B, D), torch.float32, cuda, 2)
+    loss, de = K.spherical_loss(e, f, coef=1.0)
+    ed = e.double().requires_grad_(True)
+    Hn = F.normalize(f.double().repeat(N // B, 1), dim=-1)
+    En = F.normalize(ed, dim=1)
+    ref = Hn.sub(En).norm(dim=-1).div(2).arcsin().pow(2).mul(2).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-6
+    assert _rel(de, ed.grad) < 1e-5
+
+
+@pytest.mark.parametrize("sdt", [None, torch.bfloat16])
+def test_adam(cuda, sdt):
+    n = 10007
+    p, g = _mk((n,), torch.float32, cuda, 1), _mk((n,), torch.float32, cuda, 2)
+    pp = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pp], lr=1e-2)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sh = torch.empty(n, dtype=sdt, device=cuda) if sdt else None
+    for step in range(1, 4):
+        gg = g * step
+        pp.grad = gg.clone()
+        opt.step()
+        K.adam(p, gg, m, v, sh, 1e-2, 0.9, 0.999, 1e-8, step)
+        assert _rel(p, pp.data) < 1e-6
+    if sdt:
+        assert torch.equal(sh, p.bfloat16())
+    ss = torch.zeros(1, dtype=torch.float32, device=cuda)
+    K.sumsq(g, ss)
+    assert abs(ss.item() - g.double().pow(2).sum().item()) / ss.item() < 1e-5
+    y = torch.ones_like(g)
+    K.axpby(g, y, 2.0, 3.0)
+    assert torch.allclose(y, 2 * g + 3)
