@@ -1,0 +1,93 @@
+"""ParamArena — flat HBM layout of a trainable mapper.
+
+All parameters of the mapper live in ONE contiguous fp32 bucket (`params`), their gradients in a
+second one (`grads`, `p.grad` are views), and the compute-dtype copies the MFMA kernels read in a
+third (`shadow`, same offsets).  This is what makes the step cheap on MI355X:
+  * one fused Adam launch updates params + m + v and rewrites the bf16 shadow in the same pass,
+  * the data-parallel all-reduce runs over a handful of large contiguous bucket slices
+    (RCCL over xGMI is per-link bound, so few large messages beat hundreds of small ones),
+  * `zero_grad` is a single memset.
+Transposed shadows (W^T, so that dgrad is a K-major GEMM) are refreshed by batched transposes.
+"""
+import torch
+
+from . import kernels as K
+from .ops import Weights
+
+_ALIGN = 64  # elements; keeps every view 256-byte aligned for 16-byte vector access
+
+
+class ParamArena:
+    def __init__(self, module, cdt, allow_cpu=False):
+        """allow_cpu=True builds only the flat params/grads buckets (no shadows, no kernels): used by the
+        gloo world_size>1 tests of the data-parallel bucket logic, never by the product path."""
+        self.cdt = cdt
+        self.module = module
+        ps = [p for p in module.parameters()]
+        if not ps:
+            raise ValueError("ParamArena: module has no parameters")
+        dev = ps[0].device
+        if dev.type != "cuda" and not allow_cpu:
+            raise RuntimeError("ParamArena needs the module on a CUDA(HIP) device; there is no CPU path")
+        self.offsets, off = [], 0
+        for p in ps:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.plist = ps
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = self.params if cdt == torch.float32 else torch.zeros(off, dtype=cdt, device=dev)
+        for p, o in zip(ps, self.offsets):
+            n = p.numel()
+            self.params[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+            p._ffvc_arena = self
+        self._index = {id(p): i for i, p in enumerate(ps)}
+        self._packs = []          # (Weights, param index) needing a transposed shadow
+        self._grad_cbs = []
+        module._ffvc_arena = self
+
+    # -- shadows ------------------------------------------------------------
+    def shadow_of(self, p):
+        i = self._index[id(p)]
+        o = self.offsets[i]
+        return self.shadow[o:o + p.numel()].view(p.shape)
+
+    def make_weights(self, weight, bias):
+        """Weights pack for a trainable [N, K, ...] parameter (Conv1d k=1 weights are viewed as [N, K])."""
+        sh = self.shadow_of(weight).view(weight.shape[0], -1)
+        sht = torch.empty(sh.shape[1], sh.shape[0], dtype=self.cdt, device=sh.device)
+        W = Weights(weight, bias, sh, sht, on_grad=self._on_grad)
+        self._packs.append(W)
+        return W
+
+    def refresh(self, cast=True):
+        """Re-derive the shadows from the fp32 masters (after load_state_dict / an optimizer step)."""
+        if cast and self.cdt != torch.float32:
+            K.cast_into(self.params, self.shadow)
+        for W in self._packs:
+            K.transpose(W.sh, out=W.sht)
+
+    # -- gradients ----------------------------------------------------------
+    def zero_grad(self):
+        self.grads.zero_()
+        for p in self.plist:            # someone (e.g. optimizer.zero_grad(set_to_none=True)) may have dropped the views
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * self.offsets[self._index[id(p)]]:
+                o = self.offsets[self._index[id(p)]]
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+
+    def add_grad_callback(self, fn):
+        """fn(param) is called when a parameter's gradient has been fully written in backward."""
+        self._grad_cbs.append(fn)
+
+    def _on_grad(self, W):
+        for fn in self._grad_cbs:
+            fn(W.weight)
+            if W.bias is not None:
+                fn(W.bias)
+
+    def param_range(self, p):
+        i = self._index[id(p)]
+        return self.offsets[i], p.numel()

@@ -416,6 +416,58 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
     y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
 }
 
+// out[r % period] += sum_c x[r, c]; one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                     int cols, int period) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    float a = 0.f;
+    for (int c = lane; c < cols; c += 64) a += ElemTraits<T>::load(x + r * cols + c);
+    a = wave_sum(a);
+    if (lane == 0) atomicAdd(out + (r % period), a);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ s, int64_t ss, float* __restrict__ d,
+                                                        int64_t ds, int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    d[r * ds + c] = s[r * ss + c];
+  }
+}
+
+template <typename XT, typename OT>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const XT* __restrict__ x, OT* __restrict__ out, int B, int H,
+                                                        int W, int C, int Kp) {
+  const int64_t n = (int64_t)B * H * W * Kp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    int64_t p = i / Kp;
+    const int xx = (int)(p % W);
+    p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    float v = 0.f;
+    if (k < 9 * C) {
+      const int tap = k / C, c = k - tap * C;
+      const int iy = yy + tap / 3 - 1, ix = xx + tap % 3 - 1;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = ElemTraits<XT>::load(x + (((int64_t)b * H + iy) * W + ix) * C + c);
+    }
+    ElemTraits<OT>::store(out + i, v);
+  }
+}
+
+// y = x * s[0] with the scalar read from device memory (backward of the loss w.r.t. an upstream scalar grad)
+__global__ __launch_bounds__(256) void mul_dev_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                             float* __restrict__ y, int64_t n) {
+  const float k = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * k;
+}
+
 }  // namespace
 
 extern "C" int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
@@ -603,6 +655,51 @@ extern "C" int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream) {
 extern "C" int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream) {
   FFVC_CHECK_ARG(x && y && n > 0, "ffvc_axpby: bad args");
   hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_rowsum(const void* x, int dtype, float* out, int64_t rows, int cols, int period, int accumulate,
+                           void* stream) {
+  FFVC_CHECK_ARG(x && out && rows > 0 && cols > 0 && period > 0, "ffvc_rowsum: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)period * sizeof(float), st);
+    if (e != hipSuccess) {
+      ffvc_set_error("ffvc_rowsum: memset failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  DISPATCH_DT(dtype, T, hipLaunchKernelGGL((rowsum_kernel<T>), dim3(ew_grid(rows, 4)), dim3(256), 0, st, (const T*)x,
+                                           out, rows, cols, period));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_copy_rows(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows,
+                              int cols, void* stream) {
+  FFVC_CHECK_ARG(src && dst && rows > 0 && cols > 0, "ffvc_copy_rows: bad args");
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(rows * cols, 1024)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_stride, dst, dst_stride, rows, cols);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_im2col3x3(const void* x, int x_dtype, void* out, int out_dtype, int B, int H, int W, int C, int Kp,
+                              void* stream) {
+  FFVC_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && C > 0 && Kp >= 9 * C, "ffvc_im2col3x3: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * H * W * Kp;
+  DISPATCH_DT(x_dtype, XT, DISPATCH_DT(out_dtype, OT,
+              hipLaunchKernelGGL((im2col3x3_kernel<XT, OT>), dim3(ew_grid(n, 1024)), dim3(256), 0, st, (const XT*)x,
+                                 (OT*)out, B, H, W, C, Kp)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_mul_dev_scalar(const float* x, const float* s, float* y, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(x && s && y && n > 0, "ffvc_mul_dev_scalar: bad args");
+  hipLaunchKernelGGL(mul_dev_scalar_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

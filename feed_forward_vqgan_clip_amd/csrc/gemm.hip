@@ -87,7 +87,7 @@ struct Stager<T, FFVC_OP_KMAJOR> {
   int kseg;
   int64_t kso;
   __device__ __forceinline__ void init(const T* base, int64_t ld, int row0, int rows, int kseg_,
-                                       int64_t kso_, int tid) {
+                                       int64_t kso_, int tid, int mi = 0, int64_t so = 0) {
     kc = (tid & 7) * EPC;
     kseg = kseg_;
     kso = kso_;
@@ -95,7 +95,8 @@ struct Stager<T, FFVC_OP_KMAJOR> {
     for (int q = 0; q < 4; ++q) {
       const int r = row0 + (tid >> 3) + 32 * q;
       rvalid[q] = r < rows;
-      rowp[q] = base + (int64_t)(rvalid[q] ? r : 0) * ld;
+      const int rr = rvalid[q] ? r : 0;
+      rowp[q] = base + (mi ? (int64_t)(rr / mi) * so + (int64_t)(rr % mi) * ld : (int64_t)rr * ld);
     }
   }
   __device__ __forceinline__ void load(u32x4_t (&reg)[4], int k0, int kend) {
@@ -129,7 +130,7 @@ struct Stager<T, FFVC_OP_TRANS> {
   int nvalid;  // how many of this thread's EPC columns are in range (<=0: none)
   int krow;
   __device__ __forceinline__ void init(const T* base, int64_t ld_, int row0, int rows, int, int64_t,
-                                       int tid) {
+                                       int tid, int = 0, int64_t = 0) {
     const int c = row0 + (tid % CPR) * EPC;
     nvalid = rows - c;
     colp = base + (nvalid > 0 ? c : 0);
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
     sx.init(xb, 0, m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0,
             tid);
   else
-    sx.init(xb, p.ldx, m0, p.M, p.kseg, p.xkso, tid);
+    sx.init(xb, p.ldx, m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
   sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid);
 
   f32x16_t acc[2][2];
@@ -564,6 +565,9 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
                  "ffvc_gemm: operand base pointers must be 16-byte aligned");
   FFVC_CHECK_ARG(mult(d.xbo, epc) && mult(d.xbi, epc) && mult(d.wbo, epc) && mult(d.wbi, epc),
                  "ffvc_gemm: operand batch strides must be multiples of %d", epc);
+  if (d.x_mi) {
+    FFVC_CHECK_ARG(d.x_mode == FFVC_OP_KMAJOR && mult(d.x_so, epc), "ffvc_gemm: x row map needs a K-major X and aligned x_so");
+  }
   if (d.y_sm == 0 && d.y_mi == 0) d.y_sm = d.N;
   // vectorised epilogue only when every row offset keeps 16-byte (fp32) / 8-byte (bf16) alignment
   int vec_ok = mult(d.y_sm, 4) && mult(d.y_so, 4) && mult(d.ybo, 4) && mult(d.ybi, 4) &&

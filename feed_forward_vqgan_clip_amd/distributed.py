@@ -1,0 +1,262 @@
+"""Data-parallel layer: the Horovod surface main.py uses, re-built for MI355X.
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" on CPU for
+tests).  Gradients live in ONE flat fp32 bucket (arena.grads); DistributedOptimizer cuts it into
+a few large contiguous slices in reverse-forward order and launches an asynchronous all-reduce
+for a slice as soon as every parameter in it has its gradient (fused-wgrad callback or autograd
+post-accumulate hook), so the exchange overlaps the rest of the backward pass.  xGMI rings are
+per-link bound, hence few large messages (default 64 MiB) and an optional bf16 wire format.
+The 1/world_size average is folded into the fused Adam kernel instead of a separate pass.
+
+Reference call sites: hvd.init/rank/size/local_rank main.py:528-531; DistributedOptimizer :627;
+broadcast_parameters :628; broadcast_optimizer_state :629; broadcast :685-687; allreduce :838-842.
+Unlike the reference, clip_grad_norm runs AFTER the gradient exchange (SURVEY.md §2c defect note).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+_STATE = {"init": False}
+
+
+def init(backend=None):
+    """hvd.init(): reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment."""
+    if _STATE["init"]:
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank())
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank())
+        dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kw)
+    _STATE["init"] = True
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank():
+    return dist.get_rank() if is_distributed() else 0
+
+
+def size():
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def allreduce(tensor, average=True):
+    """hvd.allreduce: returns the (averaged) sum over ranks; used for the 4 log scalars (main.py:838-842)."""
+    if not is_distributed():
+        return tensor
+    t = tensor.detach().clone()
+    dist.all_reduce(t)
+    return t / size() if average else t
+
+
+def allreduce_scalars(*tensors):
+    """One fused all-reduce for several scalars instead of the reference's four blocking ones."""
+    if not is_distributed():
+        return tensors
+    buf = torch.stack([t.detach().float().reshape(()) for t in tensors])
+    dist.all_reduce(buf)
+    buf /= size()
+    return tuple(buf[i] for i in range(len(tensors)))
+
+
+def broadcast(tensor, root_rank=0):
+    if is_distributed():
+        dist.broadcast(tensor, src=root_rank)
+    return tensor
+
+
+def broadcast_parameters(module_or_state_dict, root_rank=0):
+    """hvd.broadcast_parameters(net.state_dict(), 0): one broadcast of the flat bucket when available."""
+    if not is_distributed():
+        return
+    arena = getattr(module_or_state_dict, "_ffvc_arena", None)
+    if arena is not None:
+        dist.broadcast(arena.params, src=root_rank)
+        arena.refresh()
+        return
+    sd = module_or_state_dict.state_dict() if hasattr(module_or_state_dict, "state_dict") else module_or_state_dict
+    for _, t in sorted(sd.items()):
+        if torch.is_tensor(t):
+            dist.broadcast(t, src=root_rank)
+
+
+def broadcast_optimizer_state(opt, root_rank=0):
+    if not is_distributed():
+        return
+    inner = getattr(opt, "opt", opt)
+    if hasattr(inner, "_m"):
+        dist.broadcast(inner._m, src=root_rank)
+        dist.broadcast(inner._v, src=root_rank)
+        step = torch.tensor([inner._step], dtype=torch.int64, device=inner._m.device)
+        dist.broadcast(step, src=root_rank)
+        inner._step = int(step.item())
+    else:
+        for st in inner.state.values():
+            for v in st.values():
+                if torch.is_tensor(v):
+                    dist.broadcast(v, src=root_rank)
+
+
+class DistributedOptimizer:
+    """hvd.DistributedOptimizer(opt): `.step()` sees gradients averaged over ranks.
+
+    opt must expose `.arena` (flat `grads`, `plist`, `param_range`, `add_grad_callback`), or an
+    arena can be passed explicitly.  bucket_bytes: target slice size; wire_dtype: None (fp32) or
+    torch.bfloat16 (halves xGMI traffic; the sum is still accumulated by RCCL in bf16).
+    """
+
+    def __init__(self, opt, arena=None, bucket_bytes=64 << 20, wire_dtype=None):
+        self.opt = opt
+        self.arena = arena if arena is not None else opt.arena
+        self.wire_dtype = wire_dtype
+        a = self.arena
+        # buckets in reverse registration order (= the order backward produces gradients)
+        self.buckets = []           # (start_elem, end_elem, [param indices])
+        cur, cur_end, cur_bytes = [], None, 0
+        for i in reversed(range(len(a.plist))):
+            o, n = a.param_range(a.plist[i])
+            if cur_end is None:
+                cur_end = self._aligned_end(i)
+            cur.append(i)
+            cur_bytes += n * 4
+            if cur_bytes >= bucket_bytes:
+                self.buckets.append((o, cur_end, cur))
+                cur, cur_end, cur_bytes = [], None, 0
+        if cur:
+            self.buckets.append((a.param_range(a.plist[cur[-1]])[0], cur_end, cur))
+        self._bucket_of = {}
+        for b, (_, _, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                self._bucket_of[id(a.plist[i])] = b
+        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+        self._seen = set()
+        self._handles = {}
+        self._wire = {}
+        a.add_grad_callback(self._param_ready)
+        for p in a.plist:
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._param_ready)
+        self.param_groups = opt.param_groups
+
+    def _aligned_end(self, i):
+        a = self.arena
+        return a.offsets[i + 1] if i + 1 < len(a.plist) else a.total
+
+    # -- gradient-ready plumbing ------------------------------------------------
+    def _param_ready(self, p):
+        if not is_distributed() or id(p) in self._seen:
+            return
+        self._seen.add(id(p))
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        g = self.arena.grads[s:e]
+        if self.wire_dtype is not None and self.wire_dtype != g.dtype:
+            w = g.to(self.wire_dtype)
+            self._wire[b] = w
+            self._handles[b] = dist.all_reduce(w, async_op=True)
+        else:
+            self._handles[b] = dist.all_reduce(g, async_op=True)
+
+    def synchronize(self):
+        """Flush buckets that never completed (unused params), wait for every exchange."""
+        if is_distributed():
+            for b in range(len(self.buckets)):
+                if b not in self._handles:
+                    self._launch(b)
+            for b, h in self._handles.items():
+                h.wait()
+                if b in self._wire:
+                    s, e, _ = self.buckets[b]
+                    self.arena.grads[s:e].copy_(self._wire[b])
+        self._handles, self._wire = {}, {}
+        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+        self._seen = set()
+
+    # -- optimizer surface --------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        if hasattr(self.opt, "arena"):
+            self.opt.zero_grad()
+        else:
+            self.arena.zero_grad()
+
+    def clip_grad_norm_(self, max_norm):
+        self.synchronize()
+        self._synced = True
+        if hasattr(self.opt, "clip_grad_norm_"):
+            self._set_scale()
+            return self.opt.clip_grad_norm_(max_norm)
+        self.arena.grads.div_(size())
+        self._prescaled = True
+        return torch.nn.utils.clip_grad_norm_(self.arena.plist, max_norm)
+
+    def _set_scale(self):
+        if hasattr(self.opt, "grad_scale"):
+            self.opt.grad_scale = 1.0 / size()
+            return True
+        return False
+
+    def step(self, closure=None):
+        if not getattr(self, "_synced", False):
+            self.synchronize()
+        self._synced = False
+        if not self._set_scale() and not getattr(self, "_prescaled", False) and size() > 1:
+            self.arena.grads.div_(size())
+        self._prescaled = False
+        return self.opt.step()
+
+    def state_dict(self):
+        return self.opt.state_dict()
+
+    def load_state_dict(self, sd):
+        return self.opt.load_state_dict(sd)
+
+
+class DistributedSampler:
+    """torch.utils.data.DistributedSampler index math (main.py:668-674): epoch-seeded permutation, padded to a
+    multiple of world size, strided `indices[rank::size]`."""
+
+    def __init__(self, n, num_replicas=None, rank_=None, shuffle=True, seed=0):
+        self.n = n
+        self.world = num_replicas if num_replicas is not None else size()
+        self.rank = rank_ if rank_ is not None else rank()
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
+        self.num_samples = (n + self.world - 1) // self.world
+        self.total = self.num_samples * self.world
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        pad = self.total - len(idx)
+        if pad > 0:
+            idx += (idx * ((pad + len(idx) - 1) // len(idx) + 1))[:pad]
+        return iter(idx[self.rank:self.total:self.world])
+
+    def __len__(self):
+        return self.num_samples

@@ -40,7 +40,7 @@ def _need_cuda(*ts):
 def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, bias=None,
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
-         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None):
+         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None):
     """Enqueue `ffvc_gemm`. See include/ffvc.h for the index maps.
 
     y_map / r_map = (mi, so, sm): row offset(m) = (m // mi) * so + (m % mi) * sm (mi = 0: m * sm).
@@ -85,6 +85,8 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     d.abo, d.abi = ab
     if conv is not None:
         d.conv_H, d.conv_W, d.conv_Cin = conv
+    if x_map is not None:
+        d.x_mi, d.x_so = x_map
     lib = _lib.load()
     _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
     return y
@@ -324,4 +326,30 @@ def sumsq(x, out):
 
 def axpby(x, y, a, b):
     _call("ffvc_axpby", x.data_ptr(), y.data_ptr(), x.numel(), a, b, stream_ptr())
+    return y
+
+
+def rowsum(x, out, period, accumulate=False):
+    cols = x.shape[-1]
+    _call("ffvc_rowsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), x.numel() // cols, cols, period,
+          int(accumulate), stream_ptr())
+    return out
+
+
+def copy_rows(src, src_stride, dst, dst_stride, rows, cols):
+    _call("ffvc_copy_rows", src.data_ptr(), src_stride, dst.data_ptr(), dst_stride, rows, cols, stream_ptr())
+    return dst
+
+
+def im2col3x3(x, out_dtype, Kp):
+    B, H, W, C = x.shape
+    out = torch.empty(B * H * W, Kp, dtype=out_dtype, device=x.device)
+    _call("ffvc_im2col3x3", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), dtype_code(out_dtype), B, H, W, C, Kp,
+          stream_ptr())
+    return out
+
+
+def mul_dev_scalar(x, s):
+    y = torch.empty_like(x)
+    _call("ffvc_mul_dev_scalar", x.data_ptr(), s.data_ptr(), y.data_ptr(), x.numel(), stream_ptr())
     return y

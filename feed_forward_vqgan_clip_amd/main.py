@@ -1,0 +1,344 @@
+"""Host surface of the training hot path — same names / config keys / call order as the
+reference's main.py (`train`, `build_model`, `load_model`, `load_dataset`, `load_clip_model`,
+`load_vqgan_model`, `MakeCutouts`, `synth`, `vector_quantize`, `clamp_with_grad`,
+`replace_grad`, `tv_loss`), with every tensor op of the step running in ffvc HIP kernels.
+
+    python -m feed_forward_vqgan_clip_amd.main train configs/example.yaml
+
+Only the `train` path is built; `test`, `evaluate`, `tokenize`,
+`encode_text_and_images*`, `train_prior` are out of scope for this round.
+No weights / BPE vocabulary ship with this repo: `vqgan_checkpoint: "random:<seed>"`,
+`clip_model_path: "random:<seed>"` and `path: "synthetic:<n>"` select seeded synthetic
+weights / token batches.
+"""
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+from torch import nn
+
+from . import clip as _clip
+from . import distributed as hvd
+from . import kernels as K
+from . import ops
+from . import vqgan as _vqgan
+from .mappers import Mixer
+from .optim import CosineAnnealingLR, FusedAdam
+from .vqgan import load_vqgan_model, synth, synth_nhwc, vector_quantize  # noqa: F401
+
+CLIP_SIZE = {"RN50": 224, "RN101": 224, "RN50x4": 288, "RN50x16": 384, "ViT-B/32": 224, "ViT-B/16": 224,
+             "ViT-L/14": 224, "openclip/ViT-B-32-quickgelu/laion400m_e32": 224, "openclip/ViT-B-32/laion2b_e16": 224}
+CLIP_DIM = {"RN50": 1024, "RN101": 512, "RN50x4": 640, "RN50x16": 768, "ViT-B/32": 512, "ViT-B/16": 512,
+            "ViT-L/14": 768, "openclip/ViT-B-32-quickgelu/laion400m_e32": 512, "openclip/ViT-B-32/laion2b_e16": 512}
+CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
+CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
+SOT, EOT = 49406, 49407
+
+
+class Config(dict):
+    """OmegaConf-like: attribute access for required keys (KeyError -> AttributeError), `.get` for optional."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(f"missing config key '{k}'")
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def load(path):
+        import yaml
+
+        with open(path) as f:
+            return Config(yaml.safe_load(f))
+
+
+def clamp_with_grad(x, lo, hi):
+    """ClampWithGrad.apply (main.py:118-132)."""
+    return ops.clamp_with_grad(x, float(lo), float(hi))
+
+
+class _ReplaceGrad(torch.autograd.Function):
+    """ReplaceGrad (main.py:105-116): value of x_forward, gradient to x_backward (pure autograd routing)."""
+
+    @staticmethod
+    def forward(ctx, x_forward, x_backward):
+        ctx.shape = x_backward.shape
+        return x_forward.view_as(x_forward)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g.sum_to_size(ctx.shape)
+
+
+replace_grad = _ReplaceGrad.apply
+
+
+class MakeCutouts(nn.Module):
+    """main.py:154-229.  Implemented: the pooling branch ((AdaptiveAvg+AdaptiveMax)/2 -> repeat cutn), the 'R'
+    aug at pool_size == cut_size (identity resize) and the additive noise `U(0,noise_fac)*N(0,1)`.
+    The kornia augmentations ('Af','Pe','Ji','Er', ...) are the next hot-path row and raise."""
+
+    def __init__(self, cut_size, cutn, cut_pow=1.0, pool_size=None, interp_size=None, augs=None, pool=True,
+                 interpolate=False):
+        super().__init__()
+        augs = tuple(augs) if augs else ("Af", "Pe", "Ji", "Er")      # main.py:164-165 (empty list -> defaults)
+        if augs != ("R",):
+            raise NotImplementedError(f"augs={list(augs)}: only ['R'] is implemented on the HIP path (kornia "
+                                      "augmentations are SURVEY.md §8f row n1)")
+        pool_size = pool_size or cut_size
+        if not pool or interpolate or pool_size != cut_size:
+            raise NotImplementedError("MakeCutouts: only pool=True, interpolate=False, pool_size == cut_size")
+        self.cut_size, self.cutn, self.noise_fac = cut_size, cutn, 0.1
+
+    def draw_noise(self, n, device):
+        if not self.noise_fac:
+            return None, None
+        facs = torch.empty(n, device=device).uniform_(0, self.noise_fac)             # main.py:224
+        noise = torch.randn(n, 3, self.cut_size, self.cut_size, device=device)       # main.py:225
+        return facs, noise
+
+    def forward(self, input, facs=None, noise=None):
+        """(B,3,H,W) in [0,1] -> (cutn*B, 3, cut, cut) fp32, cut-major like `repeat(cutn,1,1,1)` (main.py:218)."""
+        xr = input.permute(0, 2, 3, 1)
+        if facs is None and self.noise_fac:
+            facs, noise = self.draw_noise(self.cutn * input.shape[0], input.device)
+        out = ops.cutouts(xr.float(), self.cut_size, self.cutn, self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0),
+                          torch.float32, noise=noise, facs=facs)
+        return out.view(self.cutn * input.shape[0], 3, self.cut_size, self.cut_size)
+
+
+def tv_loss(Y_hat):
+    """main.py:423-428 (optional regulariser, tv_coef defaults to 0; plain autograd ops, off the default path)."""
+    return 0.5 * (torch.abs(Y_hat[:, :, 1:, :] - Y_hat[:, :, :-1, :]).mean() +
+                  torch.abs(Y_hat[:, :, :, 1:] - Y_hat[:, :, :, :-1]).mean())
+
+
+def _cdt(config):
+    name = str(config.get("compute_dtype", "bf16"))
+    return {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[name]
+
+
+def load_clip_model(model_type, path=None, cdt=torch.bfloat16):
+    """main.py:1308-1333 for the OpenAI / OpenCLIP ViT families (state_dict in clip.model.CLIP layout)."""
+    arch = {"ViT-B/32": _clip.VIT_B32, "openclip/ViT-B-32-quickgelu/laion400m_e32": _clip.VIT_B32,
+            "ViT-L/14": _clip.VIT_L14}.get(model_type)
+    if arch is None:
+        raise ValueError(f"clip_model '{model_type}' is not built on the HIP path (ViT-B/32, ViT-L/14)")
+    if path is None or str(path).startswith("random:"):
+        seed = int(str(path).split(":", 1)[1]) if path else 1234
+        sd = _clip.random_state_dict(arch, seed)
+    else:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj.get("state_dict", obj)
+    return _clip.CLIP(sd, cdt)
+
+
+def synthetic_tokens(n, seed=0, context_length=77):
+    """Seeded int64 token rows: SOT, L~U{4..30} ids in [1, 49405], EOT (= max id so argmax finds it), zeros."""
+    g = torch.Generator().manual_seed(seed)
+    toks = torch.zeros(n, context_length, dtype=torch.long)
+    L = torch.randint(4, 31, (n,), generator=g)
+    for i in range(n):
+        toks[i, 0] = SOT
+        toks[i, 1:1 + L[i]] = torch.randint(1, SOT, (int(L[i]),), generator=g)
+        toks[i, 1 + L[i]] = EOT
+    return toks
+
+
+def load_dataset(path):
+    """main.py:1293-1306.  `.pkl` files (token tensor or (inp, out) feature tuple) load as in the reference;
+    `synthetic:<n>[:seed]` yields seeded token rows; raw text needs the CLIP BPE vocabulary, which is not shipped."""
+    if path.startswith("synthetic:"):
+        parts = path.split(":")
+        return synthetic_tokens(int(parts[1]), int(parts[2]) if len(parts) > 2 else 0)
+    if path.endswith("pkl"):
+        return torch.load(path, weights_only=False)
+    raise NotImplementedError("text prompts need clip.tokenize (BPE vocabulary not available offline); pre-tokenise to "
+                              "a .pkl or use path: synthetic:<n>  (SURVEY.md §8f row n4)")
+
+
+def build_model(config, vq_channels=None):
+    """main.py:448-502 (the VQGAN is NOT re-loaded here just to read z_channels; pass it in)."""
+    clip_dim = config.get("clip_dim", CLIP_DIM.get(config.clip_model))
+    if vq_channels is None:
+        vq_channels = config.get("vq_channels", 256)
+    vq_image_size = config.get("vq_image_size", 16)
+    noise_dim = config.noise_dim
+    if config.model_type == "mlp_mixer":
+        net = Mixer(input_dim=clip_dim + noise_dim, image_size=vq_image_size, channels=vq_channels, patch_size=1,
+                    dim=config.dim, depth=config.depth, dropout=config.dropout)
+    elif config.model_type in ("vitgan", "simple_vitgan", "xtransformer"):
+        from . import mappers
+        net = mappers.build_other(config, clip_dim + noise_dim, vq_image_size, vq_channels)
+    else:
+        raise ValueError("model_type should be 'vitgan' or  'mlp_mixer' or 'xtransformer'")
+    return net
+
+
+def load_model(path, cdt=torch.bfloat16, vq_channels=256):
+    """main.py:1273-1290 for dict checkpoints {"state_dict","config","step","epoch"}."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    if not isinstance(ckpt, dict):
+        raise NotImplementedError("legacy pickled-module checkpoints (model.th) are not supported")
+    config = Config(ckpt["config"])
+    net = build_model(config, vq_channels)
+    net.load_state_dict(ckpt["state_dict"])
+    net.config = config
+    return net.cuda().prepare(cdt)
+
+
+class TrainStep:
+    """One rank's state for the loop body of `train` (main.py:715-837): mapper, frozen VQGAN + CLIP, cutout
+    parameters, optimizer.  `__call__(inp, out)` performs forward, loss, backward and the optimizer step."""
+
+    def __init__(self, config, net, vq, perceptor, opt, scheduler=None):
+        self.config, self.net, self.vq, self.perceptor, self.opt, self.scheduler = config, net, vq, perceptor, opt, scheduler
+        clip_model = config.clip_model
+        self.clip_size = config.get("clip_size", CLIP_SIZE.get(clip_model))
+        self.clip_dim = config.get("clip_dim", CLIP_DIM.get(clip_model))
+        self.cutn, self.repeat = config.cutn, config.repeat
+        self.make_cutouts = MakeCutouts(cut_size=config.get("cut_size", self.clip_size), cutn=self.cutn,
+                                        augs=config.get("augs"), pool=config.get("pool", True),
+                                        pool_size=config.get("pool_size", self.clip_size),
+                                        interpolate=config.get("interpolate", False),
+                                        interp_size=config.get("interp_size", self.clip_size))
+        if config.get("noise_fac") is not None:
+            self.make_cutouts.noise_fac = config.get("noise_fac")
+        if config.noise_dim or (config.repeat != 1) or config.diversity_coef:
+            raise NotImplementedError("noise_dim > 0, repeat > 1 and diversity_coef > 0 are not built yet")
+        self.target_loss_coef = config.get("target_loss_coef", 1)
+        self.clip_grad_norm = config.get("clip_grad_norm")
+        self.normalize_input = config.get("normalize_input", False)
+        self.l2_coef, self.tv_coef = config.get("l2_coef", 0.0), config.get("tv_coef", 0.0)
+        if config.get("input_loss", False) or self.normalize_input or self.l2_coef or self.tv_coef:
+            raise NotImplementedError("input_loss / normalize_input / l2_coef / tv_coef are not built yet")
+
+    def features(self, t):
+        return self.perceptor.encode_text(t).float() if t.dtype == torch.long else t.float().cuda()
+
+    def forward_loss(self, inp, out=None, facs=None, noise=None):
+        """main.py:729-811 -> (loss, intermediates)."""
+        cfg = self.config
+        inp_feats = self.features(inp)                                          # :733
+        out_feats = inp_feats if (out is None or out is inp) else self.features(out)   # :737 (identical work skipped)
+        z = self.net(inp_feats)                                                 # :754
+        z_nhwc = z.permute(0, 2, 3, 1)                                          # contiguous for NHWC-native mappers
+        z_nhwc = ops.clamp_with_grad(z_nhwc, self.vq.z_min, self.vq.z_max)      # :763
+        xr, idx = synth_nhwc(self.vq, z_nhwc)                                   # :767
+        B = xr.shape[0]
+        mc = self.make_cutouts
+        if facs is None and mc.noise_fac:
+            facs, noise = mc.draw_noise(self.cutn * B, xr.device)
+        patches = ops.cutouts(xr, mc.cut_size, self.cutn, self.perceptor.patch, tuple(CLIP_MEAN), tuple(CLIP_STD),
+                              self.perceptor.cdt, noise=noise, facs=facs)       # :796-797 fused
+        embed = self.perceptor.encode_patches(patches)                          # :799
+        loss = ops.spherical_loss(embed, out_feats, self.target_loss_coef)      # :801-811
+        return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats}
+
+    def __call__(self, inp, out=None, facs=None, noise=None):
+        loss, mid = self.forward_loss(inp, out, facs, noise)
+        self.opt.zero_grad()                                                    # :825
+        loss.backward()                                                         # :832
+        if self.clip_grad_norm:
+            self.opt.clip_grad_norm_(self.clip_grad_norm)                       # :833-834 (after the exchange in DP)
+        self.opt.step()                                                         # :835
+        if self.scheduler is not None:
+            self.scheduler.step()                                               # :836-837
+        return loss.detach(), mid
+
+
+def train(config_file):
+    """main.py:504-974 (train loop; logging reduced to stdout + JSONL scalars, checkpoints as in the reference)."""
+    config = Config.load(config_file)
+    if "folder" not in config:
+        config.folder = os.path.dirname(config_file)
+    os.makedirs(config.folder, exist_ok=True)
+    hvd.init()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(hvd.local_rank())
+    cdt = _cdt(config)
+    toks = load_dataset(config.path)
+    vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt)
+    perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt)
+    vq_channels = vq.codebook.shape[1]
+    checkpoint_path = os.path.join(config.folder, "checkpoint.th")
+    net = build_model(config, vq_channels)
+    net.step, net.epoch = 0, 0
+    if os.path.exists(checkpoint_path):
+        print(f"Resuming model from checkpoint {checkpoint_path}...")
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        net.load_state_dict(ckpt["state_dict"])
+        net.epoch, net.step = ckpt["epoch"], ckpt["step"]
+    net = net.cuda().prepare(cdt)
+    net.config = config
+    opt = FusedAdam(net.parameters(), lr=config.lr)
+    opt_path = os.path.join(config.folder, "opt.th")
+    if os.path.exists(opt_path):
+        print(f"Resuming optimizer state from {opt_path}")
+        opt.load_state_dict(torch.load(opt_path, map_location="cpu", weights_only=False))
+    log_interval = config.get("log_interval", 100)
+    rank_zero = hvd.rank() == 0
+    if hvd.size() > 1:
+        opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if config.get("grad_wire") == "bf16" else None)
+        hvd.broadcast_parameters(net, root_rank=0)
+        hvd.broadcast_optimizer_state(opt, root_rank=0)
+    scheduler = None
+    if config.get("scheduler") is not None:
+        if config.scheduler == "cosine":
+            scheduler = CosineAnnealingLR(opt, T_max=config.max_steps, eta_min=0)
+        else:
+            raise ValueError(config.scheduler)
+    if isinstance(toks, tuple):
+        data = tuple(toks)
+    else:
+        data = (toks, toks)
+    print(f"Number of examples:{len(data[0])}")
+    bs = config.batch_size
+    sampler = hvd.DistributedSampler(len(data[0]), shuffle=True)
+    stepper = TrainStep(config, net, vq, perceptor, opt, scheduler)
+    log_f = open(os.path.join(config.folder, "scalars.jsonl"), "a") if rank_zero else None
+    avg_loss, step = 1.0, net.step
+    t_last = time.time()
+    for epoch in range(net.epoch, config.epochs):
+        sampler.set_epoch(epoch)
+        order = list(iter(sampler))
+        for i in range(0, len(order), bs):
+            sel = torch.tensor(order[i:i + bs])
+            inp, out = data[0][sel].cuda(), data[1][sel].cuda()
+            loss, mid = stepper(inp, None if data[0] is data[1] else out)
+            if step % log_interval == 0 or log_f is None:
+                (loss_r,) = hvd.allreduce_scalars(loss)
+            else:
+                loss_r = loss
+            if rank_zero and step % log_interval == 0:
+                lv = float(loss_r.item())
+                avg_loss = lv * 0.01 + avg_loss * 0.99
+                dt, t_last = time.time() - t_last, time.time()
+                print(f"epoch:{epoch:03d}, step:{step:05d}, avg_loss:{avg_loss:.3f}, loss:{lv:.3f}, dists:{lv:.3f}, "
+                      f"sec/interval:{dt:.2f}")
+                log_f.write(json.dumps({"step": step, "loss": lv, "dists": lv}) + "\n")
+                log_f.flush()
+                net.step = step
+                torch.save({"state_dict": net.state_dict(), "config": dict(config), "step": step, "epoch": epoch},
+                           checkpoint_path)
+                torch.save(opt.state_dict(), opt_path)
+            step += 1
+            if config.get("max_steps") is not None and step >= config.max_steps:
+                return
+
+
+def _cli(argv):
+    if len(argv) >= 2 and argv[0] == "train":
+        return train(argv[1])
+    print("usage: python -m feed_forward_vqgan_clip_amd.main train <config.yaml>", file=sys.stderr)
+    return 2
+
+
+if __name__ == "__main__":
+    sys.exit(_cli(sys.argv[1:]) or 0)

@@ -1,0 +1,572 @@
+"""Differentiable ops of the hot path: torch.autograd.Function wrappers whose forward AND
+backward only enqueue ffvc_* kernels (feed_forward_vqgan_clip_amd/kernels.py).
+
+Conventions
+  * activations are contiguous; `cdt` (compute dtype) is torch.bfloat16 (throughput mode, fp32
+    accumulate) or torch.float32 (parity mode: exact fp32 MFMA).  Residual streams of the mapper
+    and of CLIP are fp32; the decoder is `cdt` end to end.
+  * weights are `Weights` packs: fp32 master (`weight`, `bias`, reference layout/names) plus the
+    `cdt` shadows the GEMMs read: `sh` = same layout [N, K], `sht` = transposed [K, N] (so dgrad
+    is also a K-major GEMM).  For trainable packs, wgrad is written by the GEMM straight into
+    `weight.grad` (a view of the flat gradient bucket) and `on_grad` is called — autograd never
+    materialises or adds weight gradients.
+  * "fork" norms return (normed, identity) so that the skip connection's gradient re-enters the
+    norm's backward kernel as `dres` instead of being added by autograd.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from .kernels import ACT_GELU, ACT_NONE, ACT_QUICKGELU  # noqa: F401
+
+
+# ---------------------------------------------------------------------------
+# weight packs
+# ---------------------------------------------------------------------------
+class Weights:
+    """fp32 master weight [N, K] (+ bias [N]) with compute-dtype shadows."""
+
+    __slots__ = ("weight", "bias", "sh", "sht", "N", "K", "on_grad")
+
+    def __init__(self, weight, bias, sh, sht, on_grad=None):
+        self.weight, self.bias, self.sh, self.sht = weight, bias, sh, sht
+        self.N, self.K = sh.shape[0], sh.shape[1]
+        self.on_grad = on_grad
+
+    @staticmethod
+    def frozen(weight, bias, cdt, need_dgrad=True):
+        """Build shadows once for a frozen layer; weight: fp32 [N, K] (any device -> cuda)."""
+        w = weight.detach().reshape(weight.shape[0], -1).float().cuda().contiguous()
+        b = None if bias is None else bias.detach().float().cuda().contiguous()
+        sh = K.cast(w, cdt) if cdt != torch.float32 else w
+        sht = K.transpose(w, cdt) if need_dgrad else None
+        return Weights(None, b, sh, sht)
+
+
+def _grad_buf(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def _split_k(n_out, k_out, red, bk):
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    if tiles >= 128:
+        return 1
+    return max(1, min((256 + tiles - 1) // tiles, red // (8 * bk)))
+
+
+def _wgrad(dy2d, x2d, W, rows):
+    """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy)."""
+    wg = _grad_buf(W.weight)
+    bk = 64 if dy2d.dtype == torch.bfloat16 else 32
+    sk = _split_k(W.N, W.K, rows, bk)
+    K.gemm(dy2d, x2d, wg, W.N, W.K, rows, ldx=W.N, ldw=W.K, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
+           flags=K.F_ATOMIC_OUT, split_k=sk)
+    if W.bias is not None and W.bias.requires_grad:
+        K.colsum(dy2d, _grad_buf(W.bias), accumulate=True)
+    if W.on_grad is not None:
+        W.on_grad(W)
+
+
+def _as(t, dtype):
+    return t if t.dtype == dtype else K.cast(t, dtype)
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# Linear  (y = x W^T + b [+ residual])
+# ---------------------------------------------------------------------------
+class _LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, W, out_dtype):
+        cdt = W.sh.dtype
+        x = _contig(x)
+        rows = x.numel() // W.K
+        y = torch.empty(*x.shape[:-1], W.N, dtype=out_dtype or cdt, device=x.device)
+        K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual)
+        ctx.W, ctx.rows = W, rows
+        ctx.train = weight is not None and weight.requires_grad
+        ctx.has_res = residual is not None
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x if ctx.train else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, rows = ctx.W, ctx.rows
+        cdt = W.sh.dtype
+        dy = _contig(dy)
+        dyt = _as(dy, cdt)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
+            K.gemm(dyt, W.sht, dx, rows, W.K, W.N, ldx=W.N, ldw=W.N)
+        if ctx.train:
+            (x,) = ctx.saved_tensors
+            _wgrad(dyt, x, W, rows)
+        return dx, None, None, (dy if ctx.has_res else None), None, None
+
+
+def linear(x, W, residual=None, out_dtype=None):
+    return _LinearFn.apply(x, W.weight, W.bias, residual, W, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# MLP  (y = act(x W1^T + b1) W2^T + b2 [+ residual]) — channel mixing, ViT / VitGAN / x-transformer FF
+# ---------------------------------------------------------------------------
+class _MLPFn(Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, W1, W2, act, out_dtype):
+        cdt = W1.sh.dtype
+        x = _contig(x)
+        rows = x.numel() // W1.K
+        h_pre = torch.empty(*x.shape[:-1], W1.N, dtype=cdt, device=x.device)
+        h = torch.empty_like(h_pre)
+        K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
+               flags=K.F_WRITE_PREACT)
+        y = torch.empty(*x.shape[:-1], W2.N, dtype=out_dtype or cdt, device=x.device)
+        K.gemm(h, W2.sh, y, rows, W2.N, W2.K, ldx=W2.K, ldw=W2.K, bias=W2.bias, residual=residual)
+        ctx.W1, ctx.W2, ctx.rows, ctx.act = W1, W2, rows, act
+        ctx.train = w1 is not None and w1.requires_grad
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x if ctx.train else None, h_pre, h if ctx.train else None)
+        ctx.xshape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W1, W2, rows = ctx.W1, ctx.W2, ctx.rows
+        cdt = W1.sh.dtype
+        x, h_pre, h = ctx.saved_tensors
+        dy = _contig(dy)
+        dyt = _as(dy, cdt)
+        dh = torch.empty_like(h_pre)
+        K.gemm(dyt, W2.sht, dh, rows, W2.K, W2.N, ldx=W2.N, ldw=W2.N, aux=h_pre, ldaux=W2.K, act=ctx.act,
+               flags=K.F_MUL_ACT_GRAD)
+        if ctx.train:
+            _wgrad(dyt, h, W2, rows)
+            _wgrad(dh, x, W1, rows)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
+            K.gemm(dh, W1.sht, dx, rows, W1.K, W1.N, ldx=W1.N, ldw=W1.N)
+        return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None, None
+
+
+def mlp(x, W1, W2, act, residual=None, out_dtype=None):
+    return _MLPFn.apply(x, W1.weight, W1.bias, W2.weight, W2.bias, residual, W1, W2, act, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# Token-mixing MLP (Conv1d k=1 over the token axis, mlp_mixer_pytorch.py:28,34):
+#   h[b] = gelu(W1 @ xn[b] + b1[:,None]);  y[b] = W2 @ h[b] + b2[:,None] + residual[b]
+# xn: [B, T, D]; W1: [O, T]; W2: [T, O].  Batched GEMMs with the activation as the TRANS operand.
+# ---------------------------------------------------------------------------
+class _TokenMLPFn(Function):
+    @staticmethod
+    def forward(ctx, xn, w1, b1, w2, b2, residual, W1, W2, out_dtype):
+        cdt = W1.sh.dtype
+        xn = _contig(xn)
+        B, T, D = xn.shape
+        O = W1.N
+        h_pre = torch.empty(B, O, D, dtype=cdt, device=xn.device)
+        h = torch.empty_like(h_pre)
+        K.gemm(W1.sh, xn, h, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, bias=W1.bias, act=ACT_GELU, aux=h_pre, ldaux=D,
+               flags=K.F_WRITE_PREACT | K.F_BIAS_ALONG_M, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
+        y = torch.empty(B, T, D, dtype=out_dtype or cdt, device=xn.device)
+        K.gemm(W2.sh, h, y, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, bias=W2.bias, residual=residual,
+               flags=K.F_BIAS_ALONG_M, batch=B, wb=(O * D, 0), yb=(T * D, 0), rb=(T * D, 0))
+        ctx.W1, ctx.W2 = W1, W2
+        ctx.train = w1 is not None and w1.requires_grad
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(xn if ctx.train else None, h_pre, h if ctx.train else None)
+        ctx.dims = (B, T, D, O)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W1, W2 = ctx.W1, ctx.W2
+        cdt = W1.sh.dtype
+        B, T, D, O = ctx.dims
+        xn, h_pre, h = ctx.saved_tensors
+        dy = _contig(dy)
+        dyt = _as(dy, cdt)
+        # dh_pre[b] = (W2^T @ dy[b]) * gelu'(h_pre[b])
+        dh = torch.empty_like(h_pre)
+        K.gemm(W2.sht, dyt, dh, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, aux=h_pre, ldaux=D, act=ACT_GELU,
+               flags=K.F_MUL_ACT_GRAD, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
+        if ctx.train:
+            bk = 64 if cdt == torch.bfloat16 else 32
+            seg_ok = D % bk == 0
+            for (g, a, W, n_out, k_out) in ((dyt, h, W2, T, O), (dh, xn, W1, O, T)):
+                wg = _grad_buf(W.weight)
+                if seg_ok:
+                    # dW[n,k] = sum_{b,d} g[b][n,d] a[b][k,d]: K-major GEMM over the segmented (b,d) axis
+                    sk = _split_k(n_out, k_out, B * D, bk)
+                    K.gemm(g, a, wg, n_out, k_out, B * D, ldx=D, ldw=D, kseg=D, xkso=n_out * D, wkso=k_out * D,
+                           flags=K.F_ATOMIC_OUT, split_k=sk)
+                else:
+                    for b in range(B):
+                        K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ATOMIC_OUT)
+                if W.bias is not None and W.bias.requires_grad:
+                    K.rowsum(g, _grad_buf(W.bias), n_out, accumulate=True)
+                if W.on_grad is not None:
+                    W.on_grad(W)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, T, D, dtype=cdt, device=dy.device)
+            K.gemm(W1.sht, dh, dx, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, batch=B, wb=(O * D, 0), yb=(T * D, 0))
+        return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None
+
+
+def token_mlp(xn, W1, W2, residual=None, out_dtype=None):
+    return _TokenMLPFn.apply(xn, W1.weight, W1.bias, W2.weight, W2.bias, residual, W1, W2, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# LayerNorm (fork form)
+# ---------------------------------------------------------------------------
+class _LNForkFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, out_dtype, eps):
+        x = _contig(x)
+        g, b = gamma.detach(), beta.detach()
+        y, mean, rstd = K.layernorm_fwd(x, g, b, out_dtype, eps)
+        ctx.save_for_backward(x, g, mean, rstd)
+        ctx.train = gamma.requires_grad
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, g, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None
+        dy = _contig(dy)
+        if dres is not None:
+            dres = _as(_contig(dres), x.dtype)
+        dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=ctx.train)
+        return dx, dg, db, None, None
+
+
+def layernorm_fork(x, gamma, beta, out_dtype, eps=1e-5):
+    """-> (LN(x) in out_dtype, identity alias of x whose gradient is fused into LN's backward)."""
+    return _LNForkFn.apply(x, gamma, beta, out_dtype, eps)
+
+
+def layernorm(x, gamma, beta, out_dtype, eps=1e-5):
+    return _LNForkFn.apply(x, gamma, beta, out_dtype, eps)[0]
+
+
+# ---------------------------------------------------------------------------
+# GroupNorm(32, eps 1e-6) [+ swish] on NHWC (fork form), frozen affine
+# ---------------------------------------------------------------------------
+class _GNForkFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, swish):
+        x = _contig(x)
+        y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.swish = swish
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dy = _as(_contig(dy), x.dtype)
+        if dres is not None:
+            dres = _as(_contig(dres), x.dtype)
+        dx = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=dres, G=32, swish=ctx.swish)
+        return dx, None, None, None
+
+
+def groupnorm_fork(x, gamma, beta, swish=True):
+    return _GNForkFn.apply(x, gamma, beta, swish)
+
+
+# ---------------------------------------------------------------------------
+# 3x3 conv (implicit GEMM, NHWC, frozen weights), optional fused nearest-2x upsample of the input
+# ---------------------------------------------------------------------------
+class ConvWeights:
+    """Frozen 3x3 conv: w [Cout, 3,3,Cin] and the dgrad filter wd [Cin, 3,3,Cout] (flipped taps), both K-major."""
+
+    __slots__ = ("w", "wd", "bias", "Cin", "Cout", "wd_small")
+
+    def __init__(self, weight_oihw, bias, cdt):
+        w = weight_oihw.detach().float().cuda()
+        self.Cout, self.Cin = w.shape[0], w.shape[1]
+        w_k = w.permute(0, 2, 3, 1).contiguous()                         # [Cout, kh, kw, Cin]
+        wd_k = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()             # [Cin, kh', kw', Cout]
+        self.w = _as(w_k.view(self.Cout, 9 * self.Cin), cdt)
+        self.bias = None if bias is None else bias.detach().float().cuda().contiguous()
+        bk = 64 if cdt == torch.bfloat16 else 32
+        self.wd = self.wd_small = None
+        if self.Cout % bk == 0:
+            self.wd = _as(wd_k.view(self.Cin, 9 * self.Cout), cdt)
+        else:
+            # small Cout (conv_out -> RGB): dgrad runs as a plain GEMM over an explicit im2col of dy
+            kp = ((9 * self.Cout + 31) // 32) * 32
+            wds = torch.zeros(self.Cin, kp, dtype=torch.float32, device=w.device)
+            wds[:, :9 * self.Cout] = wd_k.view(self.Cin, 9 * self.Cout)
+            self.wd_small = _as(wds, cdt)
+
+
+class _Conv3x3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, residual, P, upsample, out_dtype):
+        x = _contig(x)
+        B, Hin, Win, Cin = x.shape
+        H, W = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
+        y = torch.empty(B, H, W, P.Cout, dtype=out_dtype or x.dtype, device=x.device)
+        K.gemm(x, P.w, y, B * H * W, P.Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=P.bias,
+               residual=residual, conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0)
+        ctx.P, ctx.upsample, ctx.geom, ctx.cdt = P, upsample, (B, H, W, Cin), x.dtype
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        P = ctx.P
+        B, H, W, Cin = ctx.geom
+        dy = _contig(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxu = torch.empty(B, H, W, Cin, dtype=ctx.cdt, device=dy.device)
+            if P.wd is not None:
+                dyt = _as(dy, ctx.cdt)
+                K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3,
+                       conv=(H, W, P.Cout))
+            else:
+                kp = P.wd_small.shape[1]
+                cols = K.im2col3x3(dy, ctx.cdt, kp)
+                K.gemm(cols, P.wd_small, dxu, B * H * W, Cin, kp, ldx=kp, ldw=kp)
+            dx = K.sumpool2x2(dxu) if ctx.upsample else dxu
+        dres = None
+        if ctx.has_res:
+            dres = dy
+        return dx, dres, None, None, None
+
+
+def conv3x3(x, P, residual=None, upsample=False, out_dtype=None):
+    return _Conv3x3Fn.apply(x, residual, P, upsample, out_dtype)
+
+
+# ---------------------------------------------------------------------------
+# Multi-head attention from a packed qkv tensor [B, T, 3*H*dh] (q | k | v blocks, heads inside)
+# ---------------------------------------------------------------------------
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class _AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, causal):
+        qkv = _contig(qkv)
+        B, T, D3 = qkv.shape
+        D = D3 // 3
+        dh = D // heads
+        Tp = _pad8(T)
+        cdt = qkv.dtype
+        BH = B * heads
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+        S = torch.empty(BH, T, Tp, dtype=torch.float32, device=qkv.device)
+        bs = (T * D3, dh)
+        K.gemm(q, k, S, T, T, dh, ldx=D3, ldw=D3, batch=BH, batch_inner=heads, xb=bs, wb=bs,
+               yb=(heads * T * Tp, T * Tp), y_map=(0, 0, Tp))
+        P = torch.empty(BH, T, Tp, dtype=cdt, device=qkv.device)
+        K.softmax_fwd(S, P, BH * T, T, Tp, Tp, scale=scale, causal=causal, q_len=T)
+        o = torch.empty(B, T, D, dtype=cdt, device=qkv.device)
+        K.gemm(P, v, o, T, dh, T, ldx=Tp, ldw=D3, w_mode=K.OP_TRANS, batch=BH, batch_inner=heads,
+               xb=(heads * T * Tp, T * Tp), wb=bs, yb=(T * D, dh), y_map=(0, 0, D))
+        ctx.save_for_backward(qkv, P)
+        ctx.cfg = (B, T, D, heads, dh, Tp, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P = ctx.saved_tensors
+        B, T, D, heads, dh, Tp, scale = ctx.cfg
+        D3, BH, cdt = 3 * D, B * heads, qkv.dtype
+        do = _as(_contig(do), cdt)
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+        bs = (T * D3, dh)
+        pb = (heads * T * Tp, T * Tp)
+        ob = (T * D, dh)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:]
+        # dP = dO V^T
+        dP = torch.empty(BH, T, Tp, dtype=torch.float32, device=do.device)
+        K.gemm(do, v, dP, T, T, dh, ldx=D, ldw=D3, batch=BH, batch_inner=heads, xb=ob, wb=bs, yb=pb, y_map=(0, 0, Tp))
+        # dV = P^T dO
+        K.gemm(P, do, dv, T, dh, T, ldx=Tp, ldw=D, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS, batch=BH, batch_inner=heads,
+               xb=pb, wb=ob, yb=bs, y_map=(0, 0, D3))
+        dS = torch.empty_like(P)
+        K.softmax_bwd(P, dP, dS, BH * T, T, Tp, Tp, scale=scale)
+        # dQ = dS K ; dK = dS^T Q
+        K.gemm(dS, k, dq, T, dh, T, ldx=Tp, ldw=D3, w_mode=K.OP_TRANS, batch=BH, batch_inner=heads, xb=pb, wb=bs,
+               yb=bs, y_map=(0, 0, D3))
+        K.gemm(dS, q, dk, T, dh, T, ldx=Tp, ldw=D3, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS, batch=BH,
+               batch_inner=heads, xb=pb, wb=bs, yb=bs, y_map=(0, 0, D3))
+        return dqkv, None, None, None
+
+
+def attention(qkv, heads, scale, causal=False):
+    return _AttentionFn.apply(qkv, heads, scale, causal)
+
+
+# ---------------------------------------------------------------------------
+# Glue: clamp-with-grad, VQ (straight-through), cutouts, patch embedding, loss
+# ---------------------------------------------------------------------------
+class _ClampFn(Function):
+    @staticmethod
+    def forward(ctx, x, mul, add, lo, hi, out_dtype):
+        x = _contig(x)
+        ctx.save_for_backward(x)
+        ctx.p = (mul, add, lo, hi)
+        return K.clamp_fwd(x, out_dtype or x.dtype, mul, add, lo, hi)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return K.clamp_bwd(x, _contig(g), *ctx.p), None, None, None, None, None
+
+
+def clamp_with_grad(x, lo, hi, mul=1.0, add=0.0, out_dtype=None):
+    """ClampWithGrad (main.py:118-132) of u = x*mul + add."""
+    return _ClampFn.apply(x, float(mul), float(add), float(lo), float(hi), out_dtype)
+
+
+class _VQFn(Function):
+    @staticmethod
+    def forward(ctx, z, codebook, cnorm, out_dtype):
+        z = _contig(z)
+        C = z.shape[-1]
+        rows = z.numel() // C
+        n = codebook.shape[0]
+        dot = torch.empty(rows, n, dtype=torch.float32, device=z.device)
+        K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
+        idx = K.vq_argmin(dot, K.rownorm_sq(z), cnorm)
+        ctx.zdtype = z.dtype
+        ctx.mark_non_differentiable(idx)
+        return K.gather_rows(codebook, idx.view(z.shape[:-1]), out_dtype), idx
+
+    @staticmethod
+    def backward(ctx, g, _):
+        return _as(_contig(g), ctx.zdtype), None, None, None      # straight-through (main.py:105-116,138)
+
+
+def vector_quantize(z, codebook, cnorm, out_dtype):
+    """z: (..., C) fp32 -> (z_q in out_dtype, indices). Nearest code, STE gradient (main.py:134-138)."""
+    return _VQFn.apply(z, codebook, cnorm, out_dtype)
+
+
+class _CutoutsFn(Function):
+    @staticmethod
+    def forward(ctx, xr, noise, facs, cut, cutn, patch, mean, std, out_dtype):
+        xr = _contig(xr)
+        ctx.save_for_backward(xr)
+        ctx.cfg = (cut, cutn, patch, std)
+        return K.cutouts_fwd(xr, cut, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xr,) = ctx.saved_tensors
+        cut, cutn, patch, std = ctx.cfg
+        return K.cutouts_bwd(xr, _contig(g), cut, cutn, patch, std), None, None, None, None, None, None, None, None
+
+
+def cutouts(xr, cut, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
+    return _CutoutsFn.apply(xr, noise, facs, cut, cutn, patch, mean, std, out_dtype)
+
+
+class _PatchEmbedFn(Function):
+    """tokens[n, 1+p, :] = patches[n, p, :] @ Wc^T + pos[1+p]; tokens[n, 0] = cls + pos[0]  (cloob.py:237-244)."""
+
+    @staticmethod
+    def forward(ctx, patches, W, cls_pos0, pos):
+        N, Pn, Kd = patches.shape
+        width = W.N
+        tok = torch.empty(N, Pn + 1, width, dtype=torch.float32, device=patches.device)
+        K.gemm(patches, W.sh, tok[:, 1:], N * Pn, width, Kd, ldx=Kd, ldw=Kd, y_map=(Pn, (Pn + 1) * width, width),
+               residual=pos[1:], r_map=(Pn, 0, width))
+        K.copy_rows(cls_pos0, 0, tok, (Pn + 1) * width, N, width)
+        ctx.W, ctx.dims, ctx.cdt = W, (N, Pn, Kd, width), patches.dtype
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        W = ctx.W
+        N, Pn, Kd, width = ctx.dims
+        dt = _as(_contig(dtok), ctx.cdt)
+        dp = torch.empty(N, Pn, Kd, dtype=ctx.cdt, device=dtok.device)
+        K.gemm(dt[:, 1:], W.sht, dp, N * Pn, Kd, width, ldx=width, ldw=width, x_map=(Pn, (Pn + 1) * width))
+        return dp, None, None, None
+
+
+def patch_embed(patches, W, cls_pos0, pos):
+    return _PatchEmbedFn.apply(patches, W, cls_pos0, pos)
+
+
+class _SphericalLossFn(Function):
+    @staticmethod
+    def forward(ctx, embed, feats, coef):
+        loss, dembed = K.spherical_loss(_contig(embed), _contig(feats), coef, want_grad=True)
+        ctx.save_for_backward(dembed)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dembed,) = ctx.saved_tensors
+        return K.mul_dev_scalar(dembed, _contig(g).float()), None, None
+
+
+def spherical_loss(embed, feats, coef=1.0):
+    """main.py:801-811 (repeat = 1): embed [cutn*B, D] fp32, feats [B, D] fp32 (no grad) -> scalar."""
+    return _SphericalLossFn.apply(embed, feats, float(coef))
+
+
+def default_scale(dh):
+    return 1.0 / math.sqrt(dh)
+
+
+# ---------------------------------------------------------------------------
+# layout / dtype plumbing with gradients
+# ---------------------------------------------------------------------------
+class _TransposeFn(Function):
+    @staticmethod
+    def forward(ctx, x, out_dtype):
+        ctx.in_dtype = x.dtype
+        return K.transpose(_contig(x), out_dtype or x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.transpose(_contig(g), ctx.in_dtype), None
+
+
+def transpose_last2(x, out_dtype=None):
+    """(..., R, C) -> (..., C, R) contiguous, optional dtype conversion (einops Rearrange, mlp_mixer_pytorch.py:31)."""
+    return _TransposeFn.apply(x, out_dtype)
+
+
+class _CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.in_dtype = x.dtype
+        return K.cast(_contig(x), dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.cast(_contig(g), ctx.in_dtype), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else _CastFn.apply(x, dtype)

@@ -66,7 +66,8 @@ extern "C" {
  *   VQ distance         (x @ codebook^T, f32) main.py:134-136
  *
  * Index maps (all offsets in ELEMENTS):
- *   X KMAJOR: x[ xb(z) + m*ldx + (k/kseg)*xkso + (k%kseg) ]      TRANS: x[ xb(z) + k*ldx + m ]
+ *   X KMAJOR: x[ xb(z) + xrow(m) + (k/kseg)*xkso + (k%kseg) ]    TRANS: x[ xb(z) + k*ldx + m ]
+ *             xrow(m) = x_mi ? (m/x_mi)*x_so + (m%x_mi)*ldx : m*ldx   (e.g. rows 1..49 of every 50-row image)
  *   W KMAJOR: w[ wb(z) + n*ldw + (k/kseg)*wkso + (k%kseg) ]      TRANS: w[ wb(z) + k*ldw + n ]
  *   y       : y[ yb(z) + (m/y_mi)*y_so + (m%y_mi)*y_sm + n ]
  *   residual: r[ rb(z) + (m/r_mi)*r_so + (m%r_mi)*r_sm + n ]
@@ -101,6 +102,9 @@ typedef struct ffvc_gemm_desc {
   int64_t xbo, xbi, wbo, wbi, ybo, ybi, rbo, rbi, abo, abi;
   /* conv geometry (x_mode == FFVC_OP_CONV3X3) */
   int32_t conv_H, conv_W, conv_Cin;
+  /* optional split row map of a KMAJOR X operand (0 = plain m*ldx) */
+  int32_t x_mi;
+  int64_t x_so;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
@@ -184,6 +188,16 @@ int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, 
  * low-precision weight shadow in the same pass; grad_scale folds 1/world_size or clip_grad_norm (main.py:833-834). */
 int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr,
               float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* out[r % period] (+)= sum_c x[r, c]: bias gradient of the token-mixing Conv1d (bias indexed by output row) */
+int ffvc_rowsum(const void* x, int dtype, float* out, int64_t rows, int cols, int period, int accumulate, void* stream);
+/* dst[r*dst_stride + c] = src[r*src_stride + c] (fp32; src_stride 0 broadcasts one row): class-token row of the
+ * ViT token buffer (cloob.py:240-244) */
+int ffvc_copy_rows(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows, int cols,
+                   void* stream);
+/* explicit 3x3/pad-1 im2col of a small-channel NHWC tensor: out[(b,y,x), (kh*3+kw)*C + c] (zero padded to Kp columns);
+ * feeds the dgrad of the decoder's conv_out (Cout = 3), taming Decoder.conv_out [upstream] */
+int ffvc_im2col3x3(const void* x, int x_dtype, void* out, int out_dtype, int B, int H, int W, int C, int Kp, void* stream);
+int ffvc_mul_dev_scalar(const float* x, const float* s, float* y, int64_t n, void* stream); /* y = x * s[0] */
 int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream);            /* out[0] += sum x^2 */
 int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream); /* y = a*x + b*y */
 

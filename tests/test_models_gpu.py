@@ -1,0 +1,207 @@
+"""GPU parity of the assembled HIP modules (mapper, VQGAN decoder, CLIP towers, full train step)
+against (a) the golden vectors produced by the reference's own code and (b) the oracle on seeded
+inputs.  fp32 ("parity") mode must agree to fp32 round-off; bf16 mode to the stated stage tolerances.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import assert_close, grads, load, t, unpack_sd  # noqa: E402
+
+from feed_forward_vqgan_clip_amd import clip as fclip  # noqa: E402
+from feed_forward_vqgan_clip_amd import main as fmain  # noqa: E402
+from feed_forward_vqgan_clip_amd import ops, vqgan as fvq  # noqa: E402
+from feed_forward_vqgan_clip_amd.mappers import Mixer  # noqa: E402
+from feed_forward_vqgan_clip_amd.optim import FusedAdam  # noqa: E402
+
+F32, BF16 = torch.float32, torch.bfloat16
+TINY_VQ = dict(ch=64, ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64,
+               out_ch=3, embed_dim=64, n_embed=128)      # 3 levels -> image = 4 * S, attention at the first level
+
+
+def _relrms(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+# ----------------------------------------------------------------------------- mapper vs reference golden
+def test_mixer_fp32_matches_reference_golden(cuda):
+    z = load("mixer.npz")
+    net = Mixer(input_dim=24, image_size=4, channels=8, patch_size=1, dim=16, depth=2)
+    net.load_state_dict(unpack_sd(z, "sd"))
+    net = net.cuda().prepare(F32)
+    x = t(z["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert y.shape == (3, 8, 4, 4)
+    assert_close(y.cpu(), z["y"], 1e-4, 1e-5, "mixer y")
+    net._ffvc_arena.zero_grad()
+    (y * t(z["gw"]).cuda()).sum().backward()
+    assert_close(x.grad.cpu(), z["dx"], 2e-4, 2e-5, "mixer dx")
+    sd = dict(net.named_parameters())
+    for k, g in grads(z, "grad").items():
+        assert_close(sd[k].grad.cpu(), g, 3e-4, 3e-5, f"mixer grad {k}")
+
+
+def test_mixer_bf16_close_to_reference_golden(cuda):
+    z = load("mixer.npz")
+    net = Mixer(input_dim=24, image_size=4, channels=8, patch_size=1, dim=16, depth=2)
+    net.load_state_dict(unpack_sd(z, "sd"))
+    net = net.cuda().prepare(BF16)
+    y = net(t(z["x"]).cuda())
+    assert _relrms(y, t(z["y"])) < 2e-2            # bf16 operands, fp32 accumulate / residual / LN
+
+
+def test_mixer_state_dict_layout():
+    net = Mixer(input_dim=24, image_size=4, channels=8, patch_size=1, dim=16, depth=2)
+    ref = unpack_sd(load("mixer.npz"), "sd")
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.items()}
+
+
+# ----------------------------------------------------------------------------- CLIP vs reference golden
+@pytest.mark.parametrize("cdt,tol", [(F32, 2e-4), (BF16, 3e-2)])
+def test_clip_matches_reference_golden(cuda, cdt, tol):
+    z = load("clip.npz")
+    sd = unpack_sd(z, "sd")
+    model = fclip.CLIP(sd, cdt, text_heads=2)
+    img = t(z["img"]).cuda().requires_grad_(True)
+    e = model.encode_image(img)
+    if cdt == F32:
+        assert_close(e.cpu(), z["image_embed"], tol, 1e-5, "image_embed")
+    else:
+        assert _relrms(e, t(z["image_embed"])) < tol
+    (e * t(z["gw"]).cuda()).sum().backward()
+    if cdt == F32:
+        assert_close(img.grad.cpu(), z["dimg"], 5e-4, 2e-5, "dimg")
+    else:
+        assert _relrms(img.grad, t(z["dimg"])) < 5e-2
+    et = model.encode_text(t(z["tok"]).cuda())          # text tower is always exact fp32
+    assert_close(et.cpu(), z["text_embed"], 2e-4, 1e-5, "text_embed")
+
+
+# ----------------------------------------------------------------------------- VQGAN decoder vs oracle
+@pytest.mark.parametrize("cdt,tol", [(F32, 1e-4), (BF16, 3e-2)])
+def test_vqgan_decoder_matches_oracle(cuda, cdt, tol):
+    from oracle import step as ostep
+    sd = fvq.random_state_dict(TINY_VQ, seed=7)
+    vq = fvq.VQGAN(sd, TINY_VQ, cdt)
+    g = torch.Generator().manual_seed(3)
+    zin = torch.randn(2, 64, 4, 4, generator=g)
+    z = zin.cuda().requires_grad_(True)
+    xr = fvq.synth(vq, z)
+    assert xr.shape == (2, 3, 16, 16)
+    zo = zin.clone().requires_grad_(True)
+    xo = ostep.synth(sd, zo, TINY_VQ)
+    gw = torch.randn(2, 3, 16, 16, generator=g)
+    (xr * gw.cuda()).sum().backward()
+    (xo * gw).sum().backward()
+    if cdt == F32:
+        assert_close(xr.cpu(), xo.detach(), tol, 1e-5, "xr")
+        assert_close(z.grad.cpu(), zo.grad, 1e-3, 1e-5, "dz")
+    else:
+        assert _relrms(xr, xo.detach()) < tol
+        assert _relrms(z.grad, zo.grad) < 8e-2
+
+
+def test_vq_and_glue_match_reference_golden(cuda):
+    z = load("glue.npz")
+    x = t(z["vq_x"]).cuda().requires_grad_(True)
+    q = fvq.vector_quantize(x, t(z["vq_codebook"]).cuda())
+    assert torch.equal(q.detach().cpu(), t(z["vq_out"]))
+    (q * t(z["vq_g"]).cuda()).sum().backward()
+    assert_close(x.grad.cpu(), z["vq_dx"], what="vq dx")
+    xc = t(z["clamp_x"]).cuda().requires_grad_(True)
+    yc = fmain.clamp_with_grad(xc, -1.0, 1.5)
+    assert torch.equal(yc.detach().cpu(), t(z["clamp_y"]))
+    (yc * t(z["clamp_g"]).cuda()).sum().backward()
+    assert torch.equal(xc.grad.cpu(), t(z["clamp_dx"]))
+    b = torch.zeros(1, 6, device="cuda", requires_grad=True)
+    r = fmain.replace_grad(t(z["rg_a"]).cuda(), b)
+    (r * t(z["rg_g"]).cuda()).sum().backward()
+    assert_close(b.grad.cpu(), z["rg_db"], what="replace_grad")
+    mc = fmain.MakeCutouts(cut_size=8, cutn=3, augs=["R"], pool=True, pool_size=8)
+    mc.noise_fac = 0
+    xi = t(z["cut_x"]).cuda().requires_grad_(True)
+    co = mc(xi)
+    assert_close(co.cpu(), z["cut_out"], what="cutouts")
+    (co * t(z["cut_g"]).cuda()).sum().backward()
+    assert_close(xi.grad.cpu(), z["cut_dx"], what="cutouts dx")
+
+
+# ----------------------------------------------------------------------------- full train step vs oracle
+def _tiny_step(cdt, seed=11):
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=64, depth=2, dropout=0, cutn=4, batch_size=4, repeat=1,
+                       nb_noise=None, diversity_coef=0, clip_model="ViT-B/32", clip_dim=32, clip_size=32,
+                       model_type="mlp_mixer", vq_image_size=12, augs=["R"])     # 48x48 image -> 32x32 cutouts
+    clip_cfg = dict(embed_dim=32, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8,
+                    context_length=16, vocab_size=96, transformer_width=64, transformer_heads=1, transformer_layers=2)
+    clip_sd = fclip.random_state_dict(clip_cfg, seed)
+    vq_sd = fvq.random_state_dict(TINY_VQ, seed + 1)
+    torch.manual_seed(seed)
+    net = fmain.build_model(cfg, 64).cuda().prepare(cdt)
+    vq = fvq.VQGAN(vq_sd, TINY_VQ, cdt)
+    perceptor = fclip.CLIP(clip_sd, cdt)
+    opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    tok = torch.zeros(4, 16, dtype=torch.long)
+    g = torch.Generator().manual_seed(seed)
+    for i, L in enumerate([3, 6, 9, 12]):
+        tok[i, 0] = 94
+        tok[i, 1:L] = torch.randint(1, 94, (L - 1,), generator=g)
+        tok[i, L] = 95
+    facs = torch.rand(16, generator=g) * 0.1
+    noise = torch.randn(16, 3, 32, 32, generator=g)
+    return cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise
+
+
+@pytest.mark.parametrize("cdt", [F32, BF16])
+def test_train_step_matches_oracle(cuda, cdt):
+    from oracle import mappers as omap
+    from oracle import step as ostep
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(cdt)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+    opt.zero_grad()
+    loss.backward()
+    # oracle on identical weights / inputs
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    oloss, omid = ostep.train_step_loss(
+        lambda sd, f: omap.mixer_forward(sd, f, image_size=12, channels=64, depth=2), osd, vq_sd, clip_sd, tok,
+        cutn=4, cut_size=32, z_min=vq.z_min, z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise, vq_cfg=TINY_VQ)
+    oloss.backward()
+    rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    agree = (mid["indices"].cpu().view(-1) == ostep.vq_indices(omid["z"].detach().movedim(1, 3), vq_sd["quantize.embedding.weight"]).view(-1)).float().mean().item()
+    print(f"[{cdt}] loss hip={loss.item():.7f} oracle={oloss.item():.7f} rel={rel:.2e} vq index agreement={agree:.4f}")
+    if cdt == F32:
+        assert_close(mid["z"].cpu(), omid["z"].detach(), 2e-4, 2e-5, "z")
+        assert agree == 1.0
+        assert_close(mid["xr"].permute(0, 3, 1, 2).cpu(), omid["xr"].detach(), 2e-4, 2e-5, "xr")
+        assert_close(mid["embed"].cpu(), omid["embed"].detach(), 5e-4, 5e-5, "embed")
+        assert rel < 1e-4                                   # north_star: CLIP loss within 1e-4 rel of the CPU reference
+        params = dict(net.named_parameters())
+        for k, v in osd.items():
+            assert _relrms(params[k].grad, v.grad) < 2e-3, k
+    else:
+        assert _relrms(mid["z"], omid["z"].detach()) < 3e-2
+        if agree == 1.0:                                    # identical codes -> the remaining stages are comparable
+            assert _relrms(mid["xr"].permute(0, 3, 1, 2), omid["xr"].detach()) < 3e-2
+            assert rel < 2e-2
+
+
+def test_optimizer_step_matches_torch_adam(cuda):
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(F32)
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in net.named_parameters()}
+    ropt = torch.optim.Adam(ref.values(), lr=cfg.lr)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    for _ in range(2):
+        loss, _ = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+        opt.zero_grad()
+        loss.backward()
+        for k, p in net.named_parameters():
+            ref[k].grad = p.grad.detach().clone()
+        opt.step()
+        ropt.step()
+    for k, p in net.named_parameters():
+        assert_close(p.detach().cpu(), ref[k].detach().cpu(), 1e-5, 1e-7, f"adam {k}")
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
