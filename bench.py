@@ -1,0 +1,217 @@
+"""bench.py — train-step images/sec of the hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] = SURVEY.md cfg2): MLP-Mixer 32x1024 mapper + VQGAN f16-16384 decoder
+(256x256) + CLIP ViT-B/32, per-GPU batch 64 prompts, cutn 8, bf16 MFMA with fp32 accumulation.  Synthetic
+seeded token batches and random-init weights of that architecture (no network).  One "step" = text tower ->
+mapper -> clamp -> VQ -> decoder -> cutouts(+noise) -> image tower -> spherical loss -> backward -> gradient
+all-reduce (N>1) -> fused Adam.  Weak scaling: the per-GPU batch is fixed (the reference's semantics, main.py:647,678).
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic forward GMAC per unit (SURVEY.md §8d / BASELINE.md §2)
+GMAC = dict(mixer=86.07, vq=2.147, dec=126.37, img=4.409, txt=2.980)
+PEAK_BF16_TFLOPS = 2516.6      # 256 CU x 4096 FLOP/clk x 2.4 GHz dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def step_tflop(B, cutn):
+    """FLOP/step = 2 * [B*txt + B*(3*mapper + vq + 2*dec + 2*cutn*img)]  (BASELINE.md §2), in TFLOP."""
+    return 2.0 * (B * GMAC["txt"] + B * (3 * GMAC["mixer"] + GMAC["vq"] + 2 * GMAC["dec"] + 2 * cutn * GMAC["img"])) / 1e3
+
+
+def build(args, device):
+    from feed_forward_vqgan_clip_amd import clip as fclip
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    from feed_forward_vqgan_clip_amd import main as fmain
+    from feed_forward_vqgan_clip_amd import vqgan as fvq
+    from feed_forward_vqgan_clip_amd.optim import FusedAdam
+
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
+                       batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
+                       model_type="mlp_mixer", vq_image_size=16, augs=["R"])
+    torch.manual_seed(1234)
+    net = fmain.build_model(cfg, 256)
+    mixer_sd = {k: v.detach().clone() for k, v in net.state_dict().items()} if args.keep_cpu_weights else None
+    net = net.to(device).prepare(cdt)
+    vq_sd = fvq.random_state_dict(fvq.F16_16384, seed=1234)
+    clip_sd = fclip.random_state_dict(fclip.VIT_B32, seed=1234)
+    vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
+    perceptor = fclip.CLIP(clip_sd, cdt)
+    opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    if hvd.size() > 1:
+        opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
+        hvd.broadcast_parameters(net, root_rank=0)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    return cfg, stepper, (mixer_sd, vq_sd, clip_sd)
+
+
+def cpu_baseline(sds, cutn, seconds_budget=30.0):
+    """The oracle (CPU restatement, fp32) timed on this box's host cores on a bounded sample of the same
+    workload: full train steps (fwd + loss + bwd + Adam) at batch 1 of the cfg2 models."""
+    from feed_forward_vqgan_clip_amd import main as fmain
+    from feed_forward_vqgan_clip_amd import vqgan as fvq
+    from oracle import mappers as omap
+    from oracle import step as ostep
+
+    mixer_sd, vq_sd, clip_sd = sds
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 1
+    tok = fmain.synthetic_tokens(B, seed=99)
+    params = {k: v.clone().requires_grad_(True) for k, v in mixer_sd.items()}
+    plist = list(params.values())
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in plist]
+    cb = vq_sd["quantize.embedding.weight"]
+    g = torch.Generator().manual_seed(5)
+    facs = (torch.rand(cutn * B, generator=g) * 0.1).view(-1, 1, 1, 1)
+    noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
+
+    def one(step):
+        loss, _ = ostep.train_step_loss(
+            lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=len([k for k in sd if k.endswith(".0.norm.weight")])),
+            params, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(),
+            facs=facs, noise=noise)
+        grads = torch.autograd.grad(loss, plist)
+        with torch.no_grad():
+            ostep.adam_step(plist, grads, state, 1e-3, step)
+        return float(loss)
+
+    t0 = time.time()
+    one(1)                       # warm-up (allocator, MKL threads)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while True:
+        one(n + 2)
+        n += 1
+        if time.time() - t0 + warm > seconds_budget or n >= 3:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} full oracle train step(s) (fwd+loss+bwd+Adam, fp32) at batch {B}, cutn {cutn}, same cfg2 "
+                      f"models/shapes; {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU prompts per step")
+    ap.add_argument("--cutn", type=int, default=8)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    from feed_forward_vqgan_clip_amd import kernels as K
+    from feed_forward_vqgan_clip_amd import main as fmain
+
+    hvd.init()
+    rank, world = hvd.rank(), hvd.size()
+    if world != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(hvd.local_rank())
+    device = torch.device("cuda", hvd.local_rank())
+    args.keep_cpu_weights = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    cfg, stepper, sds = build(args, device)
+
+    B = args.batch
+    toks = fmain.synthetic_tokens(B * (args.steps + args.warmup), seed=1234 + rank).to(device)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        stepper(toks[it * B:(it + 1) * B])
+        it += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = stepper(toks[it * B:(it + 1) * B])
+        it += 1
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    out = {
+        "metric": "train-step images/sec (whole node), ViT-B/32 + VQGAN-f16 256x256, bs=64, 1/2/4/8 GPU",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic seeded token batches, random-init weights (no network)",
+        "config": {"workload": f"cfg2: MLP-Mixer {args.depth}x{args.dim} mapper + VQGAN f16-16384 decoder 256x256 + CLIP "
+                               f"ViT-B/32, per-GPU batch {B}, cutn {args.cutn}, augs ['R'] + noise, full step "
+                               "(fwd+loss+bwd+all-reduce+Adam)",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire},
+        "final_loss": float(loss.item()),
+    }
+    tf_step = step_tflop(B, args.cutn) if (args.depth, args.dim) == (32, 1024) else None
+    if tf_step:
+        out["step_tflop"] = tf_step
+        out["step_mfma_frac"] = tf_step / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS
+
+    if rank == 0 and not args.no_roofline:
+        # one extra, event-bracketed step: per-launch HIP events on the launch stream (torch's current stream)
+        K.PROFILE = []
+        stepper(toks[:B])
+        torch.cuda.synchronize()
+        prof, K.PROFILE = K.PROFILE, None
+        agg = {}
+        for name, flops, e0, e1 in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        dom = max(agg.items(), key=lambda kv: kv[1][2])
+        name, (n, flops, secs) = dom
+        peak = PEAK_BF16_TFLOPS if name.endswith("bf16") else 157.3
+        out["roofline"] = {"bound": "mfma", "kernel": name, "launches_per_step": n,
+                           "avg_launch_ms": secs / n * 1e3, "achieved": flops / secs / 1e12, "peak": peak,
+                           "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": None}
+        out["kernel_classes"] = {k: {"launches": v[0], "ms": v[2] * 1e3, "tflops": v[1] / max(v[2], 1e-12) / 1e12}
+                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+        out["gemm_ms_per_step"] = sum(v[2] for v in agg.values()) * 1e3
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del stepper
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(sds, args.cutn)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

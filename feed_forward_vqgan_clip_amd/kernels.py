@@ -19,6 +19,13 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing (bench.py roofline leg): when PROFILE is a list, every ffvc_gemm launch is
+# bracketed by HIP events recorded on the launch stream and (kernel class, algorithmic flops, events) is appended.
+PROFILE = None
+_GEMM_CLASS = {(OP_KMAJOR, OP_KMAJOR): "gemm_nt", (OP_CONV3X3, OP_KMAJOR): "conv3x3", (OP_TRANS, OP_TRANS): "gemm_tn",
+               (OP_KMAJOR, OP_TRANS): "gemm_nn", (OP_TRANS, OP_KMAJOR): "gemm_tk"}
+
+
 def dtype_code(dt):
     if dt == torch.bfloat16:
         return BF16
@@ -88,6 +95,14 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     if x_map is not None:
         d.x_mi, d.x_so = x_map
     lib = _lib.load()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
+        e1.record()
+        PROFILE.append((_GEMM_CLASS[(x_mode, w_mode)] + ("_f32" if x.dtype == torch.float32 else "_bf16"),
+                        2.0 * M * N * K * max(1, batch), e0, e1))
+        return y
     _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
     return y
 
