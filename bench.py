@@ -60,6 +60,25 @@ def build(args, device):
     return cfg, stepper, (mixer_sd, vq_sd, clip_sd)
 
 
+def effective_cores():
+    """Host cores this process may actually use: min(affinity, cgroup v2/v1 CPU quota).  (The GPU boxes expose
+    256 logical CPUs behind a 16-CPU quota; oversubscribing them makes the oracle ~100x slower.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(sds, cutn, seconds_budget=30.0):
     """The oracle (CPU restatement, fp32) timed on this box's host cores on a bounded sample of the same
     workload: full train steps (fwd + loss + bwd + Adam) at batch 1 of the cfg2 models."""
@@ -69,7 +88,7 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0):
     from oracle import step as ostep
 
     mixer_sd, vq_sd, clip_sd = sds
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     torch.set_num_threads(cores)
     B = 1
     tok = fmain.synthetic_tokens(B, seed=99)
@@ -92,15 +111,16 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0):
         return float(loss)
 
     t0 = time.time()
-    one(1)                       # warm-up (allocator, MKL threads)
-    warm = time.time() - t0
+    one(1)                       # first step doubles as warm-up (allocator, MKL threads)
+    first = time.time() - t0
     n, t0 = 0, time.time()
-    while True:
+    while first + (time.time() - t0) < seconds_budget and n < 3:
         one(n + 2)
         n += 1
-        if time.time() - t0 + warm > seconds_budget or n >= 3:
-            break
-    dt = (time.time() - t0) / n
+    if n == 0:                   # one step already used the budget: report it (includes warm-up cost)
+        n, dt = 1, first
+    else:
+        dt = (time.time() - t0) / n
     return {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n} full oracle train step(s) (fwd+loss+bwd+Adam, fp32) at batch {B}, cutn {cutn}, same cfg2 "
                       f"models/shapes; {dt:.2f} s/step"}
@@ -119,6 +139,7 @@ def main():
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-shapes", type=int, default=0, help="print the N most expensive GEMM shapes (stderr)")
     args = ap.parse_args()
 
     from feed_forward_vqgan_clip_amd import distributed as hvd
@@ -186,11 +207,21 @@ def main():
         torch.cuda.synchronize()
         prof, K.PROFILE = K.PROFILE, None
         agg = {}
-        for name, flops, e0, e1 in prof:
+        shapes = {}
+        for name, flops, e0, e1, shp in prof:
             a = agg.setdefault(name, [0, 0.0, 0.0])
+            ms = e0.elapsed_time(e1)
             a[0] += 1
             a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
+            a[2] += ms * 1e-3
+            sa = shapes.setdefault((name,) + shp, [0, 0.0, flops])
+            sa[0] += 1
+            sa[1] += ms
+        if args.gemm_shapes:
+            print("# top GEMM shapes by time: class M N K batch splitk | calls total_ms avg_ms TFLOP/s", file=sys.stderr)
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:args.gemm_shapes]:
+                print(f"# {k[0]:14s} {k[1]:8d} {k[2]:6d} {k[3]:6d} b{k[4]:<5d} sk{k[5]:<3d} | {v[0]:4d} {v[1]:8.3f} {v[1]/v[0]:7.3f} "
+                      f"{v[2]/(v[1]/v[0]*1e-3)/1e12:7.1f}", file=sys.stderr)
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         name, (n, flops, secs) = dom
         peak = PEAK_BF16_TFLOPS if name.endswith("bf16") else 157.3

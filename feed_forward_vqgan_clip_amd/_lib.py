@@ -22,6 +22,7 @@ F_RES_F32 = 16
 F_OUT_F32 = 32
 F_TR_SAFE = 64
 F_UPSAMPLE2X = 128
+F_ACCUM_OUT = 256
 
 
 class GemmDesc(Structure):

@@ -149,6 +149,25 @@ __device__ __forceinline__ float act_gelu_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), sharing exp(-x^2/2) between the cdf and the pdf.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float act_gelu_fast(float x) {
+  float cdf, e;
+  gelu_parts_fast(x, cdf, e);
+  return x * cdf;
+}
+__device__ __forceinline__ float act_gelu_grad_fast(float x) {
+  float cdf, e;
+  gelu_parts_fast(x, cdf, e);
+  return cdf + x * 0.39894228040143267794f * e;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_quickgelu(float x) { return x * sigmoidf_(1.702f * x); }
 __device__ __forceinline__ float act_quickgelu_grad(float x) {

@@ -298,13 +298,17 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const u32x4_t& a
                                                0, 0);
 }
 
+// bf16 storage rounds the result to 2^-8 relative: the 1.5e-7-accurate erf (common.h) is exact for that purpose
+// and ~3x cheaper in the epilogue; fp32 ("parity") storage keeps libm's erff.
+template <typename T>
 __device__ __forceinline__ float apply_act(int act, float v) {
-  if (act == FFVC_ACT_GELU) return act_gelu(v);
+  if (act == FFVC_ACT_GELU) return sizeof(T) == 2 ? act_gelu_fast(v) : act_gelu(v);
   if (act == FFVC_ACT_QUICKGELU) return act_quickgelu(v);
   return v;
 }
+template <typename T>
 __device__ __forceinline__ float apply_act_grad(int act, float pre) {
-  if (act == FFVC_ACT_GELU) return act_gelu_grad(pre);
+  if (act == FFVC_ACT_GELU) return sizeof(T) == 2 ? act_gelu_grad_fast(pre) : act_gelu_grad(pre);
   if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad(pre);
   return 1.0f;
 }
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
   const bool out_f32 = flags & FFVC_F_OUT_F32;
   const bool res_f32 = flags & FFVC_F_RES_F32;
   const bool atomic_out = flags & FFVC_F_ATOMIC_OUT;
+  const bool accum_out = flags & FFVC_F_ACCUM_OUT;
   const int64_t ybz = zo * p.ybo + zi * p.ybi;
   const int64_t rbz = zo * p.rbo + zi * p.rbi;
   const int64_t abz = zo * p.abo + zi * p.abi;
@@ -430,11 +435,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
           if (flags & FFVC_F_MUL_ACT_GRAD) {
             const f32x4_t pre = load4((const T*)p.aux + arow + n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad(p.act, pre[j]);
+            for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad<T>(p.act, pre[j]);
           } else if (p.act != FFVC_ACT_NONE) {
             if (flags & FFVC_F_WRITE_PREACT) store4((T*)p.aux + arow + n, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_act(p.act, v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(p.act, v[j]);
           }
           if (p.residual) {
             const f32x4_t rv = res_f32 ? load4((const float*)p.residual + rrow + n)
@@ -445,6 +450,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
             float* yp = (float*)p.y + yrow + n;
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(yp + j, v[j]);
+          } else if (accum_out) {
+            float* yp = (float*)p.y + yrow + n;
+            store4(yp, load4(yp) + v);
           } else if (out_f32) {
             store4((float*)p.y + yrow + n, v);
           } else {
@@ -457,16 +465,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
             float u = v[j];
             if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) u += p.bias[n + j];
             if (flags & FFVC_F_MUL_ACT_GRAD) {
-              u *= apply_act_grad(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
+              u *= apply_act_grad<T>(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
             } else if (p.act != FFVC_ACT_NONE) {
               if (flags & FFVC_F_WRITE_PREACT) ElemTraits<T>::store((T*)p.aux + arow + n + j, u);
-              u = apply_act(p.act, u);
+              u = apply_act<T>(p.act, u);
             }
             if (p.residual)
               u += res_f32 ? ((const float*)p.residual)[rrow + n + j]
                            : ElemTraits<T>::load((const T*)p.residual + rrow + n + j);
             if (atomic_out)
               atomicAdd((float*)p.y + yrow + n + j, u);
+            else if (accum_out)
+              ((float*)p.y)[yrow + n + j] += u;
             else if (out_f32)
               ((float*)p.y)[yrow + n + j] = u;
             else
@@ -533,8 +543,9 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   if (d.split_k < 1) d.split_k = 1;
   FFVC_CHECK_ARG(d.split_k == 1 || (d.flags & FFVC_F_ATOMIC_OUT),
                  "ffvc_gemm: split_k>1 needs FFVC_F_ATOMIC_OUT");
-  FFVC_CHECK_ARG(!(d.flags & FFVC_F_ATOMIC_OUT) || (d.flags & FFVC_F_OUT_F32),
-                 "ffvc_gemm: atomic output must be fp32");
+  FFVC_CHECK_ARG(!(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) || (d.flags & FFVC_F_OUT_F32),
+                 "ffvc_gemm: atomic / accumulating output must be fp32");
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_ACCUM_OUT) || d.split_k == 1, "ffvc_gemm: FFVC_F_ACCUM_OUT needs split_k == 1");
   FFVC_CHECK_ARG(!((d.flags & (FFVC_F_WRITE_PREACT | FFVC_F_MUL_ACT_GRAD)) && !d.aux),
                  "ffvc_gemm: aux pointer required by flags");
   const int es = d.in_dtype == FFVC_BF16 ? 2 : 4;

@@ -568,7 +568,7 @@ extern "C" int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma
 
 extern "C" int ffvc_layernorm_bwd_blocks(int64_t rows) {
   // number of partial rows ffvc_layernorm_bwd writes into part_g / part_b
-  int64_t nb = (rows + 127) / 128;
+  int64_t nb = (rows + 15) / 16;
   return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -579,7 +579,7 @@ extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, i
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
   FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = 128;
+  const int rpb = 16;
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
   const bool v4 = (dim % 4) == 0;

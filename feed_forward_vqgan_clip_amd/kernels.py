@@ -10,7 +10,7 @@ from ctypes import byref, c_int32, c_int64
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, BF16, F32, F_ATOMIC_OUT, F_BIAS_ALONG_M,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, BF16, F32, F_ACCUM_OUT, F_ATOMIC_OUT, F_BIAS_ALONG_M,  # noqa: F401
                    F_MUL_ACT_GRAD, F_OUT_F32, F_RES_F32, F_TR_SAFE, F_UPSAMPLE2X, F_WRITE_PREACT,
                    OP_CONV3X3, OP_KMAJOR, OP_TRANS, GemmDesc)
 
@@ -101,7 +101,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
         _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
         e1.record()
         PROFILE.append((_GEMM_CLASS[(x_mode, w_mode)] + ("_f32" if x.dtype == torch.float32 else "_bf16"),
-                        2.0 * M * N * K * max(1, batch), e0, e1))
+                        2.0 * M * N * K * max(1, batch), e0, e1, (M, N, K, max(1, batch), split_k)))
         return y
     _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
     return y

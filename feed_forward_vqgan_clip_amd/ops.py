@@ -64,7 +64,7 @@ def _wgrad(dy2d, x2d, W, rows):
     bk = 64 if dy2d.dtype == torch.bfloat16 else 32
     sk = _split_k(W.N, W.K, rows, bk)
     K.gemm(dy2d, x2d, wg, W.N, W.K, rows, ldx=W.N, ldw=W.K, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
-           flags=K.F_ATOMIC_OUT, split_k=sk)
+           flags=K.F_ATOMIC_OUT if sk > 1 else K.F_ACCUM_OUT, split_k=sk)
     if W.bias is not None and W.bias.requires_grad:
         K.colsum(dy2d, _grad_buf(W.bias), accumulate=True)
     if W.on_grad is not None:
@@ -210,10 +210,10 @@ class _TokenMLPFn(Function):
                     # dW[n,k] = sum_{b,d} g[b][n,d] a[b][k,d]: K-major GEMM over the segmented (b,d) axis
                     sk = _split_k(n_out, k_out, B * D, bk)
                     K.gemm(g, a, wg, n_out, k_out, B * D, ldx=D, ldw=D, kseg=D, xkso=n_out * D, wkso=k_out * D,
-                           flags=K.F_ATOMIC_OUT, split_k=sk)
+                           flags=K.F_ATOMIC_OUT if sk > 1 else K.F_ACCUM_OUT, split_k=sk)
                 else:
                     for b in range(B):
-                        K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ATOMIC_OUT)
+                        K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ACCUM_OUT)
                 if W.bias is not None and W.bias.requires_grad:
                     K.rowsum(g, _grad_buf(W.bias), n_out, accumulate=True)
                 if W.on_grad is not None:

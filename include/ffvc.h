@@ -52,6 +52,7 @@ extern "C" {
 #define FFVC_F_OUT_F32 32       /* y is fp32 (else in_dtype)                    */
 #define FFVC_F_TR_SAFE 64       /* transposed bf16 fragments via scalar LDS gathers (debug/verification) */
 #define FFVC_F_UPSAMPLE2X 128   /* conv: input is nearest-2x upsampled on the fly */
+#define FFVC_F_ACCUM_OUT 256    /* y += acc with plain read-modify-write (fp32 y, split_k == 1: one owner per element) */
 
 /*
  * ffvc_gemm — y[m,n] (+)= act( alpha * sum_k X[m,k] * W[n,k] + bias ) (+ residual)
