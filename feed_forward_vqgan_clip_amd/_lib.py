@@ -97,7 +97,10 @@ _SIGNATURES = {
                                  c_void_p]),
     "ffvc_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
-    "ffvc_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "ffvc_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "ffvc_copy2d": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "ffvc_sln_fwd": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "ffvc_sln_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 14 + [c_int64, c_int, c_void_p]),
     "ffvc_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
     "ffvc_clamp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
     "ffvc_clamp_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_float, c_float, c_float, c_float,

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const ST* __restrict__ s, DT*
 // dst[b][c][r] = src[b][r][c] with dtype conversion (weight shadows W^T, mixer rearrange).
 template <typename ST, typename DT>
 __global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ s, DT* __restrict__ d, int rows,
-                                                        int cols, int64_t sb, int64_t db) {
+                                                        int cols, int64_t sb, int64_t db, int dld) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ s
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) ElemTraits<DT>::store(d + b * db + (int64_t)c * rows + r, tile[tx][i]);
+    if (c < cols && r < dld) ElemTraits<DT>::store(d + b * db + (int64_t)c * dld + r, r < rows ? tile[tx][i] : 0.f);
   }
 }
 
@@ -468,6 +468,19 @@ __global__ __launch_bounds__(256) void mul_dev_scalar_kernel(const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * k;
 }
 
+// dst[r, c] = c < cols ? src[r, c] : 0 for c < dst_cols, independent leading dims, dtype conversion
+// (pad / unpad of per-head blocks, e.g. VitGAN's dim_head = 170 -> 176)
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void copy2d_kernel(const ST* __restrict__ s, int64_t sld, DT* __restrict__ d, int64_t dld,
+                                                     int64_t rows, int cols, int dst_cols) {
+  const int64_t n = rows * dst_cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / dst_cols;
+    const int c = (int)(i - r * dst_cols);
+    ElemTraits<DT>::store(d + r * dld + c, c < cols ? ElemTraits<ST>::load(s + r * sld + c) : 0.f);
+  }
+}
+
 }  // namespace
 
 extern "C" int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
@@ -482,14 +495,27 @@ extern "C" int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtyp
 }
 
 extern "C" int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int batch, int rows, int cols,
-                              int64_t src_batch_stride, int64_t dst_batch_stride, void* stream) {
-  FFVC_CHECK_ARG(src && dst && batch > 0 && batch <= 65535 && rows > 0 && cols > 0, "ffvc_transpose: bad args");
+                              int64_t src_batch_stride, int64_t dst_batch_stride, int dst_ld, void* stream) {
+  FFVC_CHECK_ARG(src && dst && batch > 0 && rows > 0 && cols > 0, "ffvc_transpose: bad args");
+  if (dst_ld <= 0) dst_ld = rows;
+  FFVC_CHECK_ARG(dst_ld >= rows, "ffvc_transpose: dst_ld < rows");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64), batch);
+  if (batch > 65535) {   // split huge batches (gridDim.z limit)
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+      const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+      const size_t ss = src_dtype == FFVC_BF16 ? 2 : 4, ds = dst_dtype == FFVC_BF16 ? 2 : 4;
+      int e = ffvc_transpose((const char*)src + (size_t)b0 * src_batch_stride * ss, src_dtype,
+                             (char*)dst + (size_t)b0 * dst_batch_stride * ds, dst_dtype, nb, rows, cols, src_batch_stride,
+                             dst_batch_stride, dst_ld, stream);
+      if (e) return e;
+    }
+    return 0;
+  }
+  dim3 grid(ceil_div(cols, 64), ceil_div(dst_ld, 64), batch);
   FFVC_CHECK_ARG(grid.y <= 65535, "ffvc_transpose: too many rows");
   DISPATCH_DT(src_dtype, ST, DISPATCH_DT(dst_dtype, DT,
               hipLaunchKernelGGL((transpose_kernel<ST, DT>), grid, dim3(256), 0, st, (const ST*)src, (DT*)dst, rows,
-                                 cols, src_batch_stride, dst_batch_stride)));
+                                 cols, src_batch_stride, dst_batch_stride, dst_ld)));
   FFVC_LAUNCH_CHECK();
   return 0;
 }
@@ -700,6 +726,18 @@ extern "C" int ffvc_im2col3x3(const void* x, int x_dtype, void* out, int out_dty
 extern "C" int ffvc_mul_dev_scalar(const float* x, const float* s, float* y, int64_t n, void* stream) {
   FFVC_CHECK_ARG(x && s && y && n > 0, "ffvc_mul_dev_scalar: bad args");
   hipLaunchKernelGGL(mul_dev_scalar_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_copy2d(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld,
+                           int64_t rows, int cols, int dst_cols, void* stream) {
+  FFVC_CHECK_ARG(src && dst && rows > 0 && cols > 0 && dst_cols > 0 && src_ld >= cols && dst_ld >= dst_cols,
+                 "ffvc_copy2d: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(src_dtype, ST, DISPATCH_DT(dst_dtype, DT,
+              hipLaunchKernelGGL((copy2d_kernel<ST, DT>), dim3(ew_grid(rows * dst_cols, 1024)), dim3(256), 0, st,
+                                 (const ST*)src, src_ld, (DT*)dst, dst_ld, rows, cols, dst_cols)));
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -549,7 +549,9 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   FFVC_CHECK_ARG(!((d.flags & (FFVC_F_WRITE_PREACT | FFVC_F_MUL_ACT_GRAD)) && !d.aux),
                  "ffvc_gemm: aux pointer required by flags");
   const int es = d.in_dtype == FFVC_BF16 ? 2 : 4;
-  const int epc = 16 / es;
+  // global_load_dwordx4 needs DWORD alignment only: leading dims / strides must keep 4-byte alignment
+  // (16-byte aligned rows are merely the fast case)
+  const int epc = 4 / es;
   const int bk = 128 / es;
   if (d.kseg == d.K) d.kseg = 0;
   if (d.kseg) {
@@ -572,8 +574,8 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
     FFVC_CHECK_ARG(mult(d.ldx, epc), "ffvc_gemm: ldx=%lld must be a multiple of %d", (long long)d.ldx, epc);
   }
   FFVC_CHECK_ARG(mult(d.ldw, epc), "ffvc_gemm: ldw=%lld must be a multiple of %d", (long long)d.ldw, epc);
-  FFVC_CHECK_ARG(mult((int64_t)(uintptr_t)d.x, 16) && mult((int64_t)(uintptr_t)d.w, 16),
-                 "ffvc_gemm: operand base pointers must be 16-byte aligned");
+  FFVC_CHECK_ARG(mult((int64_t)(uintptr_t)d.x, 4) && mult((int64_t)(uintptr_t)d.w, 4),
+                 "ffvc_gemm: operand base pointers must be 4-byte aligned");
   FFVC_CHECK_ARG(mult(d.xbo, epc) && mult(d.xbi, epc) && mult(d.wbo, epc) && mult(d.wbi, epc),
                  "ffvc_gemm: operand batch strides must be multiples of %d", epc);
   if (d.x_mi) {

@@ -183,6 +183,164 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
   }
 }
 
+// ------------------------- self-modulated LayerNorm ------------------------
+// vitgan.py:8-21 (SLN): out = gamma_s * w * LN(hl) + beta_s * w, gamma_s/beta_s scalar parameters, w the
+// per-token modulation tensor.  hl, w fp32 [rows, dim]; out in the compute dtype.
+template <int VEC, typename YT>
+__global__ __launch_bounds__(256) void sln_fwd_kernel(const float* __restrict__ hl, const float* __restrict__ w,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ gs, const float* __restrict__ bs,
+                                                      YT* __restrict__ y, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int64_t rows, int dim, float eps) {
+  constexpr int NIT = LN_MAXE / VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float g_s = gs[0], b_s = bs[0];
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float v[LN_MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        ld_vec<VEC>(hl + row * dim + idx, &v[k * VEC]);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += v[k * VEC + j];
+      }
+    }
+    const float mu = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float d = v[k * VEC + j] - mu;
+          q += d * d;
+        }
+      }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / dim + eps);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        float o[VEC], g[VEC], b[VEC], wv[VEC];
+        ld_vec<VEC>(gamma + idx, g);
+        ld_vec<VEC>(beta + idx, b);
+        ld_vec<VEC>(w + row * dim + idx, wv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = (g_s * ((v[k * VEC + j] - mu) * rs * g[j] + b[j]) + b_s) * wv[j];
+        st_vec<VEC>(y + row * dim + idx, o);
+      }
+    }
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+// Backward of SLN: dhl (+ dres), dw, LayerNorm dgamma/dbeta partial rows, and partial sums of the two scalars
+// (part_s[block][2] = {sum dy*w*ln, sum dy*w}).
+template <int VEC, typename DYT>
+__global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy, const float* __restrict__ hl,
+                                                      const float* __restrict__ w, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ gs,
+                                                      const float* __restrict__ bs, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                      float* __restrict__ dhl, float* __restrict__ dw,
+                                                      float* __restrict__ part_g, float* __restrict__ part_b,
+                                                      float* __restrict__ part_s, int64_t rows, int dim,
+                                                      int rows_per_block) {
+  constexpr int NIT = LN_MAXE / VEC;
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] + [2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float g_s = gs[0], b_s = bs[0];
+  float ag[LN_MAXE], ab[LN_MAXE];
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) ag[i] = ab[i] = 0.f;
+  float sg = 0.f, sb = 0.f;
+  for (int i = threadIdx.x; i < 2 * dim + 2; i += 256) ln_smem[i] = 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  for (int64_t row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXE], xh[LN_MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        float d[VEC], xv[VEC], gm[VEC], bt[VEC], wv[VEC], dwv[VEC];
+        ld_vec<VEC>(dy + row * dim + idx, d);
+        ld_vec<VEC>(hl + row * dim + idx, xv);
+        ld_vec<VEC>(gamma + idx, gm);
+        ld_vec<VEC>(beta + idx, bt);
+        ld_vec<VEC>(w + row * dim + idx, wv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float h = (xv[j] - mu) * rs;
+          const float ln = h * gm[j] + bt[j];
+          dwv[j] = d[j] * (g_s * ln + b_s);
+          sg += d[j] * wv[j] * ln;
+          sb += d[j] * wv[j];
+          const float dln = d[j] * g_s * wv[j];
+          xh[k * VEC + j] = h;
+          g[k * VEC + j] = dln * gm[j];
+          s1 += g[k * VEC + j];
+          s2 += g[k * VEC + j] * h;
+          ag[k * VEC + j] += dln * h;
+          ab[k * VEC + j] += dln;
+        }
+        st_vec<VEC>(dw + row * dim + idx, dwv);
+      }
+    }
+    s1 = wave_sum(s1) / dim;
+    s2 = wave_sum(s2) / dim;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = rs * (g[k * VEC + j] - s1 - xh[k * VEC + j] * s2);
+        if (dres) {
+          float r[VEC];
+          ld_vec<VEC>(dres + row * dim + idx, r);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] += r[j];
+        }
+        st_vec<VEC>(dhl + row * dim + idx, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int idx = (k * 64 + lane) * VEC;
+    if (idx < dim) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        atomicAdd(&ln_smem[idx + j], ag[k * VEC + j]);
+        atomicAdd(&ln_smem[dim + idx + j], ab[k * VEC + j]);
+      }
+    }
+  }
+  sg = wave_sum(sg);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+    atomicAdd(&ln_smem[2 * dim], sg);
+    atomicAdd(&ln_smem[2 * dim + 1], sb);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dim; i += 256) {
+    part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
+    part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
+  }
+  if (threadIdx.x < 2) part_s[(int64_t)blockIdx.x * 2 + threadIdx.x] = ln_smem[2 * dim + threadIdx.x];
+}
+
 // ------------------------------ GroupNorm ----------------------------------
 // NHWC tensor [B, HW, C], G groups of C/G consecutive channels, eps 1e-6, affine, optional
 // fused swish (taming Normalize + nonlinearity).
@@ -685,6 +843,48 @@ extern "C" int ffvc_softmax_bwd(const void* p, const float* dp, void* ds, int p_
   DISPATCH_DT(p_dtype, PT,
               hipLaunchKernelGGL((softmax_bwd_kernel<PT>), dim3(grid_rows(rows)), dim3(256), 0, st, (const PT*)p, dp,
                                  (PT*)ds, rows, cols, ldp, lddp, scale));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_sln_fwd(const float* hl, const float* w, const float* gamma, const float* beta, const float* gamma_s,
+                            const float* beta_s, void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int dim,
+                            float eps, void* stream) {
+  FFVC_CHECK_ARG(hl && w && gamma && beta && gamma_s && beta_s && y && mean && rstd, "ffvc_sln_fwd: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_sln_fwd: dim=%d unsupported", dim);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_rows(rows);
+  DISPATCH_DT(y_dtype, YT, {
+    if (dim % 4 == 0)
+      hipLaunchKernelGGL((sln_fwd_kernel<4, YT>), dim3(grid), dim3(256), 0, st, hl, w, gamma, beta, gamma_s, beta_s,
+                         (YT*)y, mean, rstd, rows, dim, eps);
+    else
+      hipLaunchKernelGGL((sln_fwd_kernel<1, YT>), dim3(grid), dim3(256), 0, st, hl, w, gamma, beta, gamma_s, beta_s,
+                         (YT*)y, mean, rstd, rows, dim, eps);
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
+                            const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
+                            const float* rstd, const float* dres, float* dhl, float* dw, float* part_g, float* part_b,
+                            float* part_s, int64_t rows, int dim, void* stream) {
+  FFVC_CHECK_ARG(dy && hl && w && gamma && beta && gamma_s && beta_s && mean && rstd && dhl && dw && part_g && part_b &&
+                     part_s, "ffvc_sln_bwd: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_sln_bwd: dim=%d unsupported", dim);
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 16;
+  const int grid = ffvc_layernorm_bwd_blocks(rows);
+  const size_t smem = (2 * (size_t)dim + 2) * sizeof(float);
+  DISPATCH_DT(dy_dtype, DYT, {
+    if (dim % 4 == 0)
+      hipLaunchKernelGGL((sln_bwd_kernel<4, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
+                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb);
+    else
+      hipLaunchKernelGGL((sln_bwd_kernel<1, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
+                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb);
+  });
   FFVC_LAUNCH_CHECK();
   return 0;
 }

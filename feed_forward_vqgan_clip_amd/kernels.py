@@ -229,16 +229,59 @@ def cast_into(src, dst):
     return dst
 
 
-def transpose(src, out_dtype=None, out=None):
-    """src: (..., R, C) contiguous -> (..., C, R) (batched over leading dims)."""
+def transpose(src, out_dtype=None, out=None, pad_to=0):
+    """src: (..., R, C) contiguous -> (..., C, max(R, pad_to)) (batched over leading dims; pad columns are zero)."""
     _need_cuda(src)
     R, C = src.shape[-2], src.shape[-1]
+    Rp = max(R, pad_to)
     batch = src.numel() // (R * C)
     if out is None:
-        out = torch.empty(*src.shape[:-2], C, R, dtype=out_dtype or src.dtype, device=src.device)
+        out = torch.empty(*src.shape[:-2], C, Rp, dtype=out_dtype or src.dtype, device=src.device)
     _call("ffvc_transpose", src.data_ptr(), dtype_code(src.dtype), out.data_ptr(), dtype_code(out.dtype), batch, R, C,
-          R * C, R * C, stream_ptr())
+          R * C, C * Rp, Rp, stream_ptr())
     return out
+
+
+def copy2d(src, src_ld, rows, cols, dst_cols, out_dtype, dst_ld=None):
+    """dst[r, c] = src[r, c] (c < cols) else 0, for c < dst_cols."""
+    dst_ld = dst_ld or dst_cols
+    dst = torch.empty(rows, dst_ld, dtype=out_dtype, device=src.device)
+    _call("ffvc_copy2d", src.data_ptr(), dtype_code(src.dtype), src_ld, dst.data_ptr(), dtype_code(out_dtype), dst_ld, rows,
+          cols, dst_cols, stream_ptr())
+    return dst
+
+
+def sln_fwd(hl, w, gamma, beta, gs, bs, out_dtype, eps=1e-5):
+    dim = hl.shape[-1]
+    rows = hl.numel() // dim
+    y = torch.empty(hl.shape, dtype=out_dtype, device=hl.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=hl.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=hl.device)
+    _call("ffvc_sln_fwd", hl.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), gs.data_ptr(), bs.data_ptr(),
+          y.data_ptr(), dtype_code(out_dtype), mean.data_ptr(), rstd.data_ptr(), rows, dim, eps, stream_ptr())
+    return y, mean, rstd
+
+
+def sln_bwd(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dres=None):
+    """-> (dhl, dw, dgamma, dbeta, dgamma_s, dbeta_s)"""
+    dim = hl.shape[-1]
+    rows = hl.numel() // dim
+    dev = hl.device
+    nb = _lib.load().ffvc_layernorm_bwd_blocks(rows)
+    dhl, dw = torch.empty_like(hl), torch.empty_like(w)
+    pg = torch.empty(nb, dim, dtype=torch.float32, device=dev)
+    pb = torch.empty(nb, dim, dtype=torch.float32, device=dev)
+    ps = torch.empty(nb, 2, dtype=torch.float32, device=dev)
+    _call("ffvc_sln_bwd", dy.data_ptr(), dtype_code(dy.dtype), hl.data_ptr(), w.data_ptr(), gamma.data_ptr(),
+          beta.data_ptr(), gs.data_ptr(), bs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dhl.data_ptr(),
+          dw.data_ptr(), pg.data_ptr(), pb.data_ptr(), ps.data_ptr(), rows, dim, stream_ptr())
+    dg = torch.empty(dim, dtype=torch.float32, device=dev)
+    db = torch.empty(dim, dtype=torch.float32, device=dev)
+    dsc = torch.empty(2, dtype=torch.float32, device=dev)
+    colsum(pg, dg)
+    colsum(pb, db)
+    colsum(ps, dsc)
+    return dhl, dw, dg, db, dsc[0:1], dsc[1:2]
 
 
 def colsum(x, out, accumulate=False, ld=None):

@@ -210,24 +210,48 @@ class TrainStep:
                                         interp_size=config.get("interp_size", self.clip_size))
         if config.get("noise_fac") is not None:
             self.make_cutouts.noise_fac = config.get("noise_fac")
-        if config.noise_dim or (config.repeat != 1) or config.diversity_coef:
-            raise NotImplementedError("noise_dim > 0, repeat > 1 and diversity_coef > 0 are not built yet")
+        if config.diversity_coef:
+            raise NotImplementedError("diversity_coef > 0 needs the LPIPS VGG16 features (out of scope, SURVEY.md §2)")
+        self.noise_dim, self.nb_noise = config.noise_dim, config.nb_noise
+        self.NOISE = None
+        if self.noise_dim and self.nb_noise:                                     # main.py:680-687
+            self.NOISE = getattr(net, "NOISE", None)
+            if self.NOISE is None:
+                self.NOISE = torch.randn(self.nb_noise, self.noise_dim)
+            self.NOISE = hvd.broadcast(self.NOISE.cuda(), root_rank=0)
+            net.NOISE = self.NOISE
+        self.input_loss = config.get("input_loss", False)
+        self.input_loss_coef = config.get("input_loss_coef", 1)
         self.target_loss_coef = config.get("target_loss_coef", 1)
         self.clip_grad_norm = config.get("clip_grad_norm")
         self.normalize_input = config.get("normalize_input", False)
         self.l2_coef, self.tv_coef = config.get("l2_coef", 0.0), config.get("tv_coef", 0.0)
-        if config.get("input_loss", False) or self.normalize_input or self.l2_coef or self.tv_coef:
-            raise NotImplementedError("input_loss / normalize_input / l2_coef / tv_coef are not built yet")
 
     def features(self, t):
         return self.perceptor.encode_text(t).float() if t.dtype == torch.long else t.float().cuda()
 
     def forward_loss(self, inp, out=None, facs=None, noise=None):
         """main.py:729-811 -> (loss, intermediates)."""
-        cfg = self.config
         inp_feats = self.features(inp)                                          # :733
-        out_feats = inp_feats if (out is None or out is inp) else self.features(out)   # :737 (identical work skipped)
-        z = self.net(inp_feats)                                                 # :754
+        if self.normalize_input:
+            inp_feats = torch.nn.functional.normalize(inp_feats, dim=1)         # :734-735
+        out_feats = inp_feats if (out is None or out is inp) and not self.normalize_input else \
+            self.features(inp if out is None else out)                          # :737 (identical work skipped)
+        bs = len(inp_feats)
+        if self.repeat != 1:
+            inp_feats = inp_feats.repeat(self.repeat, 1)                        # :739-740
+            out_feats = out_feats.repeat(self.repeat, 1)
+        inp_feats_net = inp_feats
+        if self.noise_dim:                                                      # :741-751
+            if self.nb_noise:
+                inds = torch.randperm(len(self.NOISE))[:self.repeat]
+                noise_vec = self.NOISE[inds.to(self.NOISE.device)].repeat(bs, 1).view(bs, self.repeat, -1) \
+                    .permute(1, 0, 2).contiguous().view(bs * self.repeat, -1)
+            else:
+                noise_vec = torch.randn(len(inp_feats), self.noise_dim, device=inp_feats.device)
+            inp_feats_net = torch.cat((inp_feats, noise_vec), dim=1)
+        z = self.net(inp_feats_net)                                             # :754
+        l2 = (z ** 2).mean() if self.l2_coef > 0 else None                      # :758-762 (optional, plain autograd)
         z_nhwc = z.permute(0, 2, 3, 1)                                          # contiguous for NHWC-native mappers
         z_nhwc = ops.clamp_with_grad(z_nhwc, self.vq.z_min, self.vq.z_max)      # :763
         xr, idx = synth_nhwc(self.vq, z_nhwc)                                   # :767
@@ -239,6 +263,12 @@ class TrainStep:
                               self.perceptor.cdt, noise=noise, facs=facs)       # :796-797 fused
         embed = self.perceptor.encode_patches(patches)                          # :799
         loss = ops.spherical_loss(embed, out_feats, self.target_loss_coef)      # :801-811
+        if self.input_loss:
+            loss = loss + ops.spherical_loss(embed, inp_feats, self.input_loss_coef)   # :812-824
+        if l2 is not None:
+            loss = loss + self.l2_coef * l2                                     # :831
+        if self.tv_coef > 0:
+            loss = loss + self.tv_coef * tv_loss(xr.permute(0, 3, 1, 2))        # :769-773,831 (optional, plain autograd)
         return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats}
 
     def __call__(self, inp, out=None, facs=None, noise=None):

@@ -108,3 +108,250 @@ class Mixer(_MapperBase):
         hn = ops.layernorm(h, fin.weight, fin.bias, cdt)                        # :37
         z = ops.linear(hn, self._w_final, out_dtype=f32)                        # :88
         return z.view(B, S, S, C).permute(0, 3, 1, 2)                           # :89-90 (non-contiguous, like the reference)
+
+
+# ---------------------------------------------------------------------------
+# VitGAN mappers (reference: vitgan.py:221-260 `Generator`, :262-305 `SimpleGenerator`)
+# ---------------------------------------------------------------------------
+class _SLN(nn.Module):
+    """Holder for vitgan.py:8-21 SLN: `.ln` LayerNorm + scalar `.gamma`, `.beta` of shape (1,1,1)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.ln = nn.LayerNorm(dim)
+        self.gamma = nn.Parameter(torch.randn(1, 1, 1))
+        self.beta = nn.Parameter(torch.randn(1, 1, 1))
+
+
+class _GAttention(nn.Module):
+    def __init__(self, dim, num_heads, dim_head=None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.dim_head = int(dim / num_heads) if dim_head is None else dim_head       # vitgan.py:62
+        self.weight_dim = self.num_heads * self.dim_head
+        self.to_qkv = nn.Linear(dim, self.weight_dim * 3, bias=False)
+        self.w_out = nn.Linear(self.weight_dim, dim, bias=True)
+
+
+class _GMLP(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.linear1 = nn.Linear(dim, hidden)
+        self.linear2 = nn.Linear(hidden, dim)
+
+
+class _GBlock(nn.Module):
+    def __init__(self, dim, num_heads, dim_head, mlp_ratio=4):
+        super().__init__()
+        self.attn = _GAttention(dim, num_heads, dim_head)
+        self.norm1 = _SLN(dim)
+        self.norm2 = _SLN(dim)
+        self.mlp = _GMLP(dim, dim * mlp_ratio)
+
+
+class _GEncoder(nn.Module):
+    def __init__(self, dim, blocks, num_heads, dim_head):
+        super().__init__()
+        self.blocks = nn.Sequential(*[_GBlock(dim, num_heads, dim_head) for _ in range(blocks)])
+
+
+class _VitGANBase(_MapperBase):
+    def _build_vit_packs(self, arena):
+        mk = arena.make_weights
+        self._bp = []
+        for blk in self.Transformer_Encoder.blocks:
+            self._bp.append((blk.norm1, mk(blk.attn.to_qkv.weight, None), mk(blk.attn.w_out.weight, blk.attn.w_out.bias),
+                             blk.norm2, mk(blk.mlp.linear1.weight, blk.mlp.linear1.bias),
+                             mk(blk.mlp.linear2.weight, blk.mlp.linear2.bias), blk.attn))
+        self._w_mlp = mk(self.mlp.weight, self.mlp.bias)
+        self._w_outp = mk(self.w_out[0].weight, self.w_out[0].bias)
+
+    def _encode(self, hl, x):
+        """GTransformerEncoder (vitgan.py:120-164): hl, x fp32 (B, T, dim)."""
+        cdt, f32 = self.cdt, torch.float32
+        B, T, dim = x.shape
+        align = 2 if cdt == torch.bfloat16 else 1          # GEMM operands need 4-byte aligned head blocks
+        for (n1, Wqkv, Wout, n2, W1, W2, att) in self._bp:
+            H, dh = att.num_heads, att.dim_head
+            dhp = (dh + align - 1) // align * align
+            y, hid = ops.sln_fork(hl, x, n1.ln.weight, n1.ln.bias, n1.gamma, n1.beta, cdt)       # vitgan.py:132
+            qkv = ops.linear(y, Wqkv)                                                            # (B,T,(d k h)) :81
+            qkv = ops.transpose_pad(qkv.view(B * T, dh, 3 * H), dhp).view(B, T, 3 * H * dhp)      # -> (k h d) :82
+            o = ops.attention(qkv, H, float(dim) ** -0.5)                                        # scale = dim^-0.5 :65
+            if dhp != dh:
+                o = ops.copy2d(o, B * T * H, dh, dhp, dh)
+            hl = ops.linear(o.view(B, T, H * dh), Wout, residual=hid, out_dtype=f32)             # w_out + hl :97,132
+            y, hid = ops.sln_fork(hl, x, n2.ln.weight, n2.ln.bias, n2.gamma, n2.beta, cdt)
+            hl = ops.mlp(y, W1, W2, ACT_GELU, residual=hid, out_dtype=f32)                       # :133
+        return hl
+
+
+class Generator(_VitGANBase):
+    def __init__(self, initialize_size=8, dim=384, blocks=6, num_heads=6, dim_head=None, dropout=0, out_channels=3,
+                 input_dim=1024):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP path")
+        self.initialize_size, self.dim, self.out_channels = initialize_size, dim, out_channels
+        T = initialize_size * 8
+        self.pos_emb1D = nn.Parameter(torch.randn(T, dim))
+        self.mlp = nn.Linear(input_dim, T * dim)
+        self.Transformer_Encoder = _GEncoder(dim, blocks, num_heads, dim_head)
+        self.w_out = nn.Sequential(nn.Linear(dim, T * out_channels))
+        self.sln_norm = _SLN(dim)
+
+    def _build_packs(self, arena):
+        self._build_vit_packs(arena)
+
+    def forward(self, noise):
+        self._arena()
+        cdt, f32 = self.cdt, torch.float32
+        T = self.initialize_size * 8
+        B = noise.shape[0]
+        x = ops.linear(ops.cast(noise.float(), cdt), self._w_mlp, out_dtype=f32).view(B, T, self.dim)   # vitgan.py:254
+        hl = self._encode(self.pos_emb1D.unsqueeze(0).expand(B, T, self.dim), x)                        # :255
+        s = self.sln_norm
+        y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt)                        # :256
+        out = ops.linear(y, self._w_outp, out_dtype=f32)                                                # :257
+        return out.view(B, self.out_channels, T, T)                                                     # raw view :258-259
+
+
+class SimpleGenerator(_VitGANBase):
+    def __init__(self, size=8, in_channels=256, dim=384, blocks=6, num_heads=6, dim_head=None, dropout=0,
+                 out_channels=3, input_dim=1024):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP path")
+        self.size, self.dim, self.out_channels = size, dim, out_channels
+        N = size * size
+        self.pos_emb1D = nn.Parameter(torch.randn(N, dim))
+        self.mlp = nn.Linear(input_dim, N * dim)
+        self.inp = nn.Linear(input_dim, N * dim)
+        self.Transformer_Encoder = _GEncoder(dim, blocks, num_heads, dim_head)
+        self.w_out = nn.Sequential(nn.Linear(dim, out_channels))
+        self.sln_norm = _SLN(dim)
+
+    def _build_packs(self, arena):
+        self._build_vit_packs(arena)
+        self._w_inp = arena.make_weights(self.inp.weight, self.inp.bias)
+
+    def forward(self, noise):
+        self._arena()
+        cdt, f32 = self.cdt, torch.float32
+        N, B = self.size * self.size, noise.shape[0]
+        nz = ops.cast(noise.float(), cdt)
+        inp = ops.linear(nz, self._w_inp, out_dtype=f32)                                                # vitgan.py:297
+        x = ops.linear(nz, self._w_mlp, out_dtype=f32).view(B, N, self.dim)                             # :298
+        inp_emb = ops.transpose_last2(inp.view(B, self.dim, N))                                         # :299
+        hl = self._encode(inp_emb + self.pos_emb1D, x)                                                  # :300
+        s = self.sln_norm
+        y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt)
+        out = ops.linear(y, self._w_outp, out_dtype=f32)
+        return out.view(B, self.size, self.size, self.out_channels).permute(0, 3, 1, 2)                 # :303
+
+
+# ---------------------------------------------------------------------------
+# x-transformer mapper (reference: transformer.py:5-46 over x-transformers==0.19.1
+# ContinuousTransformerWrapper(Decoder); PARITY UNPINNED upstream, see oracle/mappers.py)
+# ---------------------------------------------------------------------------
+class _XAttention(nn.Module):
+    def __init__(self, dim, heads, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(dim, inner, bias=False)
+        self.to_v = nn.Linear(dim, inner, bias=False)
+        self.to_out = nn.Linear(inner, dim)
+
+
+class _XFeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Sequential(nn.Linear(dim, dim * mult), nn.Identity()), nn.Identity(),
+                                 nn.Linear(dim * mult, dim))
+
+
+class _XAttnLayers(nn.Module):
+    def __init__(self, dim, depth, heads):
+        super().__init__()
+        layers = []
+        for _ in range(depth):
+            layers.append(nn.ModuleList([nn.LayerNorm(dim), _XAttention(dim, heads), nn.Identity()]))
+            layers.append(nn.ModuleList([nn.LayerNorm(dim), _XFeedForward(dim), nn.Identity()]))
+        self.layers = nn.ModuleList(layers)
+
+
+class _XPosEmb(nn.Module):
+    def __init__(self, dim, max_seq_len):
+        super().__init__()
+        self.emb = nn.Embedding(max_seq_len, dim)
+
+
+class _XWrapper(nn.Module):
+    def __init__(self, dim_in, dim_out, max_seq_len, dim, depth, heads):
+        super().__init__()
+        self.pos_emb = _XPosEmb(dim, max_seq_len)
+        self.project_in = nn.Linear(dim_in, dim)
+        self.attn_layers = _XAttnLayers(dim, depth, heads)
+        self.norm = nn.LayerNorm(dim)
+        self.project_out = nn.Linear(dim, dim_out)
+
+
+class XTransformer(_MapperBase):
+    def __init__(self, input_dim, image_size, channels, dim, depth, heads, initial_proj=True, add_input=True):
+        super().__init__()
+        if not initial_proj:
+            raise NotImplementedError("XTransformer: only initial_proj=True (the configured default, main.py:497)")
+        self.input_dim, self.image_size, self.channels, self.dim, self.depth, self.heads = \
+            input_dim, image_size, channels, dim, depth, heads
+        self.add_input = add_input
+        self.transformer = _XWrapper(dim, channels, image_size * image_size + (0 if add_input else 1), dim, depth, heads)
+        self.proj = nn.Linear(input_dim, image_size * image_size * dim)
+
+    def _build_packs(self, arena):
+        mk = arena.make_weights
+        t = self.transformer
+        self._w_proj = mk(self.proj.weight, self.proj.bias)
+        self._w_in = mk(t.project_in.weight, t.project_in.bias)
+        self._w_outp = mk(t.project_out.weight, t.project_out.bias)
+        self._xl = []
+        L = t.attn_layers.layers
+        for j in range(self.depth):
+            (n1, a, _), (n2, f, _) = L[2 * j], L[2 * j + 1]
+            self._xl.append((n1, mk(a.to_q.weight, None), mk(a.to_k.weight, None), mk(a.to_v.weight, None),
+                             mk(a.to_out.weight, a.to_out.bias), n2, mk(f.net[0][0].weight, f.net[0][0].bias),
+                             mk(f.net[2].weight, f.net[2].bias)))
+
+    def forward(self, x):
+        self._arena()
+        cdt, f32 = self.cdt, torch.float32
+        B, S, dim = x.shape[0], self.image_size, self.dim
+        n = S * S
+        t = self.transformer
+        h = ops.linear(ops.cast(x.float(), cdt), self._w_proj).view(B, n, dim)              # transformer.py:30-31
+        h = ops.linear(h, self._w_in, out_dtype=f32)                                        # project_in
+        h = h + t.pos_emb.emb.weight[:n] * (dim ** -0.5)                                    # scaled abs. pos. emb.
+        for (n1, Wq, Wk, Wv, Wo, n2, W1, W2) in self._xl:
+            hn, hid = ops.layernorm_fork(h, n1.weight, n1.bias, cdt)                        # pre-norm
+            o = ops.attention(ops.qkv3(hn, Wq, Wk, Wv), self.heads, 64 ** -0.5, True)       # causal, dim_head 64
+            h = ops.linear(o, Wo, residual=hid, out_dtype=f32)
+            hn, hid = ops.layernorm_fork(h, n2.weight, n2.bias, cdt)
+            h = ops.mlp(hn, W1, W2, ACT_GELU, residual=hid, out_dtype=f32)
+        hn = ops.layernorm(h, t.norm.weight, t.norm.bias, cdt)
+        z = ops.linear(hn, self._w_outp, out_dtype=f32)
+        return z.view(B, S, S, self.channels).permute(0, 3, 1, 2)                           # transformer.py:44-45
+
+
+def build_other(config, input_dim, vq_image_size, vq_channels):
+    """The non-Mixer branches of build_model (main.py:459-478,489-499)."""
+    if config.model_type == "vitgan":
+        return Generator(initialize_size=vq_image_size // 8, dropout=config.dropout, out_channels=vq_channels,
+                         input_dim=input_dim, dim=config.dim, num_heads=config.get("num_heads", 6), blocks=config.depth)
+    if config.model_type == "simple_vitgan":
+        return SimpleGenerator(size=vq_image_size, dropout=config.dropout, out_channels=vq_channels, input_dim=input_dim,
+                               dim=config.dim, num_heads=config.get("num_heads", 6), blocks=config.depth)
+    if config.model_type == "xtransformer":
+        return XTransformer(input_dim=input_dim, image_size=vq_image_size, channels=vq_channels, dim=config.dim,
+                            depth=config.depth, heads=config.get("num_heads", 6),
+                            initial_proj=config.get("initial_proj", True), add_input=config.get("add_input", False))
+    raise ValueError("model_type should be 'vitgan' or  'mlp_mixer' or 'xtransformer'")

@@ -58,15 +58,15 @@ def _split_k(n_out, k_out, red, bk):
     return max(1, min((256 + tiles - 1) // tiles, red // (8 * bk)))
 
 
-def _wgrad(dy2d, x2d, W, rows):
-    """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy)."""
+def _wgrad(dy2d, x2d, W, rows, ldy=None):
+    """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N)."""
     wg = _grad_buf(W.weight)
     bk = 64 if dy2d.dtype == torch.bfloat16 else 32
     sk = _split_k(W.N, W.K, rows, bk)
-    K.gemm(dy2d, x2d, wg, W.N, W.K, rows, ldx=W.N, ldw=W.K, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
+    K.gemm(dy2d, x2d, wg, W.N, W.K, rows, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
            flags=K.F_ATOMIC_OUT if sk > 1 else K.F_ACCUM_OUT, split_k=sk)
     if W.bias is not None and W.bias.requires_grad:
-        K.colsum(dy2d, _grad_buf(W.bias), accumulate=True)
+        K.colsum(dy2d, _grad_buf(W.bias), accumulate=True, ld=ldy)
     if W.on_grad is not None:
         W.on_grad(W)
 
@@ -570,3 +570,114 @@ class _CastFn(Function):
 
 def cast(x, dtype):
     return x if x.dtype == dtype else _CastFn.apply(x, dtype)
+
+
+# ---------------------------------------------------------------------------
+# VitGAN / x-transformer specific ops
+# ---------------------------------------------------------------------------
+class _SLNForkFn(Function):
+    """Self-modulated LayerNorm (vitgan.py:8-21), fork form: -> (gamma_s*w*LN(hl) + beta_s*w, identity alias of hl)."""
+
+    @staticmethod
+    def forward(ctx, hl, w, gamma, beta, gs, bs, out_dtype):
+        hl, w = _contig(hl), _contig(w)
+        g, b, gsd, bsd = gamma.detach(), beta.detach(), gs.detach().reshape(1), bs.detach().reshape(1)
+        y, mean, rstd = K.sln_fwd(hl, w, g, b, gsd, bsd, out_dtype)
+        ctx.save_for_backward(hl, w, g, b, gsd, bsd, mean, rstd)
+        ctx.sshape = gs.shape
+        ctx.set_materialize_grads(False)
+        return y, hl.view_as(hl)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        hl, w, g, b, gsd, bsd, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None, None, None
+        if dres is not None:
+            dres = _as(_contig(dres), torch.float32)
+        dhl, dw, dg, db, dgs, dbs = K.sln_bwd(_contig(dy), hl, w, g, b, gsd, bsd, mean, rstd, dres=dres)
+        return dhl, dw, dg, db, dgs.view(ctx.sshape), dbs.view(ctx.sshape), None
+
+
+def sln_fork(hl, w, ln_weight, ln_bias, gamma_s, beta_s, out_dtype):
+    return _SLNForkFn.apply(hl, w, ln_weight, ln_bias, gamma_s, beta_s, out_dtype)
+
+
+class _TransposePadFn(Function):
+    """(..., R, C) -> (..., C, Rp) with zero padding of the new last dim (VitGAN '(d k h)' regroup, vitgan.py:82)."""
+
+    @staticmethod
+    def forward(ctx, x, pad_to):
+        x = _contig(x)
+        ctx.R, ctx.C = x.shape[-2], x.shape[-1]
+        return K.transpose(x, pad_to=pad_to)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _contig(g)
+        R, C, Rp = ctx.R, ctx.C, g.shape[-1]
+        gt = K.transpose(g)                                    # (..., Rp, C)
+        if Rp == R:
+            return gt, None
+        batch = g.numel() // (C * Rp)
+        out = K.copy2d(gt, Rp * C, batch, R * C, R * C, g.dtype)
+        return out.view(*g.shape[:-2], R, C), None
+
+
+def transpose_pad(x, pad_to):
+    return _TransposePadFn.apply(x, pad_to)
+
+
+class _Copy2dFn(Function):
+    """rows x cols block copy between leading dims (drop / add per-head zero padding)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, cols, src_ld, dst_cols):
+        x = _contig(x)
+        ctx.cfg = (rows, cols, src_ld, dst_cols)
+        return K.copy2d(x, src_ld, rows, cols, dst_cols, x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, cols, src_ld, dst_cols = ctx.cfg
+        return K.copy2d(_contig(g), dst_cols, rows, min(cols, dst_cols), src_ld, g.dtype), None, None, None, None
+
+
+def copy2d(x, rows, cols, src_ld, dst_cols):
+    return _Copy2dFn.apply(x, rows, cols, src_ld, dst_cols)
+
+
+class _QKV3Fn(Function):
+    """qkv[..., 0:D | D:2D | 2D:3D] = x Wq^T | x Wk^T | x Wv^T (three bias-free Linears of x-transformers' Attention)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, Wq, Wk, Wv):
+        cdt = Wq.sh.dtype
+        x = _contig(x)
+        D, Kd = Wq.N, Wq.K
+        rows = x.numel() // Kd
+        qkv = torch.empty(*x.shape[:-1], 3 * D, dtype=cdt, device=x.device)
+        for i, W in enumerate((Wq, Wk, Wv)):
+            K.gemm(x, W.sh, qkv.view(-1)[i * D:], rows, D, Kd, ldx=Kd, ldw=Kd, y_map=(0, 0, 3 * D))
+        ctx.Ws, ctx.rows = (Wq, Wk, Wv), rows
+        ctx.train = wq.requires_grad
+        ctx.save_for_backward(x)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        (x,) = ctx.saved_tensors
+        Wq = ctx.Ws[0]
+        cdt, D, Kd, rows = Wq.sh.dtype, Wq.N, Wq.K, ctx.rows
+        dqkv = _as(_contig(dqkv), cdt)
+        dx = torch.empty_like(x)
+        for i, W in enumerate(ctx.Ws):
+            g = dqkv.view(-1)[i * D:]
+            K.gemm(g, W.sht, dx, rows, Kd, D, ldx=3 * D, ldw=D, residual=dx if i else None)
+            if ctx.train:
+                _wgrad(g, x, W, rows, ldy=3 * D)
+        return dx, None, None, None, None, None, None
+
+
+def qkv3(x, Wq, Wk, Wv):
+    return _QKV3Fn.apply(x, Wq.weight, Wk.weight, Wv.weight, Wq, Wk, Wv)

@@ -77,6 +77,9 @@ extern "C" {
  *   CONV3X3 : X is NHWC [B, Hin, Win, Cin]; m = (b*H + oy)*W + ox over the OUTPUT grid
  *             (H = Hin, or 2*Hin with FFVC_F_UPSAMPLE2X); k = (kh*3+kw)*Cin + ci; K = 9*Cin;
  *             W is [Cout][3][3][Cin] (KMAJOR).  Cin must be a multiple of 64 (bf16) / 32 (f32).
+ * Alignment: operand pointers, leading dims and batch / segment strides must keep 4-byte alignment (even element
+ * counts for bf16); the vectorised epilogue additionally needs 4-element aligned y / residual / aux rows, else a
+ * scalar epilogue is used.
  */
 typedef struct ffvc_gemm_desc {
   const void* x;
@@ -125,6 +128,17 @@ int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
                        const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
                        float* part_b, int64_t rows, int dim, void* stream);
 
+/* Self-modulated LayerNorm of the VitGAN generator (vitgan.py:8-21): y = gamma_s*w*LN(hl) + beta_s*w with scalar
+ * parameters gamma_s/beta_s (device pointers) and the per-token modulation w; hl, w fp32 [rows, dim].
+ * Backward emits dhl (+dres), dw, LN dgamma/dbeta partial rows and {sum dy*w*ln, sum dy*w} partial pairs
+ * (ffvc_layernorm_bwd_blocks(rows) rows each). */
+int ffvc_sln_fwd(const float* hl, const float* w, const float* gamma, const float* beta, const float* gamma_s,
+                 const float* beta_s, void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int dim, float eps,
+                 void* stream);
+int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma, const float* beta,
+                 const float* gamma_s, const float* beta_s, const float* mean, const float* rstd, const float* dres,
+                 float* dhl, float* dw, float* part_g, float* part_b, float* part_s, int64_t rows, int dim, void* stream);
+
 /* GroupNorm(G groups, affine) on NHWC [B, HW, C] with optional fused swish x*sigmoid(x):
  * taming Normalize()/nonlinearity() [upstream taming-transformers 0.0.6, SURVEY.md App. A.1].
  * ws: workspace of ffvc_groupnorm_ws_bytes(B, HW, G) bytes.  mean/rstd: [B, G] fp32. */
@@ -149,8 +163,13 @@ int ffvc_softmax_bwd(const void* p, const float* dp, void* ds, int p_dtype, int6
  * ------------------------------------------------------------------------- */
 int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* dst[b][c][r] = src[b][r][c] (+dtype conversion): einops Rearrange mlp_mixer_pytorch.py:31; W^T shadows for dgrad */
+/* dst_ld (0 = rows) >= rows pads every output row with zeros (per-head padding of VitGAN's (d k h) qkv layout,
+ * vitgan.py:82) */
 int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int batch, int rows, int cols,
-                   int64_t src_batch_stride, int64_t dst_batch_stride, void* stream);
+                   int64_t src_batch_stride, int64_t dst_batch_stride, int dst_ld, void* stream);
+/* dst[r, c] = c < cols ? src[r, c] : 0, c < dst_cols; independent leading dims (pad / unpad per-head blocks) */
+int ffvc_copy2d(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int64_t rows,
+                int cols, int dst_cols, void* stream);
 /* out[c] (+)= sum_r x[r,c]: bias gradients of nn.Linear / Conv1d */
 int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, int64_t ld, int accumulate,
                 void* stream);

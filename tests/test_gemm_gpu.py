@@ -177,3 +177,27 @@ def test_bad_args_raise(cuda):
         K.gemm(x, x, y, 8, 8, 8, ldx=7, ldw=8)
     with pytest.raises(FFVCError):
         K.gemm(x, x, y, 8, 8, 8, ldx=8, ldw=8, split_k=2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_dword_aligned_leading_dims(cuda, dt):
+    """VitGAN's dim_head = 170 gives K = 1020 / N = 3060: rows are only 4-/8-byte aligned."""
+    M, N, K_ = 96, 3060, 1020
+    x, w = _mk((M, K_), dt, cuda, 1), _mk((N, K_), dt, cuda, 2)
+    y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_)
+    assert _rel(y, x.double() @ w.double().T) < 2e-5
+    dy = _mk((M, N), dt, cuda, 3)
+    wg = torch.zeros(N, K_, dtype=torch.float32, device=cuda)
+    K.gemm(dy, x, wg, N, K_, M, ldx=N, ldw=K_, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS, flags=K.F_ACCUM_OUT)
+    assert _rel(wg, dy.double().T @ x.double()) < 2e-5
+    # head blocks at 340-byte offsets (170 bf16): q_h . k_h^T
+    H, dh, T = 6, 170, 16
+    qkv = _mk((2, T, 3 * H * dh), dt, cuda, 4)
+    S = torch.empty(2 * H, T, T, dtype=torch.float32, device=cuda)
+    D3 = 3 * H * dh
+    K.gemm(qkv, qkv.view(-1)[H * dh:], S, T, T, dh, ldx=D3, ldw=D3, batch=2 * H, batch_inner=H, xb=(T * D3, dh),
+           wb=(T * D3, dh), yb=(H * T * T, T * T), y_map=(0, 0, T))
+    q = qkv[:, :, :H * dh].reshape(2, T, H, dh).double()
+    k = qkv[:, :, H * dh:2 * H * dh].reshape(2, T, H, dh).double()
+    assert _rel(S.view(2, H, T, T), torch.einsum("bthd,bshd->bhts", q, k)) < 2e-5

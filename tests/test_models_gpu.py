@@ -179,8 +179,11 @@ def test_train_step_matches_oracle(cuda, cdt):
         assert_close(mid["embed"].cpu(), omid["embed"].detach(), 5e-4, 5e-5, "embed")
         assert rel < 1e-4                                   # north_star: CLIP loss within 1e-4 rel of the CPU reference
         params = dict(net.named_parameters())
+        gmax = max(v.grad.abs().max().item() for v in osd.values())
         for k, v in osd.items():
-            assert _relrms(params[k].grad, v.grad) < 2e-3, k
+            # parameters whose exact gradient is 0 (token-mix bias in front of a LayerNorm) hold round-off only
+            tiny = (params[k].grad.cpu() - v.grad).abs().max().item() < 1e-6 * gmax
+            assert tiny or _relrms(params[k].grad, v.grad) < 2e-3, k
     else:
         assert _relrms(mid["z"], omid["z"].detach()) < 3e-2
         if agree == 1.0:                                    # identical codes -> the remaining stages are comparable
@@ -205,3 +208,66 @@ def test_optimizer_step_matches_torch_adam(cuda):
         assert_close(p.detach().cpu(), ref[k].detach().cpu(), 1e-5, 1e-7, f"adam {k}")
     sd = opt.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+# ----------------------------------------------------------------------------- other mapper families
+from feed_forward_vqgan_clip_amd.mappers import Generator, SimpleGenerator, XTransformer  # noqa: E402
+
+
+def _check_mapper_golden(name, net, shape):
+    z = load(name)
+    net.load_state_dict(unpack_sd(z, "sd"))
+    net = net.cuda().prepare(F32)
+    x = t(z["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert tuple(y.shape) == shape
+    assert_close(y.cpu(), z["y"], 2e-4, 2e-5, name + " y")
+    net._ffvc_arena.zero_grad()
+    (y * t(z["gw"]).cuda()).sum().backward()
+    assert_close(x.grad.cpu(), z["dx"], 5e-4, 5e-5, name + " dx")
+    sd = dict(net.named_parameters())
+    gmax = max(g.abs().max().item() for g in grads(z, "grad").values())
+    for k, g in grads(z, "grad").items():
+        assert_close(sd[k].grad.cpu(), g, 1e-3, 1e-5 * gmax + 1e-6, f"{name} grad {k}")
+
+
+def test_vitgan_fp32_matches_reference_golden(cuda):
+    _check_mapper_golden("vitgan.npz", Generator(initialize_size=1, out_channels=8, input_dim=24, dim=12, num_heads=6,
+                                                 blocks=2), (3, 8, 8, 8))
+
+
+def test_simple_vitgan_fp32_matches_reference_golden(cuda):
+    _check_mapper_golden("simple_vitgan.npz", SimpleGenerator(size=4, dim=12, num_heads=6, blocks=2, out_channels=8,
+                                                              input_dim=24), (3, 8, 4, 4))
+
+
+@pytest.mark.parametrize("kind", ["vitgan", "simple_vitgan", "xtransformer"])
+@pytest.mark.parametrize("cdt", [F32, BF16])
+def test_other_mappers_match_oracle(cuda, kind, cdt):
+    """Realistic head geometry (dim 120 / 6 heads -> dim_head 20; x-transformer 3 heads x 64) vs the oracle."""
+    from oracle import mappers as omap
+    torch.manual_seed(5)
+    if kind == "vitgan":
+        net = Generator(initialize_size=1, out_channels=16, input_dim=32, dim=120, num_heads=6, blocks=2)
+        ofn = lambda sd, x: omap.vitgan_forward(sd, x, initialize_size=1, dim=120, blocks=2, num_heads=6, out_channels=16)  # noqa: E731
+    elif kind == "simple_vitgan":
+        net = SimpleGenerator(size=4, dim=120, num_heads=6, blocks=2, out_channels=16, input_dim=32)
+        ofn = lambda sd, x: omap.simple_vitgan_forward(sd, x, size=4, dim=120, blocks=2, num_heads=6, out_channels=16)  # noqa: E731
+    else:
+        net = XTransformer(input_dim=32, image_size=4, channels=16, dim=64, depth=2, heads=3)
+        ofn = lambda sd, x: omap.xtransformer_forward(sd, x, image_size=4, channels=16, dim=64, depth=2, heads=3)  # noqa: E731
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda().prepare(cdt)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(5, 32, generator=g)
+    y = net(x.cuda())
+    yo = ofn(sd, x)
+    gw = torch.randn(*yo.shape, generator=g)
+    net._ffvc_arena.zero_grad()
+    (y * gw.cuda()).sum().backward()
+    (yo * gw).sum().backward()
+    tol = 2e-4 if cdt == F32 else 4e-2
+    assert _relrms(y, yo.detach()) < tol, "forward"
+    params = dict(net.named_parameters())
+    worst = max(_relrms(params[k].grad, v.grad) for k, v in sd.items() if v.grad.abs().max() > 1e-6)
+    assert worst < (2e-3 if cdt == F32 else 1e-1), f"worst param-grad rel-rms {worst}"
