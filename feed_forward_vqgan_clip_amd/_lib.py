@@ -74,6 +74,7 @@ class GemmDesc(Structure):
         ("conv_Cin", c_int32),
         ("x_mi", c_int32),
         ("x_so", c_int64),
+        ("slab_stride", c_int64),
     ]
 
 
@@ -122,6 +123,7 @@ _SIGNATURES = {
     "ffvc_copy_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "ffvc_im2col3x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_mul_dev_scalar": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ffvc_slab_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ffvc_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ffvc_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ffvc_last_error": (c_char_p, []),

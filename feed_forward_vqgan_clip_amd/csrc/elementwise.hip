@@ -58,23 +58,56 @@ __global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ s
 }
 
 // ---------------------------- column sums ----------------------------------
-// out[c] (+)= scale * sum_r x[r, c]   (bias gradients; reduction of LayerNorm partials)
+// out[c] (+)= sum_r x[r, c]   (bias gradients; reduction of LayerNorm partials)
+// block = 64 column-quads x 4 row-lanes (8/16-byte loads); gridDim.y strips of rows, atomics combine strips.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
-                                                     int cols, int64_t ld, int rows_per_block) {
-  // block = 64 columns x 4 row-lanes; gridDim.y strips of rows, atomics combine strips
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int ry = threadIdx.x >> 6;
+                                                     int cols, int64_t ld, int rows_per_block, int vec) {
+  __shared__ float red[4][256];
+  const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float a = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + ry; r < r1; r += 4) a += ElemTraits<T>::load(x + r * ld + c);
-  red[ry][threadIdx.x & 63] = a;
-  __syncthreads();
-  if (ry == 0 && c < cols) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(out + c, t);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    const int c = (blockIdx.x * 64 + tx) * 4;
+    if (c < cols)
+      for (int64_t r = r0 + ry; r < r1; r += 4) {
+        const f32x4_t v = load4(x + r * ld + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += v[j];
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[ry][tx * 4 + j] = a[j];
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        atomicAdd(out + c + j, red[0][tx * 4 + j] + red[1][tx * 4 + j] + red[2][tx * 4 + j] + red[3][tx * 4 + j]);
+    }
+  } else {
+    const int c = blockIdx.x * 64 + tx;
+    if (c < cols)
+      for (int64_t r = r0 + ry; r < r1; r += 4) a[0] += ElemTraits<T>::load(x + r * ld + c);
+    red[ry][tx] = a[0];
+    __syncthreads();
+    if (ry == 0 && c < cols) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+  }
+}
+
+// y[i] (+)= sum_s slab[s][i]  — combine of split-K partial slabs (plain vector stores instead of scalar fp32
+// atomics, each of which is its own fabric transaction)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ y,
+                                                          int64_t n, int nslab, int accumulate) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4_t a = accumulate ? load4(y + i * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < nslab; ++s2) a += load4(slabs + (int64_t)s2 * n + i * 4);
+    store4(y + i * 4, a);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    float a = accumulate ? y[i] : 0.f;
+    for (int s2 = 0; s2 < nslab; ++s2) a += slabs[(int64_t)s2 * n + i];
+    y[i] = a;
   }
 }
 
@@ -423,7 +456,14 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ x, fl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
     float a = 0.f;
-    for (int c = lane; c < cols; c += 64) a += ElemTraits<T>::load(x + r * cols + c);
+    if ((cols & 3) == 0) {
+      for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4_t v = load4(x + r * cols + c);
+        a += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    } else {
+      for (int c = lane; c < cols; c += 64) a += ElemTraits<T>::load(x + r * cols + c);
+    }
     a = wave_sum(a);
     if (lane == 0) atomicAdd(out + (r % period), a);
   }
@@ -534,9 +574,11 @@ extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, i
   int strips = (int)((rows + 511) / 512);
   if (strips > 512) strips = 512;
   const int rpb = (int)((rows + strips - 1) / strips);
-  dim3 grid(ceil_div(cols, 64), ceil_div(rows, rpb));
+  const int es = dtype == FFVC_BF16 ? 2 : 4;
+  const int vec = (cols % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0);
+  dim3 grid(ceil_div(cols, vec ? 256 : 64), ceil_div(rows, rpb));
   DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, cols,
-                                           ld, rpb));
+                                           ld, rpb, vec));
   FFVC_LAUNCH_CHECK();
   return 0;
 }
@@ -738,6 +780,16 @@ extern "C" int ffvc_copy2d(const void* src, int src_dtype, int64_t src_ld, void*
   DISPATCH_DT(src_dtype, ST, DISPATCH_DT(dst_dtype, DT,
               hipLaunchKernelGGL((copy2d_kernel<ST, DT>), dim3(ew_grid(rows * dst_cols, 1024)), dim3(256), 0, st,
                                  (const ST*)src, src_ld, (DT*)dst, dst_ld, rows, cols, dst_cols)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nslab, int accumulate, void* stream) {
+  FFVC_CHECK_ARG(slabs && y && n > 0 && nslab > 0, "ffvc_slab_reduce: bad args");
+  FFVC_CHECK_ARG(((uintptr_t)slabs % 16) == 0 && ((uintptr_t)y % 16) == 0 && (n % 4) == 0,
+                 "ffvc_slab_reduce: needs 16-byte aligned buffers and n %% 4 == 0");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, slabs, y, n, nslab,
+                     accumulate);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
   const bool res_f32 = flags & FFVC_F_RES_F32;
   const bool atomic_out = flags & FFVC_F_ATOMIC_OUT;
   const bool accum_out = flags & FFVC_F_ACCUM_OUT;
-  const int64_t ybz = zo * p.ybo + zi * p.ybi;
+  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)blockIdx.z * p.slab_stride;
   const int64_t rbz = zo * p.rbo + zi * p.rbi;
   const int64_t abz = zo * p.abo + zi * p.abi;
 #pragma unroll
@@ -541,8 +541,11 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   if (d.batch_inner < 1) d.batch_inner = 1;
   FFVC_CHECK_ARG(d.batch <= 65535, "ffvc_gemm: batch %d > 65535", d.batch);
   if (d.split_k < 1) d.split_k = 1;
-  FFVC_CHECK_ARG(d.split_k == 1 || (d.flags & FFVC_F_ATOMIC_OUT),
-                 "ffvc_gemm: split_k>1 needs FFVC_F_ATOMIC_OUT");
+  FFVC_CHECK_ARG(d.split_k == 1 || (d.flags & FFVC_F_ATOMIC_OUT) || d.slab_stride > 0,
+                 "ffvc_gemm: split_k>1 needs FFVC_F_ATOMIC_OUT or slab_stride (partial slabs)");
+  FFVC_CHECK_ARG(d.slab_stride == 0 || ((d.flags & FFVC_F_OUT_F32) && !d.bias && !d.residual && d.act == FFVC_ACT_NONE &&
+                                        !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) && mult(d.slab_stride, 4)),
+                 "ffvc_gemm: slab output must be a plain fp32 store (no bias/residual/activation)");
   FFVC_CHECK_ARG(!(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) || (d.flags & FFVC_F_OUT_F32),
                  "ffvc_gemm: atomic / accumulating output must be fp32");
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_ACCUM_OUT) || d.split_k == 1, "ffvc_gemm: FFVC_F_ACCUM_OUT needs split_k == 1");

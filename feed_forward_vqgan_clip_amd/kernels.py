@@ -47,7 +47,7 @@ def _need_cuda(*ts):
 def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, bias=None,
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
-         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None):
+         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0):
     """Enqueue `ffvc_gemm`. See include/ffvc.h for the index maps.
 
     y_map / r_map = (mi, so, sm): row offset(m) = (m // mi) * so + (m % mi) * sm (mi = 0: m * sm).
@@ -94,6 +94,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
         d.conv_H, d.conv_W, d.conv_Cin = conv
     if x_map is not None:
         d.x_mi, d.x_so = x_map
+    d.slab_stride = slab_stride
     lib = _lib.load()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -411,3 +412,14 @@ def mul_dev_scalar(x, s):
     y = torch.empty_like(x)
     _call("ffvc_mul_dev_scalar", x.data_ptr(), s.data_ptr(), y.data_ptr(), x.numel(), stream_ptr())
     return y
+
+
+def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
+    """out[M,N] (fp32, contiguous) += X W^T with the K range cut into `split_k` slices whose partial tiles go to
+    slabs (plain stores) and are combined by one ffvc_slab_reduce pass."""
+    if split_k <= 1:
+        return gemm(x, w, out, M, N, K, flags=kw.pop("flags", 0) | F_ACCUM_OUT, **kw)
+    slabs = torch.empty(split_k, M, N, dtype=torch.float32, device=out.device)
+    gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
+    _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
+    return out

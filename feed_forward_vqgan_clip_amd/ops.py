@@ -53,9 +53,9 @@ def _grad_buf(p):
 
 def _split_k(n_out, k_out, red, bk):
     tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
-    if tiles >= 128:
+    if tiles >= 512:
         return 1
-    return max(1, min((256 + tiles - 1) // tiles, red // (8 * bk)))
+    return max(1, min((768 + tiles - 1) // tiles, red // (8 * bk)))
 
 
 def _wgrad(dy2d, x2d, W, rows, ldy=None):
@@ -63,8 +63,8 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None):
     wg = _grad_buf(W.weight)
     bk = 64 if dy2d.dtype == torch.bfloat16 else 32
     sk = _split_k(W.N, W.K, rows, bk)
-    K.gemm(dy2d, x2d, wg, W.N, W.K, rows, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
-           flags=K.F_ATOMIC_OUT if sk > 1 else K.F_ACCUM_OUT, split_k=sk)
+    K.gemm_splitk_accumulate(dy2d, x2d, wg, W.N, W.K, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
+                             w_mode=K.OP_TRANS)
     if W.bias is not None and W.bias.requires_grad:
         K.colsum(dy2d, _grad_buf(W.bias), accumulate=True, ld=ldy)
     if W.on_grad is not None:
@@ -209,8 +209,8 @@ class _TokenMLPFn(Function):
                 if seg_ok:
                     # dW[n,k] = sum_{b,d} g[b][n,d] a[b][k,d]: K-major GEMM over the segmented (b,d) axis
                     sk = _split_k(n_out, k_out, B * D, bk)
-                    K.gemm(g, a, wg, n_out, k_out, B * D, ldx=D, ldw=D, kseg=D, xkso=n_out * D, wkso=k_out * D,
-                           flags=K.F_ATOMIC_OUT if sk > 1 else K.F_ACCUM_OUT, split_k=sk)
+                    K.gemm_splitk_accumulate(g, a, wg, n_out, k_out, B * D, sk, ldx=D, ldw=D, kseg=D, xkso=n_out * D,
+                                             wkso=k_out * D)
                 else:
                     for b in range(B):
                         K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ACCUM_OUT)

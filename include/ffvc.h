@@ -109,6 +109,9 @@ typedef struct ffvc_gemm_desc {
   /* optional split row map of a KMAJOR X operand (0 = plain m*ldx) */
   int32_t x_mi;
   int64_t x_so;
+  /* split-K through partial slabs: K-slice z stores its fp32 partial tile at y + z*slab_stride (plain vector
+   * stores); combine with ffvc_slab_reduce.  0 = off. */
+  int64_t slab_stride;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
@@ -218,6 +221,8 @@ int ffvc_copy_rows(const float* src, int64_t src_stride, float* dst, int64_t dst
  * feeds the dgrad of the decoder's conv_out (Cout = 3), taming Decoder.conv_out [upstream] */
 int ffvc_im2col3x3(const void* x, int x_dtype, void* out, int out_dtype, int B, int H, int W, int C, int Kp, void* stream);
 int ffvc_mul_dev_scalar(const float* x, const float* s, float* y, int64_t n, void* stream); /* y = x * s[0] */
+/* y[i] (+)= sum_s slabs[s*n + i]: combine of split-K partial slabs */
+int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nslab, int accumulate, void* stream);
 int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream);            /* out[0] += sum x^2 */
 int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream); /* y = a*x + b*y */
 

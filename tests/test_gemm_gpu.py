@@ -201,3 +201,15 @@ def test_dword_aligned_leading_dims(cuda, dt):
     q = qkv[:, :, :H * dh].reshape(2, T, H, dh).double()
     k = qkv[:, :, H * dh:2 * H * dh].reshape(2, T, H, dh).double()
     assert _rel(S.view(2, H, T, T), torch.einsum("bthd,bshd->bhts", q, k)) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_splitk_slabs(cuda, dt):
+    M, N, K_ = 256, 384, 4096
+    xt, wt = _mk((K_, M), dt, cuda, 1), _mk((K_, N), dt, cuda, 2)
+    out = torch.ones(M, N, dtype=torch.float32, device=cuda)
+    K.gemm_splitk_accumulate(xt, wt, out, M, N, K_, 5, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
+    assert _rel(out, xt.double().T @ wt.double() + 1.0) < 2e-5
+    out2 = torch.ones(M, N, dtype=torch.float32, device=cuda)
+    K.gemm_splitk_accumulate(xt, wt, out2, M, N, K_, 1, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
+    assert _rel(out2, xt.double().T @ wt.double() + 1.0) < 2e-5
