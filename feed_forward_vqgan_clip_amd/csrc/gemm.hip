@@ -24,7 +24,9 @@
 //     the very same staging/fragment code: a 16-byte chunk is 8 bf16 (one MFMA) or 4 f32 (four).
 //   * workgroup id -> tile map is XCD-aware (consecutive ids round-robin over the 8 XCDs, so
 //     each XCD gets a contiguous run of tiles that share operand panels in its private L2).
-#include "common.h"
+#include "gemm_common.h"
+
+int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok);   // gemm2.hip: 1 = handled, 0 = not eligible, <0 error
 
 namespace {
 
@@ -298,21 +300,6 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const u32x4_t& a
                                                0, 0);
 }
 
-// bf16 storage rounds the result to 2^-8 relative: the 1.5e-7-accurate erf (common.h) is exact for that purpose
-// and ~3x cheaper in the epilogue; fp32 ("parity") storage keeps libm's erff.
-template <typename T>
-__device__ __forceinline__ float apply_act(int act, float v) {
-  if (act == FFVC_ACT_GELU) return sizeof(T) == 2 ? act_gelu_fast(v) : act_gelu(v);
-  if (act == FFVC_ACT_QUICKGELU) return act_quickgelu(v);
-  return v;
-}
-template <typename T>
-__device__ __forceinline__ float apply_act_grad(int act, float pre) {
-  if (act == FFVC_ACT_GELU) return sizeof(T) == 2 ? act_gelu_grad_fast(pre) : act_gelu_grad(pre);
-  if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad(pre);
-  return 1.0f;
-}
-
 template <typename T, int XMODE, int WMODE, bool TRSAFE>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, int tiles_n,
                                                         int n_tiles, int ksplit_len, int vec_ok) {
@@ -398,94 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
     }
   }
 
-  // ---- epilogue: lane holds, per (nt, mt, q), 4 consecutive n for one m --------------------
-  const int flags = p.flags;
-  const bool out_f32 = flags & FFVC_F_OUT_F32;
-  const bool res_f32 = flags & FFVC_F_RES_F32;
-  const bool atomic_out = flags & FFVC_F_ATOMIC_OUT;
-  const bool accum_out = flags & FFVC_F_ACCUM_OUT;
-  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)blockIdx.z * p.slab_stride;
-  const int64_t rbz = zo * p.rbo + zi * p.rbi;
-  const int64_t abz = zo * p.abo + zi * p.abi;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = m0 + wm * 64 + mt * 32 + l31;
-    if (m >= p.M) continue;
-    const int64_t yrow = ybz + (p.y_mi ? (int64_t)(m / p.y_mi) * p.y_so + (int64_t)(m % p.y_mi) * p.y_sm
-                                       : (int64_t)m * p.y_sm);
-    const int64_t rrow = rbz + (p.r_mi ? (int64_t)(m / p.r_mi) * p.r_so + (int64_t)(m % p.r_mi) * p.r_sm
-                                       : (int64_t)m * p.r_sm);
-    const int64_t arow = abz + (int64_t)m * p.ldaux;
-    const float bias_m = (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) ? p.bias[m] : 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
-        if (n >= p.N) continue;
-        f32x4_t v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
-        const bool full = vec_ok && (n + 3 < p.N);
-        if (full) {
-          if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
-            const f32x4_t bv = *(const f32x4_t*)(p.bias + n);
-            v += bv;
-          }
-          if (flags & FFVC_F_MUL_ACT_GRAD) {
-            const f32x4_t pre = load4((const T*)p.aux + arow + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad<T>(p.act, pre[j]);
-          } else if (p.act != FFVC_ACT_NONE) {
-            if (flags & FFVC_F_WRITE_PREACT) store4((T*)p.aux + arow + n, v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(p.act, v[j]);
-          }
-          if (p.residual) {
-            const f32x4_t rv = res_f32 ? load4((const float*)p.residual + rrow + n)
-                                       : load4((const T*)p.residual + rrow + n);
-            v += rv;
-          }
-          if (atomic_out) {
-            float* yp = (float*)p.y + yrow + n;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(yp + j, v[j]);
-          } else if (accum_out) {
-            float* yp = (float*)p.y + yrow + n;
-            store4(yp, load4(yp) + v);
-          } else if (out_f32) {
-            store4((float*)p.y + yrow + n, v);
-          } else {
-            store4((T*)p.y + yrow + n, v);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (n + j >= p.N) continue;
-            float u = v[j];
-            if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) u += p.bias[n + j];
-            if (flags & FFVC_F_MUL_ACT_GRAD) {
-              u *= apply_act_grad<T>(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
-            } else if (p.act != FFVC_ACT_NONE) {
-              if (flags & FFVC_F_WRITE_PREACT) ElemTraits<T>::store((T*)p.aux + arow + n + j, u);
-              u = apply_act<T>(p.act, u);
-            }
-            if (p.residual)
-              u += res_f32 ? ((const float*)p.residual)[rrow + n + j]
-                           : ElemTraits<T>::load((const T*)p.residual + rrow + n + j);
-            if (atomic_out)
-              atomicAdd((float*)p.y + yrow + n + j, u);
-            else if (accum_out)
-              ((float*)p.y)[yrow + n + j] += u;
-            else if (out_f32)
-              ((float*)p.y)[yrow + n + j] = u;
-            else
-              ElemTraits<T>::store((T*)p.y + yrow + n + j, u);
-          }
-        }
-      }
-    }
-  }
+  ffvc_gemm_detail::gemm_epilogue<T>(p, acc, m0, n0, wm, wn, lane, zo, zi, vec_ok);
 }
 
 template <typename T, int XMODE, int WMODE, bool TRSAFE>

@@ -1,0 +1,330 @@
+// gemm2.hip — LDS-DMA staged bf16 fast path of ffvc_gemm (second kernel generation).
+//
+// Why: profiling the register-staged kernel (gemm.hip) on MI355X shows it is bound by the LDS *write* path:
+// one K step stages 32 KB through ds_write_b128 (~79 B/clk/CU => ~415 cycles) next to 512 cycles of MFMA.
+// Here operand tiles travel HBM/L2 -> LDS directly with `global_load_lds_dwordx4` (1 KiB per wave-instruction,
+// no VGPR round trip, no ds_write), into a 2-deep LDS ring so the DMA of tile t+1 overlaps the MFMAs of tile t,
+// with ONE barrier per K step:
+//
+//     loop t:  s_waitcnt vmcnt(0)   (my pieces of tile t landed)
+//              barrier              (everyone's pieces landed; everyone finished reading tile t-1)
+//              issue DMA of tile t+1 into ring[(t+1)&1]
+//              64 MFMAs on ring[t&1]
+//
+// LDS-DMA writes lane-linearly (wave-uniform base + lane*16 B), so the bank-conflict-free image is obtained by
+// permuting the per-lane SOURCE address and applying the same involution on the fragment read:
+//   K-major / conv tile  [128 rows][128 B]: two rows form a 256-B line of 16 slots; slot' = slot ^ (line & 15)
+//                         -> the 16 lanes of every ds_read_b128 lane group hit 16 distinct slots;
+//   reduction-major tile [64 k][256 B]:     slot' = slot ^ ((k & 3) << 2) -> the 4 k-rows x 2 column blocks of a
+//                         ds_read_b64_tr_b16 lane group land on 8 distinct 32-B ranges.
+// Out-of-range rows / conv halo taps / K tails read from a zeroed page instead of being masked (the DMA cannot
+// write zeros for inactive lanes).
+//
+// Same tile geometry and epilogue as v1 (128x128, 4 waves x 64x64, MFMA 32x32x16, A := W rows, B := X rows).
+// Shapes this path does not cover (fp32, rows not 16-byte aligned, ...) fall back to gemm.hip.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = 16384;              // 128 x 128 B (K-major)  ==  64 x 256 B (reduction-major)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // X tile + W tile
+constexpr int EPC = 8;                         // bf16 per 16-byte chunk
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+__device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)lds_wave_base, 16, 0, 0);
+}
+
+// ---- K-major operand: 4 DMA pieces per thread per K step ------------------------------------------------
+// piece j of wave w covers LDS chunk positions p = (4j + w) * 64 + lane; line = p >> 4, slot = p & 15,
+// source chunk c' = slot ^ (line & 15): row = 2 * line + (c' >> 3), k-chunk = c' & 7.
+struct KMajorDma {
+  const uint16_t* rowp[4];
+  int kc[4];        // element offset of this lane's k-chunk inside the K step
+  bool rvalid[4];
+  int kseg;
+  int64_t kso;
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int row0, int rows, int kseg_, int64_t kso_,
+                                       int tid, int mi, int64_t so) {
+    const int lane = tid & 63, w = tid >> 6;
+    kseg = kseg_;
+    kso = kso_;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = (4 * j + w) * 64 + lane;
+      const int line = p >> 4, cp = (p & 15) ^ (line & 15);
+      const int r = row0 + 2 * line + (cp >> 3);
+      kc[j] = (cp & 7) * EPC;
+      rvalid[j] = r < rows;
+      const int rr = rvalid[j] ? r : 0;
+      rowp[j] = base + (mi ? (int64_t)(rr / mi) * so + (int64_t)(rr % mi) * ld : (int64_t)rr * ld);
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+    const int64_t kbase = kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = rvalid[j] && (k0 + kc[j] + EPC <= kend);
+      dma16(ok ? (const void*)(rowp[j] + kbase + kc[j]) : (const void*)zero, tile + (4 * j + w) * 1024);
+    }
+  }
+};
+
+// ---- implicit im2col (3x3, pad 1, optional fused nearest 2x upsample) ------------------------------------
+struct ConvDma {
+  const uint16_t* base;
+  int pix[4], oy[4], ox[4], kc[4];
+  bool rvalid[4];
+  int H, W, Win, Cin, ups;
+  __device__ __forceinline__ void init(const uint16_t* base_, int row0, int rows, int H_, int W_, int Cin_, int ups_,
+                                       int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    base = base_;
+    H = H_;
+    W = W_;
+    Cin = Cin_;
+    ups = ups_;
+    Win = W_ >> ups_;
+    const int Hin = H_ >> ups_;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = (4 * j + w) * 64 + lane;
+      const int line = p >> 4, cp = (p & 15) ^ (line & 15);
+      const int r = row0 + 2 * line + (cp >> 3);
+      kc[j] = (cp & 7) * EPC;
+      rvalid[j] = r < rows;
+      const int rr = rvalid[j] ? r : 0;
+      const int b = rr / (H * W);
+      const int rem = rr - b * (H * W);
+      oy[j] = rem / W;
+      ox[j] = rem - oy[j] * W;
+      pix[j] = b * Hin * Win;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int /*kend*/, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+    const int tap = k0 / Cin;
+    const int ci0 = k0 - tap * Cin;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
+      const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (4 * j + w) * 1024);
+    }
+  }
+};
+
+// ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
+// source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
+struct TransDma {
+  const uint16_t* colp[4];
+  int krow[4];
+  bool cvalid[4];
+  int64_t ld;
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld_, int col0, int cols, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    ld = ld_;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = (4 * j + w) * 64 + lane;
+      krow[j] = p >> 4;
+      const int c = col0 + (((p & 15) ^ ((krow[j] & 3) << 2)) * EPC);
+      cvalid[j] = c + EPC <= cols;
+      colp[j] = base + (cvalid[j] ? c : 0);
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + krow[j];
+      const bool ok = cvalid[j] && k < kend;
+      dma16(ok ? (const void*)(colp[j] + (int64_t)k * ld) : (const void*)zero, tile + (4 * j + w) * 1024);
+    }
+  }
+};
+
+// ---- fragment reads (one 16-byte chunk = 8 bf16, k = 16*sub + 8*h + e) -----------------------------------
+__device__ __forceinline__ u32x4_t frag_kmajor(const unsigned char* tile, int row, int sub, int lane) {
+  const int line = row >> 1;
+  const int cp = (((row & 1) << 3) | (2 * sub + (lane >> 5))) ^ (line & 15);
+  return *(const u32x4_t*)(tile + line * 256 + cp * 16);
+}
+__device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row, int sub, int lane) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const int c = lane & 15;
+  const int i = (row - (lane & 31)) + 16 * ((lane >> 4) & 1) + (c & 3) * 4;      // column of this lane's 4 elements
+  const int k = 16 * sub + 8 * (lane >> 5) + (c >> 2);                          // k & 3 == c >> 2 for both reads
+  const int slot = (i >> 3) ^ ((k & 3) << 2);
+  const unsigned char* a0 = tile + k * 256 + slot * 16 + (i & 7) * 2;
+  union {
+    s16x4_t hh[2];
+    u32x4_t v;
+  } u;
+  u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * 256));
+  return u.v;
+}
+
+__device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  union {
+    u32x4_t u;
+    bf16x8_t h;
+  } ua, ub;
+  ua.u = a;
+  ub.u = b;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+}
+
+template <int XMODE, int WMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles,
+                                                         int ksplit_len, int vec_ok, const uint16_t* zero) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_BYTES];   // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+  const int k_begin = blockIdx.z * ksplit_len;
+  const int k_end = min(p.K, k_begin + ksplit_len);
+  const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
+  const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
+
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma,
+                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma, KMajorDma>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma, KMajorDma>::type;
+  XDma sx;
+  WDma sw;
+  if constexpr (XMODE == FFVC_OP_CONV3X3)
+    sx.init(xb, m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  else if constexpr (XMODE == FFVC_OP_TRANS)
+    sx.init(xb, p.ldx, m0, p.M, tid);
+  else
+    sx.init(xb, p.ldx, m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
+  if constexpr (WMODE == FFVC_OP_TRANS)
+    sw.init(wb, p.ldw, n0, p.N, tid);
+  else
+    sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid, 0, 0);
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk > 0) {
+    sx.issue(smem, k_begin, k_end, zero, tid);
+    sw.issue(smem + TILE_BYTES, k_begin, k_end, zero, tid);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned char* cur = smem + (kt & 1) * STAGE_BYTES;
+    if (kt + 1 < nk) {
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      sx.issue(nxt, k_begin + (kt + 1) * BK, k_end, zero, tid);
+      sw.issue(nxt + TILE_BYTES, k_begin + (kt + 1) * BK, k_end, zero, tid);
+    }
+    const unsigned char* sX = cur;
+    const unsigned char* sW = cur + TILE_BYTES;
+    // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
+    u32x4_t fa[2][2], fb[2][2];
+    auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rw = wn * 64 + t * 32 + l31, rx = wm * 64 + t * 32 + l31;
+        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+      }
+    };
+    fetch(0, fa[0], fb[0]);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < 3) fetch(sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+    }
+  }
+  ffvc_gemm_detail::gemm_epilogue<uint16_t>(p, acc, m0, n0, wm, wn, lane, zo, zi, vec_ok);
+}
+
+uint16_t* g_zero_page[16] = {nullptr};
+
+const uint16_t* zero_page() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_zero_page[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
+    g_zero_page[dev] = (uint16_t*)p;
+  }
+  return g_zero_page[dev];
+}
+
+template <int XMODE, int WMODE>
+int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
+  const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
+  const int n_tiles = tiles_m * tiles_n;
+  int split = d.split_k < 1 ? 1 : d.split_k;
+  const int ksteps = ceil_div(d.K, BK);
+  if (split > ksteps) split = ksteps < 1 ? 1 : ksteps;
+  const int ksplit_len = ceil_div(ksteps, split) * BK;
+  split = ceil_div(d.K, ksplit_len);
+  if (split < 1) split = 1;
+  dim3 grid(n_tiles, d.batch, split);
+  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE>), grid, dim3(NTHREADS), 0, st, d, tiles_n, n_tiles, ksplit_len, vec_ok,
+                     zero);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ffvc_set_error("gemm2 launch failed: %s", hipGetErrorString(e));
+    return -(int)e - 1000;
+  }
+  return 1;
+}
+
+inline bool m8(int64_t v) { return (v % 8) == 0; }
+
+}  // namespace
+
+// 1 = enqueued here, 0 = shape not eligible (caller falls back to gemm.hip), < 0 = launch error.
+int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
+  if (d.in_dtype != FFVC_BF16 || (d.flags & FFVC_F_TR_SAFE)) return 0;
+  // the DMA moves whole 16-byte chunks from 16-byte aligned addresses
+  if (((uintptr_t)d.x % 16) || ((uintptr_t)d.w % 16)) return 0;
+  if (!m8(d.xbo) || !m8(d.xbi) || !m8(d.wbo) || !m8(d.wbi) || !m8(d.ldw)) return 0;
+  if (d.x_mode != FFVC_OP_CONV3X3 && !m8(d.ldx)) return 0;
+  if (d.x_mode == FFVC_OP_KMAJOR && (!m8(d.K) || (d.x_mi && !m8(d.x_so)))) return 0;
+  if (d.w_mode == FFVC_OP_KMAJOR && !m8(d.K)) return 0;
+  if (d.x_mode == FFVC_OP_TRANS && !m8(d.M)) return 0;
+  if (d.w_mode == FFVC_OP_TRANS && !m8(d.N)) return 0;
+  if (d.kseg && (!m8(d.xkso) || !m8(d.wkso))) return 0;
+  const uint16_t* zero = zero_page();
+  if (!zero) return 0;
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero);
+  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) return launch2<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero);
+  return 0;
+}
