@@ -26,10 +26,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int TILE_BYTES = 16384;              // 128 x 128 B (K-major)  ==  64 x 256 B (reduction-major)
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // X tile + W tile
+constexpr int BN = 128, BK = 64, NTHREADS = 256;
 constexpr int EPC = 8;                         // bf16 per 16-byte chunk
+// An operand tile of ROWS rows is ROWS x 128 B (K-major) == 64 x (2*ROWS) B (reduction-major): ROWS/32 DMA pieces
+// per thread per K step.  The W tile is always 128 rows; the X tile 128 or 256 (block tile BM x 128).
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
@@ -41,10 +41,12 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_b
 // ---- K-major operand: 4 DMA pieces per thread per K step ------------------------------------------------
 // piece j of wave w covers LDS chunk positions p = (4j + w) * 64 + lane; line = p >> 4, slot = p & 15,
 // source chunk c' = slot ^ (line & 15): row = 2 * line + (c' >> 3), k-chunk = c' & 7.
+template <int ROWS>
 struct KMajorDma {
-  const uint16_t* rowp[4];
-  int kc[4];        // element offset of this lane's k-chunk inside the K step
-  bool rvalid[4];
+  static constexpr int NP = ROWS / 32;
+  const uint16_t* rowp[NP];
+  int kc[NP];        // element offset of this lane's k-chunk inside the K step
+  bool rvalid[NP];
   int kseg;
   int64_t kso;
   __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int row0, int rows, int kseg_, int64_t kso_,
@@ -53,7 +55,7 @@ struct KMajorDma {
     kseg = kseg_;
     kso = kso_;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const int p = (4 * j + w) * 64 + lane;
       const int line = p >> 4, cp = (p & 15) ^ (line & 15);
       const int r = row0 + 2 * line + (cp >> 3);
@@ -67,7 +69,7 @@ struct KMajorDma {
     const int w = tid >> 6;
     const int64_t kbase = kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const bool ok = rvalid[j] && (k0 + kc[j] + EPC <= kend);
       dma16(ok ? (const void*)(rowp[j] + kbase + kc[j]) : (const void*)zero, tile + (4 * j + w) * 1024);
     }
@@ -75,10 +77,12 @@ struct KMajorDma {
 };
 
 // ---- implicit im2col (3x3, pad 1, optional fused nearest 2x upsample) ------------------------------------
+template <int ROWS>
 struct ConvDma {
+  static constexpr int NP = ROWS / 32;
   const uint16_t* base;
-  int pix[4], oy[4], ox[4], kc[4];
-  bool rvalid[4];
+  int pix[NP], oy[NP], ox[NP], kc[NP];
+  bool rvalid[NP];
   int H, W, Win, Cin, ups;
   __device__ __forceinline__ void init(const uint16_t* base_, int row0, int rows, int H_, int W_, int Cin_, int ups_,
                                        int tid) {
@@ -91,7 +95,7 @@ struct ConvDma {
     Win = W_ >> ups_;
     const int Hin = H_ >> ups_;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const int p = (4 * j + w) * 64 + lane;
       const int line = p >> 4, cp = (p & 15) ^ (line & 15);
       const int r = row0 + 2 * line + (cp >> 3);
@@ -111,7 +115,7 @@ struct ConvDma {
     const int ci0 = k0 - tap * Cin;
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
       const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
@@ -122,19 +126,22 @@ struct ConvDma {
 
 // ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
 // source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
+template <int ROWS>
 struct TransDma {
-  const uint16_t* colp[4];
-  int krow[4];
-  bool cvalid[4];
+  static constexpr int NP = ROWS / 32;
+  static constexpr int CPR = ROWS / 8;      // 16-byte chunks per k-row
+  const uint16_t* colp[NP];
+  int krow[NP];
+  bool cvalid[NP];
   int64_t ld;
   __device__ __forceinline__ void init(const uint16_t* base, int64_t ld_, int col0, int cols, int tid) {
     const int lane = tid & 63, w = tid >> 6;
     ld = ld_;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const int p = (4 * j + w) * 64 + lane;
-      krow[j] = p >> 4;
-      const int c = col0 + (((p & 15) ^ ((krow[j] & 3) << 2)) * EPC);
+      krow[j] = p / CPR;
+      const int c = col0 + (((p % CPR) ^ ((krow[j] & 3) << 2)) * EPC);
       cvalid[j] = c + EPC <= cols;
       colp[j] = base + (cvalid[j] ? c : 0);
     }
@@ -142,7 +149,7 @@ struct TransDma {
   __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
     const int w = tid >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
       const int k = k0 + krow[j];
       const bool ok = cvalid[j] && k < kend;
       dma16(ok ? (const void*)(colp[j] + (int64_t)k * ld) : (const void*)zero, tile + (4 * j + w) * 1024);
@@ -156,19 +163,21 @@ __device__ __forceinline__ u32x4_t frag_kmajor(const unsigned char* tile, int ro
   const int cp = (((row & 1) << 3) | (2 * sub + (lane >> 5))) ^ (line & 15);
   return *(const u32x4_t*)(tile + line * 256 + cp * 16);
 }
+template <int ROWS>
 __device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row, int sub, int lane) {
+  constexpr int RS = ROWS * 2;   // bytes per k-row
   typedef __attribute__((address_space(3))) s16x4_t* lds_p;
   const int c = lane & 15;
   const int i = (row - (lane & 31)) + 16 * ((lane >> 4) & 1) + (c & 3) * 4;      // column of this lane's 4 elements
   const int k = 16 * sub + 8 * (lane >> 5) + (c >> 2);                          // k & 3 == c >> 2 for both reads
   const int slot = (i >> 3) ^ ((k & 3) << 2);
-  const unsigned char* a0 = tile + k * 256 + slot * 16 + (i & 7) * 2;
+  const unsigned char* a0 = tile + k * RS + slot * 16 + (i & 7) * 2;
   union {
     s16x4_t hh[2];
     u32x4_t v;
   } u;
   u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
-  u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * 256));
+  u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * RS));
   return u.v;
 }
 
@@ -182,10 +191,13 @@ __device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
 }
 
-template <int XMODE, int WMODE>
+template <int XMODE, int WMODE, int BM>
 __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles,
                                                          int ksplit_len, int vec_ok, const uint16_t* zero) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_BYTES];   // the ONLY LDS object
+  constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
+  constexpr int XTILE = BM * 128, WTILE = BN * 128;  // bytes
+  constexpr int STAGE = XTILE + WTILE;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // the ONLY LDS object: 2 stages
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid & 1, wn = wid >> 1;
   const int l31 = lane & 31;
@@ -205,9 +217,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p,
   const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
   const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
 
-  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma,
-                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma, KMajorDma>::type>::type;
-  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma, KMajorDma>::type;
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM>,
+                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM>, KMajorDma<BM>>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN>, KMajorDma<BN>>::type;
   XDma sx;
   WDma sw;
   if constexpr (XMODE == FFVC_OP_CONV3X3)
@@ -221,38 +233,42 @@ __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p,
   else
     sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid, 0, 0);
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[2][MT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < MT; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
   if (nk > 0) {
     sx.issue(smem, k_begin, k_end, zero, tid);
-    sw.issue(smem + TILE_BYTES, k_begin, k_end, zero, tid);
+    sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
   }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned char* cur = smem + (kt & 1) * STAGE_BYTES;
+    unsigned char* cur = smem + (kt & 1) * STAGE;
     if (kt + 1 < nk) {
-      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
       sx.issue(nxt, k_begin + (kt + 1) * BK, k_end, zero, tid);
-      sw.issue(nxt + TILE_BYTES, k_begin + (kt + 1) * BK, k_end, zero, tid);
+      sw.issue(nxt + XTILE, k_begin + (kt + 1) * BK, k_end, zero, tid);
     }
     const unsigned char* sX = cur;
-    const unsigned char* sW = cur + TILE_BYTES;
+    const unsigned char* sW = cur + XTILE;
     // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
-    u32x4_t fa[2][2], fb[2][2];
-    auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[2]) {
+    u32x4_t fa[2][2], fb[2][MT];
+    auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int rw = wn * 64 + t * 32 + l31, rx = wm * 64 + t * 32 + l31;
-        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
-        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+        const int rw = wn * 64 + t * 32 + l31;
+        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int rx = wm * (32 * MT) + t * 32 + l31;
+        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
       }
     };
     fetch(0, fa[0], fb[0]);
@@ -262,10 +278,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p,
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+        for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
     }
   }
-  ffvc_gemm_detail::gemm_epilogue<uint16_t>(p, acc, m0, n0, wm, wn, lane, zo, zi, vec_ok);
+  ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
 
 uint16_t* g_zero_page[16] = {nullptr};
@@ -282,7 +298,7 @@ const uint16_t* zero_page() {
   return g_zero_page[dev];
 }
 
-template <int XMODE, int WMODE>
+template <int XMODE, int WMODE, int BM>
 int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
   const int n_tiles = tiles_m * tiles_n;
@@ -293,14 +309,25 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   split = ceil_div(d.K, ksplit_len);
   if (split < 1) split = 1;
   dim3 grid(n_tiles, d.batch, split);
-  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE>), grid, dim3(NTHREADS), 0, st, d, tiles_n, n_tiles, ksplit_len, vec_ok,
-                     zero);
+  constexpr int lds = 2 * (BM * 128 + BN * 128);
+  static bool attr_set = false;
+  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM>), grid, dim3(NTHREADS), lds, st, d, tiles_n, n_tiles, ksplit_len,
+                     vec_ok, zero);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ffvc_set_error("gemm2 launch failed: %s", hipGetErrorString(e));
     return -(int)e - 1000;
   }
   return 1;
+}
+
+template <int XMODE, int WMODE>
+int launch2_bm(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int bm) {
+  return bm == 256 ? launch2<XMODE, WMODE, 256>(d, st, vec_ok, zero) : launch2<XMODE, WMODE, 128>(d, st, vec_ok, zero);
 }
 
 inline bool m8(int64_t v) { return (v % 8) == 0; }
@@ -310,6 +337,7 @@ inline bool m8(int64_t v) { return (v % 8) == 0; }
 // 1 = enqueued here, 0 = shape not eligible (caller falls back to gemm.hip), < 0 = launch error.
 int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.in_dtype != FFVC_BF16 || (d.flags & FFVC_F_TR_SAFE)) return 0;
+  if (!vec_ok || (d.N % 4) != 0) return 0;     // this path carries the vectorised epilogue only
   // the DMA moves whole 16-byte chunks from 16-byte aligned addresses
   if (((uintptr_t)d.x % 16) || ((uintptr_t)d.w % 16)) return 0;
   if (!m8(d.xbo) || !m8(d.xbi) || !m8(d.wbo) || !m8(d.wbi) || !m8(d.ldw)) return 0;
@@ -321,10 +349,23 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.kseg && (!m8(d.xkso) || !m8(d.wkso))) return 0;
   const uint16_t* zero = zero_page();
   if (!zero) return 0;
-  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero);
-  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero);
-  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) return launch2<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero);
-  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero);
-  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero);
+  // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | unset (heuristic)
+  static int env_bm = -1;
+  if (env_bm < 0) {
+    const char* e = getenv("FFVC_GEMM2_BM");
+    env_bm = e ? atoi(e) : 1;
+  }
+  if (env_bm == 0) return 0;
+  int bm = env_bm == 128 || env_bm == 256 ? env_bm : 0;
+  if (!bm) {
+    // 256-row tiles (128x64 per wave: 2/3 of the LDS fragment traffic per FLOP) once they still fill the chip
+    const int64_t tiles256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, BN) * d.batch * (d.split_k < 1 ? 1 : d.split_k);
+    bm = tiles256 >= 256 ? 256 : 128;
+  }
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) return launch2_bm<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
   return 0;
 }

@@ -21,95 +21,98 @@ __device__ __forceinline__ float apply_act_grad(int act, float pre) {
 }
 
 
-// Fused epilogue for a 128x128 tile owned by 4 waves (2(M) x 2(N), 64x64 each, 2x2 MFMA 32x32 tiles):
+// Fused epilogue for a (64*MT)x128 tile owned by 4 waves (2(M) x 2(N), (32*MT)x64 each, 2 x MT MFMA 32x32 tiles):
 // lane holds, per (nt, mt, q), 4 consecutive n for one m (MFMA roles swapped: A = W rows, B = X rows).
+// VEC_ONLY drops the element-wise fallback (callers guarantee vec_ok and N % 4 == 0), which keeps the fully
+// unrolled code small enough for the accumulators to stay in registers at MT = 4.
 template <typename T>
-__device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][2], int m0, int n0, int wm,
+__device__ __forceinline__ void epilogue_quad(const ffvc_gemm_desc& p, f32x4_t v, int n, int64_t yrow, int64_t rrow,
+                                              int64_t arow, int flags, bool vec) {
+  const bool out_f32 = flags & FFVC_F_OUT_F32;
+  const bool res_f32 = flags & FFVC_F_RES_F32;
+  if (vec) {
+    if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) v += *(const f32x4_t*)(p.bias + n);
+    if (flags & FFVC_F_MUL_ACT_GRAD) {
+      const f32x4_t pre = load4((const T*)p.aux + arow + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad<T>(p.act, pre[j]);
+    } else if (p.act != FFVC_ACT_NONE) {
+      if (flags & FFVC_F_WRITE_PREACT) store4((T*)p.aux + arow + n, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(p.act, v[j]);
+    }
+    if (p.residual)
+      v += res_f32 ? load4((const float*)p.residual + rrow + n) : load4((const T*)p.residual + rrow + n);
+    if (flags & FFVC_F_ATOMIC_OUT) {
+      float* yp = (float*)p.y + yrow + n;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(yp + j, v[j]);
+    } else if (flags & FFVC_F_ACCUM_OUT) {
+      float* yp = (float*)p.y + yrow + n;
+      store4(yp, load4(yp) + v);
+    } else if (out_f32) {
+      store4((float*)p.y + yrow + n, v);
+    } else {
+      store4((T*)p.y + yrow + n, v);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (n + j >= p.N) continue;
+      float u = v[j];
+      if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) u += p.bias[n + j];
+      if (flags & FFVC_F_MUL_ACT_GRAD) {
+        u *= apply_act_grad<T>(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
+      } else if (p.act != FFVC_ACT_NONE) {
+        if (flags & FFVC_F_WRITE_PREACT) ElemTraits<T>::store((T*)p.aux + arow + n + j, u);
+        u = apply_act<T>(p.act, u);
+      }
+      if (p.residual)
+        u += res_f32 ? ((const float*)p.residual)[rrow + n + j] : ElemTraits<T>::load((const T*)p.residual + rrow + n + j);
+      if (flags & FFVC_F_ATOMIC_OUT)
+        atomicAdd((float*)p.y + yrow + n + j, u);
+      else if (flags & FFVC_F_ACCUM_OUT)
+        ((float*)p.y)[yrow + n + j] += u;
+      else if (out_f32)
+        ((float*)p.y)[yrow + n + j] = u;
+      else
+        ElemTraits<T>::store((T*)p.y + yrow + n + j, u);
+    }
+  }
+}
+
+template <typename T, int MT = 2, bool VEC_ONLY = false>
+__device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0, int wm,
                                               int wn, int lane, int zo, int zi, int vec_ok) {
   const int l31 = lane & 31, h = lane >> 5;
   const int flags = p.flags;
-  const bool out_f32 = flags & FFVC_F_OUT_F32;
-  const bool res_f32 = flags & FFVC_F_RES_F32;
-  const bool atomic_out = flags & FFVC_F_ATOMIC_OUT;
-  const bool accum_out = flags & FFVC_F_ACCUM_OUT;
   const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)blockIdx.z * p.slab_stride;
   const int64_t rbz = zo * p.rbo + zi * p.rbi;
   const int64_t abz = zo * p.abo + zi * p.abi;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = m0 + wm * 64 + mt * 32 + l31;
-    if (m >= p.M) continue;
-    const int64_t yrow = ybz + (p.y_mi ? (int64_t)(m / p.y_mi) * p.y_so + (int64_t)(m % p.y_mi) * p.y_sm
-                                       : (int64_t)m * p.y_sm);
-    const int64_t rrow = rbz + (p.r_mi ? (int64_t)(m / p.r_mi) * p.r_so + (int64_t)(m % p.r_mi) * p.r_sm
-                                       : (int64_t)m * p.r_sm);
-    const int64_t arow = abz + (int64_t)m * p.ldaux;
-    const float bias_m = (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) ? p.bias[m] : 0.0f;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wm * (32 * MT) + mt * 32 + l31;
+    const bool mok = m < p.M;
+    const int mm = mok ? m : 0;
+    const int64_t yrow = ybz + (p.y_mi ? (int64_t)(mm / p.y_mi) * p.y_so + (int64_t)(mm % p.y_mi) * p.y_sm
+                                       : (int64_t)mm * p.y_sm);
+    const int64_t rrow = rbz + (p.r_mi ? (int64_t)(mm / p.r_mi) * p.r_so + (int64_t)(mm % p.r_mi) * p.r_sm
+                                       : (int64_t)mm * p.r_sm);
+    const int64_t arow = abz + (int64_t)mm * p.ldaux;
+    const float bias_m = (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) ? p.bias[mm] : 0.0f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
-        if (n >= p.N) continue;
         f32x4_t v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
-        const bool full = vec_ok && (n + 3 < p.N);
-        if (full) {
-          if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
-            const f32x4_t bv = *(const f32x4_t*)(p.bias + n);
-            v += bv;
-          }
-          if (flags & FFVC_F_MUL_ACT_GRAD) {
-            const f32x4_t pre = load4((const T*)p.aux + arow + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad<T>(p.act, pre[j]);
-          } else if (p.act != FFVC_ACT_NONE) {
-            if (flags & FFVC_F_WRITE_PREACT) store4((T*)p.aux + arow + n, v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(p.act, v[j]);
-          }
-          if (p.residual) {
-            const f32x4_t rv = res_f32 ? load4((const float*)p.residual + rrow + n)
-                                       : load4((const T*)p.residual + rrow + n);
-            v += rv;
-          }
-          if (atomic_out) {
-            float* yp = (float*)p.y + yrow + n;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(yp + j, v[j]);
-          } else if (accum_out) {
-            float* yp = (float*)p.y + yrow + n;
-            store4(yp, load4(yp) + v);
-          } else if (out_f32) {
-            store4((float*)p.y + yrow + n, v);
-          } else {
-            store4((T*)p.y + yrow + n, v);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (n + j >= p.N) continue;
-            float u = v[j];
-            if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) u += p.bias[n + j];
-            if (flags & FFVC_F_MUL_ACT_GRAD) {
-              u *= apply_act_grad<T>(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
-            } else if (p.act != FFVC_ACT_NONE) {
-              if (flags & FFVC_F_WRITE_PREACT) ElemTraits<T>::store((T*)p.aux + arow + n + j, u);
-              u = apply_act<T>(p.act, u);
-            }
-            if (p.residual)
-              u += res_f32 ? ((const float*)p.residual)[rrow + n + j]
-                           : ElemTraits<T>::load((const T*)p.residual + rrow + n + j);
-            if (atomic_out)
-              atomicAdd((float*)p.y + yrow + n + j, u);
-            else if (accum_out)
-              ((float*)p.y)[yrow + n + j] += u;
-            else if (out_f32)
-              ((float*)p.y)[yrow + n + j] = u;
-            else
-              ElemTraits<T>::store((T*)p.y + yrow + n + j, u);
-          }
+        if (mok && n < p.N) {
+          if constexpr (VEC_ONLY)
+            epilogue_quad<T>(p, v, n, yrow, rrow, arow, flags, true);
+          else
+            epilogue_quad<T>(p, v, n, yrow, rrow, arow, flags, vec_ok && (n + 3 < p.N));
         }
       }
     }
