@@ -496,6 +496,11 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
              mult((int64_t)(uintptr_t)d.aux, 16);
   if (d.bias && !(d.flags & FFVC_F_BIAS_ALONG_M)) vec_ok = vec_ok && mult((int64_t)(uintptr_t)d.bias, 16);
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int r2 = ffvc_gemm2_try(d, st, vec_ok);   // LDS-DMA fast path (bf16, 16-byte aligned operands)
+    if (r2 == 1) return 0;
+    if (r2 < 0) return r2;
+  }
   if (d.in_dtype == FFVC_BF16) return dispatch<uint16_t>(d, st, vec_ok);
   return dispatch<float>(d, st, vec_ok);
 }
