@@ -365,7 +365,12 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
-  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) return launch2_bm<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) {
+    // measured: wgrad (both operands through ds_read_b64_tr_b16) runs 745 TFLOP/s on the register-staged kernel
+    // (3 workgroups/CU) vs 551 here (2/CU) -> keep it on gemm.hip unless forced
+    if (env_bm != 128 && env_bm != 256) return 0;
+    return launch2_bm<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
+  }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
   return 0;
