@@ -571,12 +571,15 @@ extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, i
       return (int)e;
     }
   }
-  int strips = (int)((rows + 511) / 512);
-  if (strips > 512) strips = 512;
-  const int rpb = (int)((rows + strips - 1) / strips);
   const int es = dtype == FFVC_BF16 ? 2 : 4;
   const int vec = (cols % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0);
-  dim3 grid(ceil_div(cols, vec ? 256 : 64), ceil_div(rows, rpb));
+  // enough row strips that column-blocks x strips fills the chip (>= ~1024 workgroups), >= 8 rows per strip
+  const int colblocks = ceil_div(cols, vec ? 256 : 64);
+  int64_t strips = (1024 + colblocks - 1) / colblocks;
+  if (strips > rows / 8) strips = rows / 8;
+  if (strips < 1) strips = 1;
+  const int rpb = (int)((rows + strips - 1) / strips);
+  dim3 grid(colblocks, ceil_div(rows, rpb));
   DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, cols,
                                            ld, rpb, vec));
   FFVC_LAUNCH_CHECK();
