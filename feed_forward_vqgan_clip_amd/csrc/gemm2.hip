@@ -82,7 +82,6 @@ struct ConvDma {
   static constexpr int NP = ROWS / 32;
   const uint16_t* base;
   int pix[NP], oy[NP], ox[NP], kc[NP];
-  int off[NP];        // element offset of this piece's current tap pixel (+ k-chunk), -1 = halo / out of range
   bool rvalid[NP];
   int H, W, Win, Cin, ups;
   __device__ __forceinline__ void init(const uint16_t* base_, int row0, int rows, int H_, int W_, int Cin_, int ups_,
@@ -108,29 +107,19 @@ struct ConvDma {
       oy[j] = rem / W;
       ox[j] = rem - oy[j] * W;
       pix[j] = b * Hin * Win;
-      off[j] = -1;
     }
   }
-  // The K loop walks (tap, channel block): the tap geometry (halo test, source pixel) is recomputed only when the
-  // tap changes (every Cin/64 steps); in between the source just advances by 64 channels.  Offsets are 32-bit
-  // element indices (the largest decoder activation has 5.4e8 elements).
   __device__ __forceinline__ void issue(unsigned char* tile, int k0, int /*kend*/, const uint16_t* zero, int tid) {
     const int w = tid >> 6;
     const int tap = k0 / Cin;
     const int ci0 = k0 - tap * Cin;
-    if (ci0 == 0) {
-      const int kh = tap / 3, kw = tap - 3 * kh;
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
-        const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        off[j] = ok ? (pix[j] + (iy >> ups) * Win + (ix >> ups)) * Cin + kc[j] : -1;
-      }
-    }
+    const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const uint16_t* src = off[j] >= 0 ? base + (unsigned)(off[j] + ci0) : zero;
-      dma16(src, tile + (4 * j + w) * 1024);
+      const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
+      const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (4 * j + w) * 1024);
     }
   }
 };
@@ -169,35 +158,10 @@ struct TransDma {
 };
 
 // ---- fragment reads (one 16-byte chunk = 8 bf16, k = 16*sub + 8*h + e) -----------------------------------
-__device__ __forceinline__ int fragoff_kmajor(int row, int sub, int lane) {
+__device__ __forceinline__ u32x4_t frag_kmajor(const unsigned char* tile, int row, int sub, int lane) {
   const int line = row >> 1;
   const int cp = (((row & 1) << 3) | (2 * sub + (lane >> 5))) ^ (line & 15);
-  return line * 256 + cp * 16;
-}
-__device__ __forceinline__ u32x4_t frag_kmajor_at(const unsigned char* tile, int off) {
-  return *(const u32x4_t*)(tile + off);
-}
-template <int ROWS>
-__device__ __forceinline__ int fragoff_trans(int row, int sub, int lane) {
-  constexpr int RS = ROWS * 2;   // bytes per k-row
-  const int c = lane & 15;
-  const int i = (row - (lane & 31)) + 16 * ((lane >> 4) & 1) + (c & 3) * 4;
-  const int k = 16 * sub + 8 * (lane >> 5) + (c >> 2);
-  const int slot = (i >> 3) ^ ((k & 3) << 2);
-  return k * RS + slot * 16 + (i & 7) * 2;
-}
-template <int ROWS>
-__device__ __forceinline__ u32x4_t frag_trans_at(const unsigned char* tile, int off) {
-  constexpr int RS = ROWS * 2;
-  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-  const unsigned char* a0 = tile + off;
-  union {
-    s16x4_t hh[2];
-    u32x4_t v;
-  } u;
-  u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
-  u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * RS));
-  return u.v;
+  return *(const u32x4_t*)(tile + line * 256 + cp * 16);
 }
 template <int ROWS>
 __device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row, int sub, int lane) {
@@ -277,30 +241,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p,
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  // byte offsets of this lane's fragments inside the W / X tiles, per sub-step (no per-read address arithmetic)
-  int foW[2][4], foX[MT][4];
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int rw = wn * 64 + t * 32 + l31;
-      foW[t][sub] = (WMODE == FFVC_OP_TRANS) ? fragoff_trans<BN>(rw, sub, lane) : fragoff_kmajor(rw, sub, lane);
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int rx = wm * (32 * MT) + t * 32 + l31;
-      foX[t][sub] = (XMODE == FFVC_OP_TRANS) ? fragoff_trans<BM>(rx, sub, lane) : fragoff_kmajor(rx, sub, lane);
-    }
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk > 0) {
+    sx.issue(smem, k_begin, k_end, zero, tid);
+    sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
   }
-  auto compute = [&](const unsigned char* sX, const unsigned char* sW) {
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned char* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nk) {
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      sx.issue(nxt, k_begin + (kt + 1) * BK, k_end, zero, tid);
+      sw.issue(nxt + XTILE, k_begin + (kt + 1) * BK, k_end, zero, tid);
+    }
+    const unsigned char* sX = cur;
+    const unsigned char* sW = cur + XTILE;
+    // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
     u32x4_t fa[2][2], fb[2][MT];
     auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans_at<BN>(sW, foW[t][sub]) : frag_kmajor_at(sW, foW[t][sub]);
+      for (int t = 0; t < 2; ++t) {
+        const int rw = wn * 64 + t * 32 + l31;
+        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+      }
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
-        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans_at<BM>(sX, foX[t][sub]) : frag_kmajor_at(sX, foX[t][sub]);
+      for (int t = 0; t < MT; ++t) {
+        const int rx = wm * (32 * MT) + t * 32 + l31;
+        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+      }
     };
     fetch(0, fa[0], fb[0]);
 #pragma unroll
@@ -310,31 +279,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p,
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
-    }
-  };
-
-  const int nk = (k_end - k_begin + BK - 1) / BK;
-  if (nk > 0) {
-    sx.issue(smem, k_begin, k_end, zero, tid);
-    sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
-  }
-  // two K steps per trip: stage 0 then stage 1, so both ring slots are compile-time offsets from `smem`
-  for (int kt = 0; kt < nk; kt += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) {
-      sx.issue(smem + STAGE, k_begin + (kt + 1) * BK, k_end, zero, tid);
-      sw.issue(smem + STAGE + XTILE, k_begin + (kt + 1) * BK, k_end, zero, tid);
-    }
-    compute(smem, smem + XTILE);
-    if (kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 2 < nk) {
-        sx.issue(smem, k_begin + (kt + 2) * BK, k_end, zero, tid);
-        sw.issue(smem + XTILE, k_begin + (kt + 2) * BK, k_end, zero, tid);
-      }
-      compute(smem + STAGE, smem + STAGE + XTILE);
     }
   }
   ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
