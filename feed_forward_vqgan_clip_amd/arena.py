@@ -72,6 +72,9 @@ class ParamArena:
 
     # -- gradients ----------------------------------------------------------
     def zero_grad(self):
+        if self.grads.is_cuda:
+            from . import ops
+            ops.join_side_stream()
         self.grads.zero_()
         for p in self.plist:            # someone (e.g. optimizer.zero_grad(set_to_none=True)) may have dropped the views
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * self.offsets[self._index[id(p)]]:

@@ -168,6 +168,9 @@ class DistributedOptimizer:
             self._launch(b)
 
     def _launch(self, b):
+        if torch.cuda.is_available():
+            from . import ops
+            ops.join_side_stream()      # the bucket's weight gradients were written on the side stream
         s, e, _ = self.buckets[b]
         g = self.arena.grads[s:e]
         if self.wire_dtype is not None and self.wire_dtype != g.dtype:

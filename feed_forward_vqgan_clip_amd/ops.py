@@ -45,6 +45,57 @@ class Weights:
         return Weights(None, b, sh, sht)
 
 
+# ---------------------------------------------------------------------------
+# side stream for weight / bias gradients
+# ---------------------------------------------------------------------------
+# wgrad GEMMs and bias-gradient reductions are NOT on the backward critical path: their results are consumed only by
+# the gradient all-reduce / the optimizer.  They are enqueued on a second HIP stream (fenced by events) so that they
+# execute concurrently with the dgrad chain of the following layers and fill MFMA / HBM bubbles of the main stream.
+_SIDE = {"enabled": True, "stream": None, "dirty": False}
+
+
+def set_wgrad_side_stream(enabled):
+    _SIDE["enabled"] = bool(enabled)
+
+
+def _side_stream():
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    return _SIDE["stream"]
+
+
+class _on_side:
+    """Context: run the enclosed launches on the side stream after everything enqueued so far on the main stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not _SIDE["enabled"]:
+            return self
+        side = _side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:                       # keep the allocator from recycling operands still in use there
+            if t is not None:
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        _SIDE["dirty"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if _SIDE["enabled"]:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side_stream():
+    """Make the current (main) stream wait for all outstanding side-stream gradient work."""
+    if _SIDE["dirty"] and _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["dirty"] = False
+
+
 def _grad_buf(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -61,12 +112,14 @@ def _split_k(n_out, k_out, red, bk):
 def _wgrad(dy2d, x2d, W, rows, ldy=None):
     """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N)."""
     wg = _grad_buf(W.weight)
+    bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad) else None
     bk = 64 if dy2d.dtype == torch.bfloat16 else 32
     sk = _split_k(W.N, W.K, rows, bk)
-    K.gemm_splitk_accumulate(dy2d, x2d, wg, W.N, W.K, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
-                             w_mode=K.OP_TRANS)
-    if W.bias is not None and W.bias.requires_grad:
-        K.colsum(dy2d, _grad_buf(W.bias), accumulate=True, ld=ldy)
+    with _on_side(dy2d, x2d):
+        K.gemm_splitk_accumulate(dy2d, x2d, wg, W.N, W.K, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
+                                 w_mode=K.OP_TRANS)
+        if bg is not None:
+            K.colsum(dy2d, bg, accumulate=True, ld=ldy)
     if W.on_grad is not None:
         W.on_grad(W)
 
@@ -206,16 +259,18 @@ class _TokenMLPFn(Function):
             seg_ok = D % bk == 0
             for (g, a, W, n_out, k_out) in ((dyt, h, W2, T, O), (dh, xn, W1, O, T)):
                 wg = _grad_buf(W.weight)
-                if seg_ok:
-                    # dW[n,k] = sum_{b,d} g[b][n,d] a[b][k,d]: K-major GEMM over the segmented (b,d) axis
-                    sk = _split_k(n_out, k_out, B * D, bk)
-                    K.gemm_splitk_accumulate(g, a, wg, n_out, k_out, B * D, sk, ldx=D, ldw=D, kseg=D, xkso=n_out * D,
-                                             wkso=k_out * D)
-                else:
-                    for b in range(B):
-                        K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ACCUM_OUT)
-                if W.bias is not None and W.bias.requires_grad:
-                    K.rowsum(g, _grad_buf(W.bias), n_out, accumulate=True)
+                bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad) else None
+                with _on_side(g, a):
+                    if seg_ok:
+                        # dW[n,k] = sum_{b,d} g[b][n,d] a[b][k,d]: K-major GEMM over the segmented (b,d) axis
+                        sk = _split_k(n_out, k_out, B * D, bk)
+                        K.gemm_splitk_accumulate(g, a, wg, n_out, k_out, B * D, sk, ldx=D, ldw=D, kseg=D,
+                                                 xkso=n_out * D, wkso=k_out * D)
+                    else:
+                        for b in range(B):
+                            K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ACCUM_OUT)
+                    if bg is not None:
+                        K.rowsum(g, bg, n_out, accumulate=True)
                 if W.on_grad is not None:
                     W.on_grad(W)
         dx = None

@@ -10,6 +10,7 @@ import math
 import torch
 
 from . import kernels as K
+from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -38,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
     def clip_grad_norm_(self, max_norm):
         """Global-norm clipping folded into the update scale (clip_grad_norm_, main.py:833-834).
         Runs on the gradients as they are at call time (i.e. after the all-reduce in DP runs)."""
+        ops.join_side_stream()
         ss = torch.zeros(1, dtype=torch.float32, device=self.arena.grads.device)
         K.sumsq(self.arena.grads, ss)
         total = math.sqrt(float(ss.item())) * abs(self.grad_scale)
@@ -49,6 +51,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         a = self.arena
         g = self.param_groups[0]
+        ops.join_side_stream()          # weight gradients are produced on the side stream
         self._step += 1
         scale = self.grad_scale * getattr(self, "_clip_coef", 1.0)
         self._clip_coef = 1.0
