@@ -51,7 +51,7 @@ class Weights:
 # wgrad GEMMs and bias-gradient reductions are NOT on the backward critical path: their results are consumed only by
 # the gradient all-reduce / the optimizer.  They are enqueued on a second HIP stream (fenced by events) so that they
 # execute concurrently with the dgrad chain of the following layers and fill MFMA / HBM bubbles of the main stream.
-_SIDE = {"enabled": True, "stream": None, "dirty": False}
+_SIDE = {"enabled": True, "stream": None, "dirty": False, "cb": False}
 
 
 def set_wgrad_side_stream(enabled):
@@ -81,12 +81,25 @@ class _on_side:
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         _SIDE["dirty"] = True
+        if not _SIDE["cb"]:
+            # join automatically when this backward pass ends, so `p.grad` is complete (in stream order on the
+            # caller's stream) as soon as `loss.backward()` returns
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+                _SIDE["cb"] = True
+            except RuntimeError:
+                pass                                  # not inside a backward pass: callers join explicitly
         return self
 
     def __exit__(self, *exc):
         if _SIDE["enabled"]:
             self.ctx.__exit__(*exc)
         return False
+
+
+def _end_of_backward():
+    _SIDE["cb"] = False
+    join_side_stream()
 
 
 def join_side_stream():
