@@ -225,9 +225,18 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         name, (n, flops, secs) = dom
         peak = PEAK_BF16_TFLOPS if name.endswith("bf16") else 157.3
+        traffic, traffic_src = None, None
+        try:     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if name in pmc:
+                traffic, traffic_src = pmc[name]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": name, "launches_per_step": n,
                            "avg_launch_ms": secs / n * 1e3, "achieved": flops / secs / 1e12, "peak": peak,
-                           "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": None}
+                           "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                           "traffic_source": traffic_src, "flop_per_launch": flops / n}
         out["kernel_classes"] = {k: {"launches": v[0], "ms": v[2] * 1e3, "tflops": v[1] / max(v[2], 1e-12) / 1e12}
                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
         out["gemm_ms_per_step"] = sum(v[2] for v in agg.values()) * 1e3
