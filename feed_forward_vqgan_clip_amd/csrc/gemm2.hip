@@ -44,34 +44,47 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_b
 template <int ROWS>
 struct KMajorDma {
   static constexpr int NP = ROWS / 32;
-  const uint16_t* rowp[NP];
-  int kc[NP];        // element offset of this lane's k-chunk inside the K step
-  bool rvalid[NP];
-  int kseg;
-  int64_t kso;
-  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int row0, int rows, int kseg_, int64_t kso_,
-                                       int tid, int mi, int64_t so) {
+  // position p = (4j + w) * 64 + lane  ->  line = p >> 4 = 16 j + 4 w + (lane >> 4), so (line & 15) and therefore the
+  // source k-chunk are the SAME for every piece j, and the source row advances by exactly 32 per piece: the whole
+  // per-thread state is one row pointer, the k-chunk offset and the first row index.
+  const uint16_t* row0p;   // pointer to (first row, k = 0)
+  int64_t step;            // elements between piece j and j + 1 (32 rows), when the row map is linear
+  int r0, rows, kc;
+  int kseg, mi;
+  int64_t kso, ld, so;
+  const uint16_t* base;
+  __device__ __forceinline__ void init(const uint16_t* base_, int64_t ld_, int row0, int rows_, int kseg_, int64_t kso_,
+                                       int tid, int mi_, int64_t so_) {
     const int lane = tid & 63, w = tid >> 6;
+    const int line = 4 * w + (lane >> 4);
+    const int cp = (lane & 15) ^ (line & 15);
+    r0 = row0 + 2 * line + (cp >> 3);
+    kc = (cp & 7) * EPC;
+    rows = rows_;
     kseg = kseg_;
     kso = kso_;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int p = (4 * j + w) * 64 + lane;
-      const int line = p >> 4, cp = (p & 15) ^ (line & 15);
-      const int r = row0 + 2 * line + (cp >> 3);
-      kc[j] = (cp & 7) * EPC;
-      rvalid[j] = r < rows;
-      const int rr = rvalid[j] ? r : 0;
-      rowp[j] = base + (mi ? (int64_t)(rr / mi) * so + (int64_t)(rr % mi) * ld : (int64_t)rr * ld);
-    }
+    ld = ld_;
+    mi = mi_;
+    so = so_;
+    base = base_;
+    step = 32 * ld_;
+    const int rr = r0 < rows ? r0 : 0;
+    row0p = base + (int64_t)rr * ld_;
   }
   __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
     const int w = tid >> 6;
-    const int64_t kbase = kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0;
+    const int64_t koff = (kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0) + kc;
+    const bool kok = k0 + kc + EPC <= kend;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const bool ok = rvalid[j] && (k0 + kc[j] + EPC <= kend);
-      dma16(ok ? (const void*)(rowp[j] + kbase + kc[j]) : (const void*)zero, tile + (4 * j + w) * 1024);
+      const int r = r0 + 32 * j;
+      const bool ok = kok && r < rows;
+      const uint16_t* src;
+      if (mi)
+        src = base + (int64_t)(r / mi) * so + (int64_t)(r % mi) * ld + koff;
+      else
+        src = row0p + j * step + koff;
+      dma16(ok ? (const void*)src : (const void*)zero, tile + (4 * j + w) * 1024);
     }
   }
 };
@@ -191,9 +204,13 @@ __device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
 }
 
+// BM = 128: 2-stage ring (DMA of tile t+1 under the MFMAs of tile t), 2 workgroups / CU.
+// BM = 256: ONE stage (48 KiB) and <= 256 registers so that 2 workgroups (2 waves / SIMD) share a CU and alternate:
+//           one streams its next tile while the other runs its 128 MFMAs per K step (128x64 per wave).
 template <int XMODE, int WMODE, int BM>
-__global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles,
-                                                         int ksplit_len, int vec_ok, const uint16_t* zero) {
+__global__ __launch_bounds__(NTHREADS, (BM == 256 ? 2 : 1)) void gemm2_kernel(const ffvc_gemm_desc p, int tiles_n,
+                                                                               int n_tiles, int ksplit_len, int vec_ok,
+                                                                               const uint16_t* zero) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
   constexpr int XTILE = BM * 128, WTILE = BN * 128;  // bytes
   constexpr int STAGE = XTILE + WTILE;
@@ -242,43 +259,77 @@ __global__ __launch_bounds__(NTHREADS) void gemm2_kernel(const ffvc_gemm_desc p,
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
-  if (nk > 0) {
-    sx.issue(smem, k_begin, k_end, zero, tid);
-    sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned char* cur = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk) {
-      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
-      sx.issue(nxt, k_begin + (kt + 1) * BK, k_end, zero, tid);
-      sw.issue(nxt + XTILE, k_begin + (kt + 1) * BK, k_end, zero, tid);
+  auto compute = [&](const unsigned char* sX, const unsigned char* sW) {
+    if constexpr (BM == 256) {
+      // one fragment set (register budget): the partner workgroup covers the LDS latency
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        u32x4_t fa[2], fb[MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rw = wn * 64 + t * 32 + l31;
+          fa[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int rx = wm * (32 * MT) + t * 32 + l31;
+          fb[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[a], fb[b]);
+      }
+    } else {
+      // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
+      u32x4_t fa[2][2], fb[2][MT];
+      auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rw = wn * 64 + t * 32 + l31;
+          a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int rx = wm * (32 * MT) + t * 32 + l31;
+          b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+        }
+      };
+      fetch(0, fa[0], fb[0]);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        if (sub < 3) fetch(sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+      }
     }
-    const unsigned char* sX = cur;
-    const unsigned char* sW = cur + XTILE;
-    // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
-    u32x4_t fa[2][2], fb[2][MT];
-    auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int rw = wn * 64 + t * 32 + l31;
-        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+  };
+  if constexpr (BM == 256) {
+    for (int kt = 0; kt < nk; ++kt) {
+      sx.issue(smem, k_begin + kt * BK, k_end, zero, tid);
+      sw.issue(smem + XTILE, k_begin + kt * BK, k_end, zero, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(smem, smem + XTILE);
+      __syncthreads();
+    }
+  } else {
+    if (nk > 0) {
+      sx.issue(smem, k_begin, k_end, zero, tid);
+      sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      unsigned char* cur = smem + (kt & 1) * STAGE;
+      if (kt + 1 < nk) {
+        unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
+        sx.issue(nxt, k_begin + (kt + 1) * BK, k_end, zero, tid);
+        sw.issue(nxt + XTILE, k_begin + (kt + 1) * BK, k_end, zero, tid);
       }
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int rx = wm * (32 * MT) + t * 32 + l31;
-        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
-      }
-    };
-    fetch(0, fa[0], fb[0]);
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      if (sub < 3) fetch(sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+      compute(cur, cur + XTILE);
     }
   }
   ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
@@ -309,7 +360,7 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   split = ceil_div(d.K, ksplit_len);
   if (split < 1) split = 1;
   dim3 grid(n_tiles, d.batch, split);
-  constexpr int lds = 2 * (BM * 128 + BN * 128);
+  constexpr int lds = (BM == 256 ? 1 : 2) * (BM * 128 + BN * 128);
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
