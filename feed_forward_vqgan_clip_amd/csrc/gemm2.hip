@@ -410,9 +410,14 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   int bm = env_bm == 128 || env_bm == 256 ? env_bm : 0;
   if (!bm) {
     // 256-row tiles (128x64 per wave: 2/3 of the LDS fragment traffic per FLOP) once they still fill the chip
-    // measured (profiles/r01): with one wave per SIMD the 256-row variant stalls on its per-K-step wait+barrier and
-    // loses to the 128x128 tile (2-3 waves per SIMD) on every hot-path shape -> only reachable through the env switch
-    bm = 128;
+    // Both variants hold 2 workgroups per CU (512 slots).  The 256-row tile (128x64 per wave) needs 25 % less LDS
+    // fragment traffic and 25 % less DMA per FLOP and measures 5-10 % faster when the grid fills whole waves of
+    // slots; otherwise the finer 128-row tiles win on tail effects (profiles/r01_gemm_tile_ab.txt).
+    const int64_t zmul = (int64_t)d.batch * (d.split_k < 1 ? 1 : d.split_k);
+    const int64_t t256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, BN) * zmul;
+    const int64_t t128 = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, BN) * zmul;
+    auto eff = [](int64_t t) { return (double)t / (double)(((t + 511) / 512) * 512); };
+    bm = (t256 >= 256 && eff(t256) * 1.07 >= eff(t128)) ? 256 : 128;
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
