@@ -787,28 +787,15 @@ extern "C" int ffvc_groupnorm_fwd(const void* x, void* y, const float* gamma, co
   FFVC_CHECK_ARG(x && y && gamma && beta && mean && rstd && ws, "ffvc_groupnorm_fwd: null pointer");
   if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_fwd")) return e;
   hipStream_t st = (hipStream_t)stream;
-  // Two passes over x: run them per sub-batch of images small enough that the second pass is served by the
-  // 256 MiB Infinity Cache instead of HBM.
-  const int es = dtype == FFVC_BF16 ? 2 : 4;
-  const int64_t per_img = (int64_t)HW * C * es;
-  int bc = (int)((int64_t)(96 << 20) / (per_img > 0 ? per_img : 1));
-  if (bc < 1) bc = 1;
-  if (bc > B) bc = B;
-  for (int b0 = 0; b0 < B; b0 += bc) {
-    const int nb = B - b0 < bc ? B - b0 : bc;
-    int rpc;
-    const int nch = gn_chunks(nb, HW, &rpc);
-    const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
-    const int nblk = (HW + rpb - 1) / rpb;
-    const int64_t off = (int64_t)b0 * HW * C;
-    DISPATCH_DT(dtype, T, {
-      hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nch, nb), dim3(256), 0, st, (const T*)x + off, (double*)ws, HW, C, G,
-                         rpc);
-      hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, nb), dim3(256), 0, st, (const T*)x + off, (T*)y + off, gamma,
-                         beta, (const double*)ws, mean + (int64_t)b0 * G, rstd + (int64_t)b0 * G, HW, C, G, nch, eps,
-                         swish, rpb);
-    });
-  }
+  int rpc;
+  const int nch = gn_chunks(B, HW, &rpc);
+  const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)x, (double*)ws, HW, C, G, rpc);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta,
+                       (const double*)ws, mean, rstd, HW, C, G, nch, eps, swish, rpb);
+  });
   FFVC_LAUNCH_CHECK();
   return 0;
 }
@@ -819,28 +806,16 @@ extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* ga
   FFVC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && ws, "ffvc_groupnorm_bwd: null pointer");
   if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_bwd")) return e;
   hipStream_t st = (hipStream_t)stream;
-  const int es = dtype == FFVC_BF16 ? 2 : 4;
-  const int64_t per_img = (int64_t)HW * C * es * 2;      // dy and x are both read twice
-  int bc = (int)((int64_t)(128 << 20) / (per_img > 0 ? per_img : 1));
-  if (bc < 1) bc = 1;
-  if (bc > B) bc = B;
-  for (int b0 = 0; b0 < B; b0 += bc) {
-    const int nb = B - b0 < bc ? B - b0 : bc;
-    int rpc;
-    const int nch = gn_chunks(nb, HW, &rpc);
-    const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
-    const int nblk = (HW + rpb - 1) / rpb;
-    const int64_t off = (int64_t)b0 * HW * C;
-    const float* mu = mean + (int64_t)b0 * G;
-    const float* rs = rstd + (int64_t)b0 * G;
-    DISPATCH_DT(dtype, T, {
-      hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, nb), dim3(256), 0, st, (const T*)dy + off, (const T*)x + off,
-                         gamma, beta, mu, rs, (double*)ws, HW, C, G, swish, rpc);
-      hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, nb), dim3(256), 0, st, (const T*)dy + off, (const T*)x + off,
-                         gamma, beta, mu, rs, (const double*)ws, dres ? (const T*)dres + off : (const T*)nullptr,
-                         (T*)dx + off, HW, C, G, nch, swish, rpb);
-    });
-  }
+  int rpc;
+  const int nch = gn_chunks(B, HW, &rpc);
+  const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                       beta, mean, rstd, (double*)ws, HW, C, G, swish, rpc);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                       beta, mean, rstd, (const double*)ws, (const T*)dres, (T*)dx, HW, C, G, nch, swish, rpb);
+  });
   FFVC_LAUNCH_CHECK();
   return 0;
 }
