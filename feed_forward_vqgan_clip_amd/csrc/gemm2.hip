@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int BN = 128, BK = 64, NTHREADS = 256;
+constexpr int BK = 64;
 constexpr int EPC = 8;                         // bf16 per 16-byte chunk
 // An operand tile of ROWS rows is ROWS x 128 B (K-major) == 64 x (2*ROWS) B (reduction-major): ROWS/32 DMA pieces
 // per thread per K step.  The W tile is always 128 rows; the X tile 128 or 256 (block tile BM x 128).
@@ -41,9 +41,9 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_b
 // ---- K-major operand: 4 DMA pieces per thread per K step ------------------------------------------------
 // piece j of wave w covers LDS chunk positions p = (4j + w) * 64 + lane; line = p >> 4, slot = p & 15,
 // source chunk c' = slot ^ (line & 15): row = 2 * line + (c' >> 3), k-chunk = c' & 7.
-template <int ROWS>
+template <int ROWS, int NW>
 struct KMajorDma {
-  static constexpr int NP = ROWS / 32;
+  static constexpr int NP = ROWS / (8 * NW);   // 1-KiB DMA pieces per thread per K step
   // position p = (4j + w) * 64 + lane  ->  line = p >> 4 = 16 j + 4 w + (lane >> 4), so (line & 15) and therefore the
   // source k-chunk are the SAME for every piece j, and the source row advances by exactly 32 per piece: the whole
   // per-thread state is one row pointer, the k-chunk offset and the first row index.
@@ -56,7 +56,7 @@ struct KMajorDma {
   __device__ __forceinline__ void init(const uint16_t* base_, int64_t ld_, int row0, int rows_, int kseg_, int64_t kso_,
                                        int tid, int mi_, int64_t so_) {
     const int lane = tid & 63, w = tid >> 6;
-    const int line = 4 * w + (lane >> 4);
+    const int line = 4 * w + (lane >> 4);        // + 4*NW per piece: (line & 15) is piece-independent (4*NW % 16 == 0)
     const int cp = (lane & 15) ^ (line & 15);
     r0 = row0 + 2 * line + (cp >> 3);
     kc = (cp & 7) * EPC;
@@ -67,7 +67,7 @@ struct KMajorDma {
     mi = mi_;
     so = so_;
     base = base_;
-    step = 32 * ld_;
+    step = (8 * NW) * ld_;
     const int rr = r0 < rows ? r0 : 0;
     row0p = base + (int64_t)rr * ld_;
   }
@@ -77,22 +77,22 @@ struct KMajorDma {
     const bool kok = k0 + kc + EPC <= kend;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int r = r0 + 32 * j;
+      const int r = r0 + (8 * NW) * j;
       const bool ok = kok && r < rows;
       const uint16_t* src;
       if (mi)
         src = base + (int64_t)(r / mi) * so + (int64_t)(r % mi) * ld + koff;
       else
         src = row0p + j * step + koff;
-      dma16(ok ? (const void*)src : (const void*)zero, tile + (4 * j + w) * 1024);
+      dma16(ok ? (const void*)src : (const void*)zero, tile + (NW * j + w) * 1024);
     }
   }
 };
 
 // ---- implicit im2col (3x3, pad 1, optional fused nearest 2x upsample) ------------------------------------
-template <int ROWS>
+template <int ROWS, int NW>
 struct ConvDma {
-  static constexpr int NP = ROWS / 32;
+  static constexpr int NP = ROWS / (8 * NW);
   const uint16_t* base;
   int pix[NP], oy[NP], ox[NP], kc[NP];
   bool rvalid[NP];
@@ -109,7 +109,7 @@ struct ConvDma {
     const int Hin = H_ >> ups_;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int p = (4 * j + w) * 64 + lane;
+      const int p = (NW * j + w) * 64 + lane;
       const int line = p >> 4, cp = (p & 15) ^ (line & 15);
       const int r = row0 + 2 * line + (cp >> 3);
       kc[j] = (cp & 7) * EPC;
@@ -132,16 +132,16 @@ struct ConvDma {
       const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
       const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
-      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (4 * j + w) * 1024);
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (NW * j + w) * 1024);
     }
   }
 };
 
 // ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
 // source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
-template <int ROWS>
+template <int ROWS, int NW>
 struct TransDma {
-  static constexpr int NP = ROWS / 32;
+  static constexpr int NP = ROWS / (8 * NW);
   static constexpr int CPR = ROWS / 8;      // 16-byte chunks per k-row
   const uint16_t* colp[NP];
   int krow[NP];
@@ -152,7 +152,7 @@ struct TransDma {
     ld = ld_;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int p = (4 * j + w) * 64 + lane;
+      const int p = (NW * j + w) * 64 + lane;
       krow[j] = p / CPR;
       const int c = col0 + (((p % CPR) ^ ((krow[j] & 3) << 2)) * EPC);
       cvalid[j] = c + EPC <= cols;
@@ -165,7 +165,7 @@ struct TransDma {
     for (int j = 0; j < NP; ++j) {
       const int k = k0 + krow[j];
       const bool ok = cvalid[j] && k < kend;
-      dma16(ok ? (const void*)(colp[j] + (int64_t)k * ld) : (const void*)zero, tile + (4 * j + w) * 1024);
+      dma16(ok ? (const void*)(colp[j] + (int64_t)k * ld) : (const void*)zero, tile + (NW * j + w) * 1024);
     }
   }
 };
@@ -204,17 +204,20 @@ __device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
 }
 
-// BM = 128: 2-stage ring (DMA of tile t+1 under the MFMAs of tile t), 2 workgroups / CU.
-// BM = 256: ONE stage (48 KiB) and <= 256 registers so that 2 workgroups (2 waves / SIMD) share a CU and alternate:
-//           one streams its next tile while the other runs its 128 MFMAs per K step (128x64 per wave).
-template <int XMODE, int WMODE, int BM>
-__global__ __launch_bounds__(NTHREADS, (BM == 256 ? 2 : 1)) void gemm2_kernel(const ffvc_gemm_desc p, int tiles_n,
-                                                                               int n_tiles, int ksplit_len, int vec_ok,
-                                                                               const uint16_t* zero) {
+// Tile configurations (BM x BN, waves as 2(M) x BN/64(N), wave tile (BM/2) x 64):
+//   128x128: 4 waves x 64x64,  2-stage ring (64 KiB),  2 workgroups / CU            -- small / ragged grids
+//   256x128: 4 waves x 128x64, ONE stage (48 KiB), <=256 regs, 2 workgroups / CU alternate load / MFMA
+//   256x256: 8 waves x 128x64, 2-stage ring (128 KiB), <=256 regs, 1 workgroup / CU = 2 waves / SIMD; 128 FLOP per
+//            L2 byte, the only shape that is not capped by the ~53 B/clk a CU can pull from L2.
+template <int XMODE, int WMODE, int BM, int BN>
+__global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2_kernel(
+    const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
+  constexpr int NW = 2 * (BN / 64);                  // waves per workgroup
   constexpr int XTILE = BM * 128, WTILE = BN * 128;  // bytes
   constexpr int STAGE = XTILE + WTILE;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // the ONLY LDS object: 2 stages
+  constexpr bool RING = !(BM == 256 && BN == 128);   // 2-stage ring except for the single-stage 256x128 variant
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid & 1, wn = wid >> 1;
   const int l31 = lane & 31;
@@ -234,9 +237,9 @@ __global__ __launch_bounds__(NTHREADS, (BM == 256 ? 2 : 1)) void gemm2_kernel(co
   const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
   const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
 
-  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM>,
-                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM>, KMajorDma<BM>>::type>::type;
-  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN>, KMajorDma<BN>>::type;
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM, NW>,
+                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM, NW>, KMajorDma<BM, NW>>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN, NW>, KMajorDma<BN, NW>>::type;
   XDma sx;
   WDma sw;
   if constexpr (XMODE == FFVC_OP_CONV3X3)
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS, (BM == 256 ? 2 : 1)) void gemm2_kernel(co
   const int nk = (k_end - k_begin + BK - 1) / BK;
   auto compute = [&](const unsigned char* sX, const unsigned char* sW) {
     if constexpr (BM == 256) {
-      // one fragment set (register budget): the partner workgroup covers the LDS latency
+      // one fragment set (register budget): the partner wave on the SIMD covers the LDS latency
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         u32x4_t fa[2], fb[MT];
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(NTHREADS, (BM == 256 ? 2 : 1)) void gemm2_kernel(co
       }
     }
   };
-  if constexpr (BM == 256) {
+  if constexpr (!RING) {
     for (int kt = 0; kt < nk; ++kt) {
       sx.issue(smem, k_begin + kt * BK, k_end, zero, tid);
       sw.issue(smem + XTILE, k_begin + kt * BK, k_end, zero, tid);
@@ -349,7 +352,7 @@ const uint16_t* zero_page() {
   return g_zero_page[dev];
 }
 
-template <int XMODE, int WMODE, int BM>
+template <int XMODE, int WMODE, int BM, int BN>
 int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
   const int n_tiles = tiles_m * tiles_n;
@@ -360,13 +363,14 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   split = ceil_div(d.K, ksplit_len);
   if (split < 1) split = 1;
   dim3 grid(n_tiles, d.batch, split);
-  constexpr int lds = (BM == 256 ? 1 : 2) * (BM * 128 + BN * 128);
+  constexpr int nthreads = 64 * 2 * (BN / 64);
+  constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128);
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM>), grid, dim3(NTHREADS), lds, st, d, tiles_n, n_tiles, ksplit_len,
+  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
                      vec_ok, zero);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -376,9 +380,12 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   return 1;
 }
 
+// cfg: 128 -> 128x128, 256 -> 256x128, 512 -> 256x256
 template <int XMODE, int WMODE>
-int launch2_bm(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int bm) {
-  return bm == 256 ? launch2<XMODE, WMODE, 256>(d, st, vec_ok, zero) : launch2<XMODE, WMODE, 128>(d, st, vec_ok, zero);
+int launch2_cfg(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg) {
+  if (cfg == 512) return launch2<XMODE, WMODE, 256, 256>(d, st, vec_ok, zero);
+  if (cfg == 256) return launch2<XMODE, WMODE, 256, 128>(d, st, vec_ok, zero);
+  return launch2<XMODE, WMODE, 128, 128>(d, st, vec_ok, zero);
 }
 
 inline bool m8(int64_t v) { return (v % 8) == 0; }
@@ -400,34 +407,36 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.kseg && (!m8(d.xkso) || !m8(d.wkso))) return 0;
   const uint16_t* zero = zero_page();
   if (!zero) return 0;
-  // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | unset (heuristic)
+  // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
   static int env_bm = -1;
   if (env_bm < 0) {
     const char* e = getenv("FFVC_GEMM2_BM");
     env_bm = e ? atoi(e) : 1;
   }
   if (env_bm == 0) return 0;
-  int bm = env_bm == 128 || env_bm == 256 ? env_bm : 0;
-  if (!bm) {
-    // 256-row tiles (128x64 per wave: 2/3 of the LDS fragment traffic per FLOP) once they still fill the chip
-    // Both variants hold 2 workgroups per CU (512 slots).  The 256-row tile (128x64 per wave) needs 25 % less LDS
-    // fragment traffic and 25 % less DMA per FLOP and measures 5-10 % faster when the grid fills whole waves of
-    // slots; otherwise the finer 128-row tiles win on tail effects (profiles/r01_gemm_tile_ab.txt).
+  int cfg = (env_bm == 128 || env_bm == 256 || env_bm == 512) ? env_bm : 0;
+  if (!cfg) {
+    // Every variant occupies a CU with 8 waves; what differs is FLOP per L2 byte (64 / 85 / 128) and grid granularity.
+    // Pick the largest tile whose grid still fills whole rounds of workgroup slots (profiles/r01_gemm_tile_ab.txt).
     const int64_t zmul = (int64_t)d.batch * (d.split_k < 1 ? 1 : d.split_k);
-    const int64_t t256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, BN) * zmul;
-    const int64_t t128 = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, BN) * zmul;
-    auto eff = [](int64_t t) { return (double)t / (double)(((t + 511) / 512) * 512); };
-    bm = (t256 >= 256 && eff(t256) * 1.07 >= eff(t128)) ? 256 : 128;
+    const int64_t t512 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 256) * zmul;
+    const int64_t t256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 128) * zmul;
+    const int64_t t128 = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * zmul;
+    auto eff = [](int64_t t, int slots) { return (double)t / (double)(((t + slots - 1) / slots) * slots); };
+    const double e512 = (d.N >= 256 && t512 >= 192) ? eff(t512, 256) * 1.25 : 0.0;
+    const double e256 = t256 >= 256 ? eff(t256, 512) * 1.07 : 0.0;
+    const double e128 = eff(t128, 512);
+    cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
   }
-  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
-  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
+  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) {
     // measured: wgrad (both operands through ds_read_b64_tr_b16) runs 745 TFLOP/s on the register-staged kernel
-    // (3 workgroups/CU) vs 551 here (2/CU) -> keep it on gemm.hip unless forced
-    if (env_bm != 128 && env_bm != 256) return 0;
-    return launch2_bm<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
+    // (3 workgroups/CU) vs 551 on the 128x128 DMA tile -> keep it on gemm.hip unless forced
+    if (env_bm != 128 && env_bm != 256 && env_bm != 512) return 0;
+    return launch2_cfg<FFVC_OP_TRANS, FFVC_OP_TRANS>(d, st, vec_ok, zero, cfg);
   }
-  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2_bm<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero, bm);
-  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2_bm<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, bm);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2_cfg<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero, cfg);
+  if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
   return 0;
 }
