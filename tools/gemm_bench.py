@@ -47,12 +47,13 @@ def main():
         t = timeit(lambda: K.gemm(x, w, y, M, N, Kd, ldx=Kd, ldw=Kd))
         rows.append((f"NT {M}x{N}x{Kd}", 2.0 * M * N * Kd / t / 1e12, t * 1e3))
     # TN wgrad with split-K
-    for (M, N, Kd, sk) in [(4096, 1024, 16384, 1), (4096, 1024, 16384, 4), (1024, 256, 65536, 16)]:
+    for (M, N, Kd, sk) in [(4096, 1024, 16384, 1), (4096, 1024, 16384, 3), (1024, 4096, 16384, 3), (4096, 1024, 16384, 2),
+                           (2304, 768, 25600, 4)]:
         xt, wt = r(Kd, M), r(Kd, N)
         y = torch.zeros(M, N, device=dev, dtype=torch.float32)
-        t = timeit(lambda: K.gemm(xt, wt, y, M, N, Kd, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS,
-                                  flags=K.F_ATOMIC_OUT, split_k=sk))
-        rows.append((f"TN {M}x{N}x{Kd} sk{sk}", 2.0 * M * N * Kd / t / 1e12, t * 1e3))
+        t = timeit(lambda: K.gemm_splitk_accumulate(xt, wt, y, M, N, Kd, sk, ldx=M, ldw=N, x_mode=K.OP_TRANS,
+                                                    w_mode=K.OP_TRANS))
+        rows.append((f"TN {M}x{N}x{Kd} slab-sk{sk}", 2.0 * M * N * Kd / t / 1e12, t * 1e3))
     # batched NN token mix: out[b][o,d] = W[o,t] xn[b][t,d]
     B, T, D, O = 64, 256, 1024, 1024
     Wm, xn = r(O, T), r(B, T, D)
