@@ -126,6 +126,7 @@ _SIGNATURES = {
     "ffvc_slab_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ffvc_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ffvc_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ffvc_set_option": (c_int, [c_char_p, c_int]),
     "ffvc_last_error": (c_char_p, []),
     "ffvc_version": (c_int, []),
     "ffvc_device_info": (c_int, [POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),

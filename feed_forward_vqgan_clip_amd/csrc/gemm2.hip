@@ -137,6 +137,54 @@ struct ConvDma {
   }
 };
 
+// ---- 3x3 conv, haloed row tile ----------------------------------------------------------------------------
+// When 256 % W == 0 a 256-pixel output tile is R = 256/W whole image rows.  For one kernel row kh and one
+// 64-channel block the LDS tile holds those R input rows WITH a one-pixel halo on both sides:
+//     tile_row = seg * (W + 2) + (ix + 1),   ix = -1 .. W,   seg = 0 .. R-1        (<= 264 rows of 128 B)
+// and serves the three kw taps by fragment reads shifted by kw rows: the activation is fetched from L2 3x per
+// (kh, channel block) less often than with the generic im2col loader (9 taps -> 3 row loads).
+struct ConvRowDma {
+  static constexpr int NP = 9;      // ceil(264 * 8 / 256) 1-KiB pieces per thread
+  const uint16_t* base;
+  int rowinfo[NP];                  // (seg << 16) | (ix + 1), or -1 when the position is beyond the tile
+  int kc;
+  int H, W, Win, Hin, Cin, ups, img, oy0;
+  __device__ __forceinline__ void init(const uint16_t* base_, int m0, int H_, int W_, int Cin_, int ups_, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    base = base_;
+    H = H_;
+    W = W_;
+    Cin = Cin_;
+    ups = ups_;
+    Win = W_ >> ups_;
+    Hin = H_ >> ups_;
+    img = m0 / (H * W);
+    oy0 = (m0 - img * (H * W)) / W;
+    const int line = 4 * w + (lane >> 4);
+    const int cp = (lane & 15) ^ (line & 15);
+    kc = (cp & 7) * EPC;
+    const int r0 = 2 * line + (cp >> 3);
+    const int tr = (256 / W) * (W + 2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int r = r0 + 32 * j;
+      rowinfo[j] = r < tr ? (((r / (W + 2)) << 16) | (r % (W + 2))) : -1;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int kh, int ci0, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      if (rowinfo[j] < 0) continue;                      // exec-masked lanes simply do not write
+      const int seg = rowinfo[j] >> 16, ix = (rowinfo[j] & 0xffff) - 1;
+      const int iy = oy0 + seg + kh - 1;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int64_t off = ((int64_t)((img * Hin + (iy >> ups)) * Win + (ix >> ups))) * Cin + ci0 + kc;
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (4 * j + w) * 1024);
+    }
+  }
+};
+
 // ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
 // source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
 template <int ROWS, int NW>
@@ -338,7 +386,89 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
 
+// 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
+// (X 33 KiB + W 16 KiB) so that two workgroups share a CU and alternate DMA / MFMA phases.
+// K order: kh (3) x 64-channel block (Cin/64) x kw (3); the X tile is (re)loaded only when (kh, block) changes.
+__global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
+                                                          const uint16_t* zero) {
+  constexpr int MT = 4, BM = 256, BN = 128;
+  constexpr int XTILE = 264 * 128, WTILE = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int W = p.conv_W, Cin = p.conv_Cin;
+  ConvRowDma sx;
+  KMajorDma<BN, 4> sw;
+  sx.init((const uint16_t*)p.x, m0, p.conv_H, W, Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  sw.init((const uint16_t*)p.w, p.ldw, n0, p.N, 0, 0, tid, 0, 0);
+
+  f32x16_t acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  // LDS row of this lane's pixel for tap kw = 0 (add kw for the others)
+  int xrow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int px = wm * 128 + t * 32 + l31;
+    xrow[t] = (px / W) * (W + 2) + (px % W);
+  }
+  unsigned char* sX = smem;
+  unsigned char* sW = smem + XTILE;
+  const int nblk = Cin / 64;
+  for (int kh = 0; kh < 3; ++kh) {
+    for (int cb = 0; cb < nblk; ++cb) {
+#pragma unroll 1
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kw == 0) sx.issue(sX, kh, cb * 64, zero, tid);
+        sw.issue(sW, (kh * 3 + kw) * Cin + cb * 64, p.K, zero, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          u32x4_t fa[2], fb[MT];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) fa[t] = frag_kmajor(sW, wn * 64 + t * 32 + l31, sub, lane);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) fb[t] = frag_kmajor(sX, xrow[t] + kw, sub, lane);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[a], fb[b]);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+}
+
 uint16_t* g_zero_page[16] = {nullptr};
+
+// run-time options (ffvc_set_option); -1 = not initialised (take the environment variable, else the default)
+int g_opt_gemm2_tile = -1;   // FFVC_GEMM2_BM: 0 off | 1 heuristic | 128 | 256 | 512 (= 256x256)
+int g_opt_conv_row = -1;     // FFVC_CONV_ROW: 0 off | 1 heuristic | 2 force whenever the geometry allows
+
+int opt_value(int& slot, const char* env, int dflt) {
+  if (slot < 0) {
+    const char* e = getenv(env);
+    slot = e ? atoi(e) : dflt;
+  }
+  return slot;
+}
 
 const uint16_t* zero_page() {
   int dev = 0;
@@ -408,11 +538,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   const uint16_t* zero = zero_page();
   if (!zero) return 0;
   // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
-  static int env_bm = -1;
-  if (env_bm < 0) {
-    const char* e = getenv("FFVC_GEMM2_BM");
-    env_bm = e ? atoi(e) : 1;
-  }
+  const int env_bm = opt_value(g_opt_gemm2_tile, "FFVC_GEMM2_BM", 1);
   if (env_bm == 0) return 0;
   int cfg = (env_bm == 128 || env_bm == 256 || env_bm == 512) ? env_bm : 0;
   if (!cfg) {
@@ -429,7 +555,30 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
-  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
+  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) {
+    const int env_row = opt_value(g_opt_conv_row, "FFVC_CONV_ROW", 1);
+    const int W = d.conv_W;
+    const bool geom_ok = (W == 64 || W == 128 || W == 256) && ((int64_t)d.conv_H * W) % 256 == 0 && d.batch == 1 &&
+                         d.split_k <= 1 && (d.N % 128) == 0 && (d.M % 256) == 0;
+    const bool fills = (int64_t)(d.M / 256) * (d.N / 128) >= 256;
+    if (geom_ok && (env_row == 2 || (env_row == 1 && fills && cfg != 512))) {
+      const int tiles_n = d.N / 128, n_tiles = (d.M / 256) * tiles_n;
+      constexpr int lds = 264 * 128 + 128 * 128;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+      }
+      hipLaunchKernelGGL(conv_row_kernel, dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        ffvc_set_error("conv_row launch failed: %s", hipGetErrorString(e));
+        return -(int)e - 1000;
+      }
+      return 1;
+    }
+    return launch2_cfg<FFVC_OP_CONV3X3, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
+  }
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) {
     // measured: wgrad (both operands through ds_read_b64_tr_b16) runs 745 TFLOP/s on the register-staged kernel
     // (3 workgroups/CU) vs 551 on the 128x128 DMA tile -> keep it on gemm.hip unless forced
@@ -439,4 +588,18 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return launch2_cfg<FFVC_OP_KMAJOR, FFVC_OP_TRANS>(d, st, vec_ok, zero, cfg);
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_TRANS, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
   return 0;
+}
+
+extern "C" int ffvc_set_option(const char* name, int value) {
+  if (!name) return FFVC_E_BADARG;
+  if (!strcmp(name, "gemm2_tile")) {
+    g_opt_gemm2_tile = value;
+    return 0;
+  }
+  if (!strcmp(name, "conv_row")) {
+    g_opt_conv_row = value;
+    return 0;
+  }
+  ffvc_set_error("ffvc_set_option: unknown option '%s'", name);
+  return FFVC_E_BADARG;
 }

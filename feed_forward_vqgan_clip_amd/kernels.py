@@ -423,3 +423,8 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
     gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
     _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
     return out
+
+
+def set_option(name, value):
+    """Kernel-selection override (tests / A-B runs): see ffvc_set_option in include/ffvc.h."""
+    _call("ffvc_set_option", name.encode(), int(value))

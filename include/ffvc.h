@@ -226,6 +226,11 @@ int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nslab, int acc
 int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream);            /* out[0] += sum x^2 */
 int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream); /* y = a*x + b*y */
 
+/* Kernel-selection overrides for tests / A-B measurements (defaults come from FFVC_GEMM2_BM / FFVC_CONV_ROW):
+ *   "gemm2_tile": 0 = register-staged kernel only, 1 = heuristic, 128 | 256 | 512 = force the LDS-DMA tile
+ *                 (128x128 | 256x128 | 256x256);   "conv_row": 0 off, 1 heuristic, 2 force the haloed row-tile conv. */
+int ffvc_set_option(const char* name, int value);
+
 /* Library / device info */
 const char* ffvc_last_error(void);
 int ffvc_version(void);

@@ -213,3 +213,28 @@ def test_splitk_slabs(cuda, dt):
     out2 = torch.ones(M, N, dtype=torch.float32, device=cuda)
     K.gemm_splitk_accumulate(xt, wt, out2, M, N, K_, 1, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
     assert _rel(out2, xt.double().T @ wt.double() + 1.0) < 2e-5
+
+
+@pytest.mark.parametrize("W,Cin,Cout,ups", [(64, 128, 128, False), (128, 64, 256, False), (256, 128, 128, False),
+                                           (64, 128, 128, True), (128, 256, 128, True)])
+def test_conv_row_tile_kernel(cuda, W, Cin, Cout, ups):
+    """Haloed row-tile conv fast path (forced) vs F.conv2d, incl. image borders and the fused 2x upsample."""
+    dt = torch.bfloat16
+    B, H = (1, W) if W >= 128 else (2, 64)
+    Hin, Win = (H // 2, W // 2) if ups else (H, W)
+    x = _mk((B, Hin, Win, Cin), dt, cuda, 1)
+    w = _mk((Cout, 3, 3, Cin), dt, cuda, 2, 0.05)
+    b = _mk((Cout,), torch.float32, cuda, 3)
+    res = _mk((B, H, W, Cout), dt, cuda, 4)
+    y = torch.empty(B, H, W, Cout, dtype=dt, device=cuda)
+    K.set_option("conv_row", 2)
+    try:
+        K.gemm(x, w, y, B * H * W, Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=b, residual=res,
+               conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if ups else 0)
+    finally:
+        K.set_option("conv_row", 1)
+    xn = x.double().permute(0, 3, 1, 2)
+    if ups:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xn, w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    assert _rel(y, ref) < 1e-2
