@@ -22,6 +22,11 @@
 //
 // Same tile geometry and epilogue as v1 (128x128, 4 waves x 64x64, MFMA 32x32x16, A := W rows, B := X rows).
 // Shapes this path does not cover (fp32, rows not 16-byte aligned, ...) fall back to gemm.hip.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace {
