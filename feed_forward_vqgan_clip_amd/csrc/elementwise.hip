@@ -59,47 +59,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ s
 
 // ---------------------------- column sums ----------------------------------
 // out[c] (+)= sum_r x[r, c]   (bias gradients; reduction of LayerNorm partials)
-// vec path: block = 64 column-octets (16-byte loads for bf16, 2 x 16 B for fp32) x 4 row-lanes, 4 rows in flight per
-// thread; gridDim.y strips of rows, atomics combine strips.  Scalar path for unaligned shapes.
+// block = 64 column-quads x 4 row-lanes (8/16-byte loads); gridDim.y strips of rows, atomics combine strips.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
                                                      int cols, int64_t ld, int rows_per_block, int vec) {
-  __shared__ float red[4][512];
+  __shared__ float red[4][256];
   const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
   if (vec) {
-    const int c = (blockIdx.x * 64 + tx) * 8;
-    float a[8];
+    const int c = (blockIdx.x * 64 + tx) * 4;
+    if (c < cols)
+      for (int64_t r = r0 + ry; r < r1; r += 4) {
+        const f32x4_t v = load4(x + r * ld + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    if (c < cols) {
-      int64_t r = r0 + ry;
-      for (; r + 12 < r1; r += 16) {
-        const f32x8 v0 = load8(x + r * ld + c), v1 = load8(x + (r + 4) * ld + c), v2 = load8(x + (r + 8) * ld + c),
-                    v3 = load8(x + (r + 12) * ld + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += (v0.v[j] + v1.v[j]) + (v2.v[j] + v3.v[j]);
+        for (int j = 0; j < 4; ++j) a[j] += v[j];
       }
-      for (; r < r1; r += 4) {
-        const f32x8 v0 = load8(x + r * ld + c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += v0.v[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[ry][tx * 8 + j] = a[j];
+    for (int j = 0; j < 4; ++j) red[ry][tx * 4 + j] = a[j];
     __syncthreads();
     if (ry == 0 && c < cols) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        atomicAdd(out + c + j, red[0][tx * 8 + j] + red[1][tx * 8 + j] + red[2][tx * 8 + j] + red[3][tx * 8 + j]);
+      for (int j = 0; j < 4; ++j)
+        atomicAdd(out + c + j, red[0][tx * 4 + j] + red[1][tx * 4 + j] + red[2][tx * 4 + j] + red[3][tx * 4 + j]);
     }
   } else {
     const int c = blockIdx.x * 64 + tx;
-    float a = 0.f;
     if (c < cols)
-      for (int64_t r = r0 + ry; r < r1; r += 4) a += ElemTraits<T>::load(x + r * ld + c);
-    red[ry][tx] = a;
+      for (int64_t r = r0 + ry; r < r1; r += 4) a[0] += ElemTraits<T>::load(x + r * ld + c);
+    red[ry][tx] = a[0];
     __syncthreads();
     if (ry == 0 && c < cols) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
   }
@@ -468,20 +456,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ x, fl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
     float a = 0.f;
-    if ((cols & 7) == 0 && (((uintptr_t)x) & 15) == 0) {
-      float a2 = 0.f;
-      int c = lane * 8;
-      for (; c + 512 < cols; c += 1024) {
-        const f32x8 v = load8(x + r * cols + c), w = load8(x + r * cols + c + 512);
-        a += ((v.v[0] + v.v[1]) + (v.v[2] + v.v[3])) + ((v.v[4] + v.v[5]) + (v.v[6] + v.v[7]));
-        a2 += ((w.v[0] + w.v[1]) + (w.v[2] + w.v[3])) + ((w.v[4] + w.v[5]) + (w.v[6] + w.v[7]));
-      }
-      for (; c < cols; c += 512) {
-        const f32x8 v = load8(x + r * cols + c);
-        a += ((v.v[0] + v.v[1]) + (v.v[2] + v.v[3])) + ((v.v[4] + v.v[5]) + (v.v[6] + v.v[7]));
-      }
-      a += a2;
-    } else if ((cols & 3) == 0) {
+    if ((cols & 3) == 0) {
       for (int c = lane * 4; c < cols; c += 256) {
         const f32x4_t v = load4(x + r * cols + c);
         a += (v[0] + v[1]) + (v[2] + v[3]);
@@ -597,9 +572,9 @@ extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, i
     }
   }
   const int es = dtype == FFVC_BF16 ? 2 : 4;
-  const int vec = (cols % 8 == 0) && (ld % 8 == 0) && (((uintptr_t)x) % 16 == 0);
+  const int vec = (cols % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0);
   // enough row strips that column-blocks x strips fills the chip (>= ~1024 workgroups), >= 8 rows per strip
-  const int colblocks = ceil_div(cols, vec ? 512 : 64);
+  const int colblocks = ceil_div(cols, vec ? 256 : 64);
   int64_t strips = (1024 + colblocks - 1) / colblocks;
   if (strips > rows / 8) strips = rows / 8;
   if (strips < 1) strips = 1;
