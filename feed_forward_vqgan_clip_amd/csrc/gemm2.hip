@@ -558,6 +558,14 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     const double e256 = t256 >= 256 ? eff(t256, 512) * 1.07 : 0.0;
     const double e128 = eff(t128, 512);
     cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
+    // short reductions are epilogue-dominated: keep two (smaller) workgroups per CU so one's epilogue overlaps the
+    // other's K loop (threshold via FFVC_SHORTK for A/B runs)
+    static int shortk = -1;
+    if (shortk < 0) {
+      const char* e = getenv("FFVC_SHORTK");
+      shortk = e ? atoi(e) : 0;
+    }
+    if (d.K <= shortk && cfg != 128) cfg = 128;
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) {
