@@ -789,7 +789,12 @@ extern "C" int ffvc_groupnorm_fwd(const void* x, void* y, const float* gamma, co
   hipStream_t st = (hipStream_t)stream;
   int rpc;
   const int nch = gn_chunks(B, HW, &rpc);
-  const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
+  // ~4096 workgroups in total (each one re-derives the group statistics from the chunk partials, so tiny
+  // workgroups waste time), at least 64 pixels per workgroup
+  int bpi = 4096 / (B < 1 ? 1 : B);
+  if (bpi > HW / 64) bpi = HW / 64;
+  if (bpi < 1) bpi = 1;
+  const int rpb = (HW + bpi - 1) / bpi;
   const int nblk = (HW + rpb - 1) / rpb;
   DISPATCH_DT(dtype, T, {
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)x, (double*)ws, HW, C, G, rpc);
@@ -808,7 +813,12 @@ extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* ga
   hipStream_t st = (hipStream_t)stream;
   int rpc;
   const int nch = gn_chunks(B, HW, &rpc);
-  const int rpb = 64 > (HW + 1023) / 1024 ? 64 : (HW + 1023) / 1024;
+  // ~4096 workgroups in total (each one re-derives the group statistics from the chunk partials, so tiny
+  // workgroups waste time), at least 64 pixels per workgroup
+  int bpi = 4096 / (B < 1 ? 1 : B);
+  if (bpi > HW / 64) bpi = HW / 64;
+  if (bpi < 1) bpi = 1;
+  const int rpb = (HW + bpi - 1) / bpi;
   const int nblk = (HW + rpb - 1) / rpb;
   DISPATCH_DT(dtype, T, {
     hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
