@@ -2,6 +2,8 @@
 // All statistics, reductions and transcendental math are fp32 (fp64 for the GroupNorm moment
 // combine); storage is bf16 or fp32 per tensor.  One wavefront (64 lanes) owns one row /
 // pixel-strip, 16-byte vector accesses, no LDS round trip for row reductions (wave shuffles).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define DISPATCH_DT(code, T, ...)   \
@@ -724,9 +726,20 @@ extern "C" int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma
   return 0;
 }
 
+static int ln_rows_per_block() {
+  static int rpb = -1;
+  if (rpb < 0) {
+    const char* e = getenv("FFVC_LN_RPB");
+    rpb = e ? atoi(e) : 16;
+    if (rpb < 4) rpb = 4;
+  }
+  return rpb;
+}
+
 extern "C" int ffvc_layernorm_bwd_blocks(int64_t rows) {
   // number of partial rows ffvc_layernorm_bwd writes into part_g / part_b
-  int64_t nb = (rows + 15) / 16;
+  const int rpb = ln_rows_per_block();
+  int64_t nb = (rows + rpb - 1) / rpb;
   return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -737,7 +750,7 @@ extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, i
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
   FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = 16;
+  const int rpb = ln_rows_per_block();
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
   const bool v4 = (dim % 4) == 0;
@@ -884,7 +897,7 @@ extern "C" int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const
                      part_s, "ffvc_sln_bwd: null pointer");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_sln_bwd: dim=%d unsupported", dim);
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = 16;
+  const int rpb = ln_rows_per_block();
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = (2 * (size_t)dim + 2) * sizeof(float);
   DISPATCH_DT(dy_dtype, DYT, {
