@@ -730,7 +730,7 @@ static int ln_rows_per_block() {
   static int rpb = -1;
   if (rpb < 0) {
     const char* e = getenv("FFVC_LN_RPB");
-    rpb = e ? atoi(e) : 16;
+    rpb = e ? atoi(e) : 32;
     if (rpb < 4) rpb = 4;
   }
   return rpb;
