@@ -43,7 +43,7 @@ def build(args, device):
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
                        batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
-                       model_type="mlp_mixer", vq_image_size=16, augs=["R"])
+                       model_type=args.model_type, vq_image_size=args.vq_image_size, augs=["R"])
     torch.manual_seed(1234)
     net = fmain.build_model(cfg, 256)
     mixer_sd = {k: v.detach().clone() for k, v in net.state_dict().items()} if args.keep_cpu_weights else None
@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--cutn", type=int, default=8)
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=32)
+    ap.add_argument("--model-type", default="mlp_mixer", choices=["mlp_mixer", "vitgan", "simple_vitgan", "xtransformer"],
+                    help="mapper family (the headline workload cfg2 is mlp_mixer; others are dev / parity configs)")
+    ap.add_argument("--vq-image-size", type=int, default=16, help="latent grid S (image = 16*S)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,6 +158,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(hvd.local_rank())
     device = torch.device("cuda", hvd.local_rank())
+    if args.model_type != "mlp_mixer":
+        args.no_cpu_baseline = True
     args.keep_cpu_weights = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     cfg, stepper, sds = build(args, device)
 
@@ -189,13 +194,16 @@ def main():
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic seeded token batches, random-init weights (no network)",
-        "config": {"workload": f"cfg2: MLP-Mixer {args.depth}x{args.dim} mapper + VQGAN f16-16384 decoder 256x256 + CLIP "
+        "config": {"workload": (f"cfg2: MLP-Mixer {args.depth}x{args.dim}" if args.model_type == "mlp_mixer" else
+                                f"{args.model_type} {args.depth}x{args.dim}") +
+                               f" mapper + VQGAN f16-16384 decoder {16 * args.vq_image_size}x{16 * args.vq_image_size} + CLIP "
                                f"ViT-B/32, per-GPU batch {B}, cutn {args.cutn}, augs ['R'] + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
                    "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire},
         "final_loss": float(loss.item()),
     }
-    tf_step = step_tflop(B, args.cutn) if (args.depth, args.dim) == (32, 1024) else None
+    tf_step = step_tflop(B, args.cutn) if (args.model_type, args.depth, args.dim, args.vq_image_size) == \
+        ("mlp_mixer", 32, 1024, 16) else None
     if tf_step:
         out["step_tflop"] = tf_step
         out["step_mfma_frac"] = tf_step / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS
