@@ -43,7 +43,8 @@ def build(args, device):
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
                        batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
-                       model_type=args.model_type, vq_image_size=args.vq_image_size, augs=["R"])
+                       model_type=args.model_type, vq_image_size=args.vq_image_size,
+                       augs=None if args.augs == "default" else args.augs.split(","))
     torch.manual_seed(1234)
     net = fmain.build_model(cfg, 256)
     mixer_sd = {k: v.detach().clone() for k, v in net.state_dict().items()} if args.keep_cpu_weights else None
@@ -79,7 +80,7 @@ def effective_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(sds, cutn, seconds_budget=30.0):
+def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     """The oracle (CPU restatement, fp32) timed on this box's host cores on a bounded sample of the same
     workload: full train steps (fwd + loss + bwd + Adam) at batch 1 of the cfg2 models."""
     from feed_forward_vqgan_clip_amd import main as fmain
@@ -99,12 +100,15 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0):
     g = torch.Generator().manual_seed(5)
     facs = (torch.rand(cutn * B, generator=g) * 0.1).view(-1, 1, 1, 1)
     noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
+    from feed_forward_vqgan_clip_amd import augment as faug
+    prm = None if augs == "R" else faug.draw_params(cutn * B, 224, faug.SUPPORTED if augs == "default" else
+                                                    tuple(a for a in augs.split(",") if a != "R"), generator=g)
 
     def one(step):
         loss, _ = ostep.train_step_loss(
             lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=len([k for k in sd if k.endswith(".0.norm.weight")])),
             params, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(),
-            facs=facs, noise=noise)
+            facs=facs, noise=noise, aug_params=prm)
         grads = torch.autograd.grad(loss, plist)
         with torch.no_grad():
             ostep.adam_step(plist, grads, state, 1e-3, step)
@@ -138,6 +142,8 @@ def main():
     ap.add_argument("--model-type", default="mlp_mixer", choices=["mlp_mixer", "vitgan", "simple_vitgan", "xtransformer"],
                     help="mapper family (the headline workload cfg2 is mlp_mixer; others are dev / parity configs)")
     ap.add_argument("--vq-image-size", type=int, default=16, help="latent grid S (image = 16*S)")
+    ap.add_argument("--augs", default="default", help="'default' = the reference's Af,Pe,Ji,Er (main.py:164-165), or a "
+                    "comma list, e.g. 'R'")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,7 +203,7 @@ def main():
         "config": {"workload": (f"cfg2: MLP-Mixer {args.depth}x{args.dim}" if args.model_type == "mlp_mixer" else
                                 f"{args.model_type} {args.depth}x{args.dim}") +
                                f" mapper + VQGAN f16-16384 decoder {16 * args.vq_image_size}x{16 * args.vq_image_size} + CLIP "
-                               f"ViT-B/32, per-GPU batch {B}, cutn {args.cutn}, augs ['R'] + noise, full step "
+                               f"ViT-B/32, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
                    "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire},
         "final_loss": float(loss.item()),
@@ -253,7 +259,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del stepper
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(sds, args.cutn)
+        out["cpu_baseline"] = cpu_baseline(sds, args.cutn, augs=args.augs)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

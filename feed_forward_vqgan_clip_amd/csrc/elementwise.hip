@@ -521,6 +521,121 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const ST* __restrict__ s, i
   }
 }
 
+// ------------------------------ augmented cutouts ----------------------------
+// The reference's default MakeCutouts pipeline (main.py:164-165,170-198,222-225,797): RandomAffine(15 deg, translate
+// .1, border) -> RandomPerspective(.7, zeros) -> ColorJitter(hue .1, saturation .1) -> RandomErasing -> + noise ->
+// (x - mean) / std, fused into ONE resampling pass over the pooled image and written as ViT patch rows.
+// Every random draw arrives as an explicit per-cutout parameter:
+//   pinv [N,9]: output pixel -> coordinates in the affine-warped image (inverse perspective homography)
+//   ainv [N,6]: affine-warped coordinates -> pooled-image coordinates (inverse affine)
+//   cmat [N,9]: RGB colour matrix (hue rotation + saturation scale, exact for identity)
+//   erase[N,4]: x0, y0, x1, y1 of the erased rectangle (x1 <= x0: none)
+// value = inside(p1) * bilinear(pooled, clamp(A^-1 p1)), p1 = P^-1 p2 — one interpolation instead of kornia's two
+// (kornia 0.5.10 is not restated: parity unpinned, statistically equivalent augmentation).
+struct AugSample {
+  int x0, y0;
+  float wx, wy, m;
+};
+__device__ __forceinline__ AugSample aug_coords(const float* __restrict__ pinv, const float* __restrict__ ainv, int ox,
+                                                int oy, int S) {
+  const float x2 = (float)ox, y2 = (float)oy;
+  const float w = pinv[6] * x2 + pinv[7] * y2 + pinv[8];
+  const float iw = 1.0f / (fabsf(w) > 1e-8f ? w : 1e-8f);
+  const float x1 = (pinv[0] * x2 + pinv[1] * y2 + pinv[2]) * iw;
+  const float y1 = (pinv[3] * x2 + pinv[4] * y2 + pinv[5]) * iw;
+  AugSample a;
+  a.m = (x1 >= -0.5f && x1 <= (float)S - 0.5f && y1 >= -0.5f && y1 <= (float)S - 0.5f) ? 1.0f : 0.0f;   // zeros padding
+  float x0 = ainv[0] * x1 + ainv[1] * y1 + ainv[2];
+  float y0 = ainv[3] * x1 + ainv[4] * y1 + ainv[5];
+  x0 = fminf(fmaxf(x0, 0.0f), (float)(S - 1));                                                            // border padding
+  y0 = fminf(fmaxf(y0, 0.0f), (float)(S - 1));
+  a.x0 = min((int)x0, S - 2 < 0 ? 0 : S - 2);
+  a.y0 = min((int)y0, S - 2 < 0 ? 0 : S - 2);
+  a.wx = x0 - (float)a.x0;
+  a.wy = y0 - (float)a.y0;
+  return a;
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ pinv,
+                                                          const float* __restrict__ ainv, const float* __restrict__ cmat,
+                                                          const int* __restrict__ erase, const float* __restrict__ noise,
+                                                          const float* __restrict__ facs, OT* __restrict__ out, int B, int S,
+                                                          int cutn, int P, float m0, float m1, float m2, float s0, float s1,
+                                                          float s2) {
+  const int gw = S / P;
+  const int64_t n_px = (int64_t)cutn * B * S * S;
+  const int64_t per_img = (int64_t)3 * S * S;
+  const float mean[3] = {m0, m1, m2}, istd[3] = {1.0f / s0, 1.0f / s1, 1.0f / s2};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_px; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % S);
+    int64_t t = i / S;
+    const int oy = (int)(t % S);
+    const int n = (int)(t / S);
+    const int b = n % B;
+    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, S);
+    const int* er = erase + n * 4;
+    const bool erased = ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3];
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* src = pooled + ((int64_t)b * 3 + c) * S * S + (int64_t)a.y0 * S + a.x0;
+      const float v00 = src[0], v01 = src[1], v10 = src[S], v11 = src[S + 1];
+      rgb[c] = a.m * ((1.f - a.wy) * ((1.f - a.wx) * v00 + a.wx * v01) + a.wy * ((1.f - a.wx) * v10 + a.wx * v11));
+    }
+    const float* cm = cmat + n * 9;
+    const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = erased ? 0.0f : cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2];
+      if (noise) v += facs[n] * noise[(int64_t)n * per_img + ((int64_t)c * S + oy) * S + ox];
+      const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)c * P * P + ky * P + kx;
+      ElemTraits<OT>::store(out + (int64_t)n * per_img + prow, (v - mean[c]) * istd[c]);
+    }
+  }
+}
+
+// dpooled (pre-zeroed) += scatter of the bilinear taps (fp32 atomics: ~4 per output pixel and channel)
+template <typename GT>
+__global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__ gout, const float* __restrict__ pinv,
+                                                          const float* __restrict__ ainv, const float* __restrict__ cmat,
+                                                          const int* __restrict__ erase, float* __restrict__ dpooled, int B,
+                                                          int S, int cutn, int P, float s0, float s1, float s2) {
+  const int gw = S / P;
+  const int64_t n_px = (int64_t)cutn * B * S * S;
+  const int64_t per_img = (int64_t)3 * S * S;
+  const float istd[3] = {1.0f / s0, 1.0f / s1, 1.0f / s2};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_px; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % S);
+    int64_t t = i / S;
+    const int oy = (int)(t % S);
+    const int n = (int)(t / S);
+    const int b = n % B;
+    const int* er = erase + n * 4;
+    if (ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3]) continue;
+    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, S);
+    if (a.m == 0.0f) continue;
+    const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)c * P * P + ky * P + kx;
+      g[c] = ElemTraits<GT>::load(gout + (int64_t)n * per_img + prow) * istd[c];
+    }
+    const float* cm = cmat + n * 9;
+    const float w00 = (1.f - a.wy) * (1.f - a.wx), w01 = (1.f - a.wy) * a.wx, w10 = a.wy * (1.f - a.wx), w11 = a.wy * a.wx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float gc = cm[c] * g[0] + cm[3 + c] * g[1] + cm[6 + c] * g[2];          // transpose of the colour matrix
+      float* dst = dpooled + ((int64_t)b * 3 + c) * S * S + (int64_t)a.y0 * S + a.x0;
+      atomicAdd(dst, gc * w00);
+      atomicAdd(dst + 1, gc * w01);
+      atomicAdd(dst + S, gc * w10);
+      atomicAdd(dst + S + 1, gc * w11);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
@@ -793,6 +908,41 @@ extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nsl
                  "ffvc_slab_reduce: needs 16-byte aligned buffers and n %% 4 == 0");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, slabs, y, n, nslab,
                      accumulate);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat,
+                                const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
+                                int S, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
+                                float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(pooled && pinv && ainv && cmat && erase && out, "ffvc_augment_fwd: null pointer");
+  FFVC_CHECK_ARG(B > 0 && S > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_fwd: bad geometry");
+  FFVC_CHECK_ARG((noise == nullptr) == (facs == nullptr), "ffvc_augment_fwd: noise and facs go together");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)cutn * B * S * S;
+  DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
+                                                pinv, ainv, cmat, erase, noise, facs, (OT*)out, B, S, cutn, patch, mean_r,
+                                                mean_g, mean_b, std_r, std_g, std_b));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
+                                const int32_t* erase, float* dpooled, int B, int S, int cutn, int patch, float std_r,
+                                float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(gout && pinv && ainv && cmat && erase && dpooled, "ffvc_augment_bwd: null pointer");
+  FFVC_CHECK_ARG(B > 0 && S > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_bwd: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dpooled, 0, (size_t)B * 3 * S * S * sizeof(float), st);
+  if (e != hipSuccess) {
+    ffvc_set_error("ffvc_augment_bwd: memset failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  const int64_t n = (int64_t)cutn * B * S * S;
+  DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
+                                              (const GT*)gout, pinv, ainv, cmat, erase, dpooled, B, S, cutn, patch, std_r,
+                                              std_g, std_b));
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -428,3 +428,20 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
 def set_option(name, value):
     """Kernel-selection override (tests / A-B runs): see ffvc_set_option in include/ffvc.h."""
     _call("ffvc_set_option", name.encode(), int(value))
+
+
+def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
+    B, _, S, _ = pooled.shape
+    g = S // patch
+    out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
+    _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), erase.data_ptr(),
+          _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, cutn, patch, mean[0], mean[1], mean[2],
+          std[0], std[1], std[2], stream_ptr())
+    return out
+
+
+def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std):
+    dpooled = torch.empty(B, 3, S, S, dtype=torch.float32, device=gout.device)
+    _call("ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
+          erase.data_ptr(), dpooled.data_ptr(), B, S, cutn, patch, std[0], std[1], std[2], stream_ptr())
+    return dpooled

@@ -20,6 +20,7 @@ import time
 import torch
 from torch import nn
 
+from . import augment as _augment
 from . import clip as _clip
 from . import distributed as hvd
 from . import kernels as K
@@ -88,13 +89,41 @@ class MakeCutouts(nn.Module):
                  interpolate=False):
         super().__init__()
         augs = tuple(augs) if augs else ("Af", "Pe", "Ji", "Er")      # main.py:164-165 (empty list -> defaults)
-        if augs != ("R",):
-            raise NotImplementedError(f"augs={list(augs)}: only ['R'] is implemented on the HIP path (kornia "
-                                      "augmentations are SURVEY.md §8f row n1)")
+        self.augs = tuple(a for a in augs if a != "R")                # 'R' = resize to cut_size: identity at pool_size == cut_size
+        for a in self.augs:
+            if a not in _augment.SUPPORTED:
+                raise NotImplementedError(f"augs={list(augs)}: '{a}' is not built on the HIP path (built: 'R' and "
+                                          f"{list(_augment.SUPPORTED)})")
         pool_size = pool_size or cut_size
         if not pool or interpolate or pool_size != cut_size:
             raise NotImplementedError("MakeCutouts: only pool=True, interpolate=False, pool_size == cut_size")
         self.cut_size, self.cutn, self.noise_fac = cut_size, cutn, 0.1
+        self.generator = None                                         # torch.Generator for reproducible parameter draws
+
+    def draw_aug_params(self, n, device):
+        """Per-cutout augmentation parameters (None when only 'R' is configured)."""
+        if not self.augs:
+            return None
+        prm = _augment.draw_params(n, self.cut_size, self.augs, generator=self.generator)
+        if torch.device(device).type != "cuda":
+            return prm
+        # pinned staging (caching host allocator) keeps the upload asynchronous: a pageable copy would stall the host
+        # until everything already queued on the stream (mapper + decoder) has run
+        return {k: v.pin_memory().to(device, non_blocking=True) for k, v in prm.items()}
+
+    def patches(self, xr_nhwc, patch, mean, std, out_dtype, facs=None, noise=None, aug_params=None):
+        """NHWC fp32 image batch -> normalised ViT patch rows with the configured augmentations (fused path)."""
+        B = xr_nhwc.shape[0]
+        n = self.cutn * B
+        if facs is None and self.noise_fac:
+            facs, noise = self.draw_noise(n, xr_nhwc.device)
+        if not self.augs:
+            return ops.cutouts(xr_nhwc, self.cut_size, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
+        if aug_params is None:
+            aug_params = self.draw_aug_params(n, xr_nhwc.device)
+        pooled = ops.cutouts(xr_nhwc, self.cut_size, 1, self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32)
+        pooled = pooled.view(B, 3, self.cut_size, self.cut_size)
+        return ops.augment(pooled, aug_params, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
 
     def draw_noise(self, n, device):
         if not self.noise_fac:
@@ -103,13 +132,11 @@ class MakeCutouts(nn.Module):
         noise = torch.randn(n, 3, self.cut_size, self.cut_size, device=device)       # main.py:225
         return facs, noise
 
-    def forward(self, input, facs=None, noise=None):
+    def forward(self, input, facs=None, noise=None, aug_params=None):
         """(B,3,H,W) in [0,1] -> (cutn*B, 3, cut, cut) fp32, cut-major like `repeat(cutn,1,1,1)` (main.py:218)."""
         xr = input.permute(0, 2, 3, 1)
-        if facs is None and self.noise_fac:
-            facs, noise = self.draw_noise(self.cutn * input.shape[0], input.device)
-        out = ops.cutouts(xr.float(), self.cut_size, self.cutn, self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0),
-                          torch.float32, noise=noise, facs=facs)
+        out = self.patches(xr.float(), self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32, facs, noise,
+                           aug_params)
         return out.view(self.cutn * input.shape[0], 3, self.cut_size, self.cut_size)
 
 
@@ -230,7 +257,7 @@ class TrainStep:
     def features(self, t):
         return self.perceptor.encode_text(t).float() if t.dtype == torch.long else t.float().cuda()
 
-    def forward_loss(self, inp, out=None, facs=None, noise=None):
+    def forward_loss(self, inp, out=None, facs=None, noise=None, aug_params=None):
         """main.py:729-811 -> (loss, intermediates)."""
         inp_feats = self.features(inp)                                          # :733
         if self.normalize_input:
@@ -255,12 +282,8 @@ class TrainStep:
         z_nhwc = z.permute(0, 2, 3, 1)                                          # contiguous for NHWC-native mappers
         z_nhwc = ops.clamp_with_grad(z_nhwc, self.vq.z_min, self.vq.z_max)      # :763
         xr, idx = synth_nhwc(self.vq, z_nhwc)                                   # :767
-        B = xr.shape[0]
-        mc = self.make_cutouts
-        if facs is None and mc.noise_fac:
-            facs, noise = mc.draw_noise(self.cutn * B, xr.device)
-        patches = ops.cutouts(xr, mc.cut_size, self.cutn, self.perceptor.patch, tuple(CLIP_MEAN), tuple(CLIP_STD),
-                              self.perceptor.cdt, noise=noise, facs=facs)       # :796-797 fused
+        patches = self.make_cutouts.patches(xr, self.perceptor.patch, tuple(CLIP_MEAN), tuple(CLIP_STD),
+                                            self.perceptor.cdt, facs, noise, aug_params)   # :796-797 fused
         embed = self.perceptor.encode_patches(patches)                          # :799
         loss = ops.spherical_loss(embed, out_feats, self.target_loss_coef)      # :801-811
         if self.input_loss:
@@ -271,8 +294,8 @@ class TrainStep:
             loss = loss + self.tv_coef * tv_loss(xr.permute(0, 3, 1, 2))        # :769-773,831 (optional, plain autograd)
         return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats}
 
-    def __call__(self, inp, out=None, facs=None, noise=None):
-        loss, mid = self.forward_loss(inp, out, facs, noise)
+    def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None):
+        loss, mid = self.forward_loss(inp, out, facs, noise, aug_params)
         self.opt.zero_grad()                                                    # :825
         loss.backward()                                                         # :832
         if self.clip_grad_norm:

@@ -556,6 +556,29 @@ def cutouts(xr, cut, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
     return _CutoutsFn.apply(xr, noise, facs, cut, cutn, patch, mean, std, out_dtype)
 
 
+class _AugmentFn(Function):
+    """Fused default augmentation chain on the pooled image (kernels.augment_fwd / augment_bwd)."""
+
+    @staticmethod
+    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype):
+        pooled = _contig(pooled)
+        ctx.save_for_backward(pinv, ainv, cmat, erase)
+        ctx.cfg = (pooled.shape[0], pooled.shape[2], cutn, patch, std)
+        return K.augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
+
+    @staticmethod
+    def backward(ctx, g):
+        pinv, ainv, cmat, erase = ctx.saved_tensors
+        B, S, cutn, patch, std = ctx.cfg
+        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std),) + (None,) * 11
+
+
+def augment(pooled, params, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
+    """pooled: (B,3,S,S) fp32 -> ViT patch rows (cutn*B, (S/patch)^2, 3*patch^2); params from augment.draw_params."""
+    return _AugmentFn.apply(pooled, noise, facs, params["pinv"], params["ainv"], params["cmat"], params["erase"], cutn,
+                            patch, mean, std, out_dtype)
+
+
 class _PatchEmbedFn(Function):
     """tokens[n, 1+p, :] = patches[n, p, :] @ Wc^T + pos[1+p]; tokens[n, 0] = cls + pos[0]  (cloob.py:237-244)."""
 

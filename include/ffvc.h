@@ -203,6 +203,19 @@ int ffvc_cutouts_fwd(const float* xr, const float* noise, const float* facs, voi
                      float std_g, float std_b, void* stream);
 int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr, int B, int H, int W, int cut,
                      int cutn, int patch, float std_r, float std_g, float std_b, void* stream);
+/* The reference's DEFAULT augmentation chain of MakeCutouts (main.py:164-165,172,178,182,190 + :222-225,797) applied to the
+ * pooled image `pooled` [B,3,S,S] fp32 (= ffvc_cutouts_fwd with cutn 1, patch S, mean 0, std 1) in one fused resampling
+ * pass: RandomAffine -> RandomPerspective -> ColorJitter(hue, saturation) -> RandomErasing -> + noise -> mean/std ->
+ * ViT patch rows.  All random draws are explicit per-cutout parameters (N = cutn*B rows, cut-major like repeat()):
+ * pinv [N,9] inverse perspective homography, ainv [N,6] inverse affine (pixel units), cmat [N,9] RGB colour matrix,
+ * erase [N,4] int32 rectangle x0,y0,x1,y1 (x1 <= x0: none).  kornia 0.5.10 itself is absent: parity unpinned.
+ * The backward scatters into dpooled [B,3,S,S] (zeroed inside); chain it with ffvc_cutouts_bwd(cutn 1, patch S). */
+int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const int32_t* erase,
+                     const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int cutn, int patch,
+                     float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
+                     const int32_t* erase, float* dpooled, int B, int S, int cutn, int patch, float std_r, float std_g,
+                     float std_b, void* stream);
 /* Spherical distance loss (main.py:801-811), repeat=1: loss = coef*mean_n 2*asin(|H-E|/2)^2 with
  * H = normalize(feats[n % B]), E = normalize(embed[n]); dembed (may be NULL) <- d loss / d embed. */
 int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, float* loss, float* dembed, int N,

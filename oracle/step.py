@@ -93,7 +93,7 @@ def spherical_loss(embed, target_feats, cutn, coef=1.0):
 
 def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_size, z_min, z_max,
                     facs=None, noise=None, vq_cfg=ovq.F16_16384, clip_heads=(None, None),
-                    pool_size=None, text_feats=None, decode_fn=None):
+                    pool_size=None, text_feats=None, decode_fn=None, aug_params=None):
     """Forward half of one training step (main.py:729-811,831) with repeat=1, noise_dim=0,
     l2/tv/diversity coefficients 0.  Returns (loss, dict of intermediates)."""
     if text_feats is None:
@@ -102,7 +102,12 @@ def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_s
     z = mapper_fn(mapper_sd, text_feats).contiguous()                                   # :754-757
     z = clamp_with_grad(z, z_min, z_max)                                                # :763
     xr = synth(vq_sd, z, vq_cfg, decode_fn)                                             # :767
-    x = make_cutouts(xr, cut_size=cut_size, cutn=cutn, facs=facs, noise=noise, pool_size=pool_size)  # :796
+    if aug_params is None:
+        x = make_cutouts(xr, cut_size=cut_size, cutn=cutn, facs=facs, noise=noise, pool_size=pool_size)  # :796
+    else:                                                                               # default augs, explicit parameters
+        pooled = (F.adaptive_avg_pool2d(xr, cut_size) + F.adaptive_max_pool2d(xr, cut_size)) / 2   # :217
+        x = augment_reference(pooled, aug_params["pinv"], aug_params["ainv"], aug_params["cmat"], aug_params["erase"], cutn,
+                              facs, noise)
     mean = torch.tensor(CLIP_MEAN, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     std = torch.tensor(CLIP_STD, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     x = (x - mean) / std                                                                # :797
@@ -120,3 +125,41 @@ def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-8):
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
         denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
         p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None):
+    """Plain-PyTorch statement of ffvc_augment_fwd (the fused Af -> Pe -> Ji -> Er chain of main.py:164-198 with
+    explicit per-cutout parameters): returns (cutn*B, 3, S, S) BEFORE mean/std normalisation.  kornia itself is not
+    restated (absent offline, parity unpinned); this pins the HIP kernel to the documented resampling formula."""
+    B, _, S, _ = pooled.shape
+    N = cutn * B
+    ys, xs = torch.meshgrid(torch.arange(S, dtype=pooled.dtype), torch.arange(S, dtype=pooled.dtype), indexing="ij")
+    x2, y2 = xs[None].expand(N, S, S), ys[None].expand(N, S, S)
+    P, A = pinv.view(N, 9).to(pooled.dtype), ainv.view(N, 6).to(pooled.dtype)
+    pe = lambda i: P[:, i].view(N, 1, 1)  # noqa: E731
+    ae = lambda i: A[:, i].view(N, 1, 1)  # noqa: E731
+    w = pe(6) * x2 + pe(7) * y2 + pe(8)
+    w = torch.where(w.abs() > 1e-8, w, torch.full_like(w, 1e-8))
+    x1 = (pe(0) * x2 + pe(1) * y2 + pe(2)) / w
+    y1 = (pe(3) * x2 + pe(4) * y2 + pe(5)) / w
+    m = ((x1 >= -0.5) & (x1 <= S - 0.5) & (y1 >= -0.5) & (y1 <= S - 0.5)).to(pooled.dtype)
+    x0 = (ae(0) * x1 + ae(1) * y1 + ae(2)).clamp(0, S - 1)
+    y0 = (ae(3) * x1 + ae(4) * y1 + ae(5)).clamp(0, S - 1)
+    xi = x0.floor().clamp(max=max(S - 2, 0)).long()
+    yi = y0.floor().clamp(max=max(S - 2, 0)).long()
+    wx, wy = x0 - xi, y0 - yi
+    src = pooled.repeat(cutn, 1, 1, 1).reshape(N, 3, S * S)
+    def tap(dy, dx):
+        idx = ((yi + dy) * S + (xi + dx)).view(N, 1, S * S).expand(N, 3, S * S)
+        return src.gather(2, idx).view(N, 3, S, S)
+    val = (1 - wy)[:, None] * ((1 - wx)[:, None] * tap(0, 0) + wx[:, None] * tap(0, 1)) + \
+        wy[:, None] * ((1 - wx)[:, None] * tap(1, 0) + wx[:, None] * tap(1, 1))
+    val = val * m[:, None]
+    out = torch.einsum("nij,njhw->nihw", cmat.view(N, 3, 3).to(pooled.dtype), val)
+    e = erase.view(N, 4)
+    er = (xs[None] >= e[:, 0].view(N, 1, 1)) & (xs[None] < e[:, 2].view(N, 1, 1)) & \
+         (ys[None] >= e[:, 1].view(N, 1, 1)) & (ys[None] < e[:, 3].view(N, 1, 1))
+    out = out * (~er)[:, None].to(pooled.dtype)
+    if facs is not None:
+        out = out + facs.view(N, 1, 1, 1) * noise
+    return out

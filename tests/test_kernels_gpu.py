@@ -218,3 +218,52 @@ def test_adam(cuda, sdt):
     y = torch.ones_like(g)
     K.axpby(g, y, 2.0, 3.0)
     assert torch.allclose(y, 2 * g + 3)
+
+
+@pytest.mark.parametrize("odt", DT)
+def test_augment_matches_oracle_reference(cuda, odt):
+    """Fused default-augmentation kernel (fwd + bwd) vs the plain-torch statement of the same resampling math."""
+    from feed_forward_vqgan_clip_amd import augment as A
+    from oracle import step as ostep
+    B, S, cutn, P = 3, 32, 4, 8
+    g = torch.Generator().manual_seed(7)
+    prm = A.draw_params(cutn * B, S, generator=g)
+    prm["erase"][:] = torch.tensor([5, 9, 17, 20], dtype=torch.int32)           # force an erased rectangle
+    pooled = torch.rand(B, 3, S, S, generator=g)
+    noise = torch.randn(cutn * B, 3, S, S, generator=g)
+    facs = torch.rand(cutn * B, generator=g) * 0.1
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    dev = {k: v.to(cuda) for k, v in prm.items()}
+    out = K.augment_fwd(pooled.to(cuda), dev["pinv"], dev["ainv"], dev["cmat"], dev["erase"], cutn, P, mean, std, odt,
+                        noise=noise.to(cuda), facs=facs.to(cuda))
+    pd = pooled.double().requires_grad_(True)
+    ref = ostep.augment_reference(pd, prm["pinv"].double(), prm["ainv"].double(), prm["cmat"].double(), prm["erase"], cutn,
+                                  facs.double(), noise.double())
+    m = torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
+    refn = (ref - m) / s
+    gw = S // P
+    ref_p = refn.view(cutn * B, 3, gw, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(cutn * B, gw * gw, 3 * P * P)
+    # a handful of pixels sit exactly on a floor()/mask boundary where fp32 and fp64 coordinates may disagree
+    err = (out.double().cpu() - ref_p).abs()
+    tol = 3e-2 if odt == torch.bfloat16 else 1e-3
+    assert (err > tol).float().mean().item() < 2e-3, f"mismatching fraction {(err > tol).float().mean().item()}"
+    gout = _mk(tuple(out.shape), odt, cuda, 5)
+    dp = K.augment_bwd(gout, dev["pinv"], dev["ainv"], dev["cmat"], dev["erase"], B, S, cutn, P, std)
+    ref_p.backward(gout.double().cpu())
+    rel = ((dp.double().cpu() - pd.grad).abs().max() / pd.grad.abs().max()).item()
+    assert rel < 2e-2, rel
+
+
+def test_augment_identity_params_equal_plain_cutouts(cuda):
+    """With every augmentation switched off the fused path must reproduce the 'R' path exactly."""
+    from feed_forward_vqgan_clip_amd import augment as A
+    B, H, cut, cutn, P = 2, 40, 32, 3, 8
+    g = torch.Generator().manual_seed(1)
+    xr = torch.rand(B, H, H, 3, generator=g).to(cuda)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    plain = K.cutouts_fwd(xr, cut, cutn, P, mean, std, torch.float32)
+    prm = {k: v.to(cuda) for k, v in A.draw_params(cutn * B, cut, augs=(), generator=g).items()}
+    pooled = K.cutouts_fwd(xr, cut, 1, cut, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32).view(B, 3, cut, cut)
+    fused = K.augment_fwd(pooled, prm["pinv"], prm["ainv"], prm["cmat"], prm["erase"], cutn, P, mean, std, torch.float32)
+    assert _rel(fused, plain) < 1e-6

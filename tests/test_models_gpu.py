@@ -191,6 +191,45 @@ def test_train_step_matches_oracle(cuda, cdt):
             assert rel < 2e-2
 
 
+@pytest.mark.parametrize("cdt", [F32, BF16])
+def test_train_step_default_augs_matches_oracle(cuda, cdt):
+    """Same step with the reference's DEFAULT augmentation set (Af, Pe, Ji, Er; main.py:164-165), the random
+    parameters drawn once and fed to both sides."""
+    from feed_forward_vqgan_clip_amd import augment as A
+    from oracle import mappers as omap
+    from oracle import step as ostep
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(cdt)
+    cfg.augs = None
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    assert stepper.make_cutouts.augs == ("Af", "Pe", "Ji", "Er")
+    prm = A.draw_params(16, 32, generator=torch.Generator().manual_seed(5))
+    prm["erase"][:] = torch.tensor([3, 4, 15, 20], dtype=torch.int32)
+    msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(),
+                                     aug_params={k: v.cuda() for k, v in prm.items()})
+    opt.zero_grad()
+    loss.backward()
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    oloss, omid = ostep.train_step_loss(
+        lambda sd, f: omap.mixer_forward(sd, f, image_size=12, channels=64, depth=2), osd, vq_sd, clip_sd, tok,
+        cutn=4, cut_size=32, z_min=vq.z_min, z_max=vq.z_max, facs=facs, noise=noise, vq_cfg=TINY_VQ, aug_params=prm)
+    oloss.backward()
+    rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    print(f"[{cdt}] default augs: loss hip={loss.item():.7f} oracle={oloss.item():.7f} rel={rel:.2e}")
+    if cdt == F32:
+        assert rel < 1e-4
+        params = dict(net.named_parameters())
+        gmax = max(v.grad.abs().max().item() for v in osd.values())
+        for k, v in osd.items():
+            tiny = (params[k].grad.cpu() - v.grad).abs().max().item() < 1e-6 * gmax
+            assert tiny or _relrms(params[k].grad, v.grad) < 5e-3, k
+    else:
+        assert rel < 3e-2
+    # a step without explicit parameters draws its own
+    loss2, _ = stepper.forward_loss(tok.cuda())
+    assert torch.isfinite(loss2)
+
+
 def test_optimizer_step_matches_torch_adam(cuda):
     cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(F32)
     ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in net.named_parameters()}
