@@ -152,6 +152,10 @@ def load():
             "or `make -C feed_forward_vqgan_clip_amd/csrc` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback."
         )
+    # torch ships its own libamdhip64.so.7; it has to be resident BEFORE this library is mapped so both share ONE HIP
+    # runtime (same SONAME).  Loaded the other way round the process holds two runtimes and launches on torch's
+    # device pointers fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
