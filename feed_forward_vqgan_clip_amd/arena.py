@@ -85,6 +85,12 @@ class ParamArena:
         """fn(param) is called when a parameter's gradient has been fully written in backward."""
         self._grad_cbs.append(fn)
 
+    def grad_written(self, *params):
+        """A kernel accumulated these parameters' gradients straight into the bucket (autograd is bypassed)."""
+        for fn in self._grad_cbs:
+            for p in params:
+                fn(p)
+
     def _on_grad(self, W):
         for fn in self._grad_cbs:
             fn(W.weight)

@@ -168,6 +168,51 @@ __device__ __forceinline__ float act_gelu_grad_fast(float x) {
   gelu_parts_fast(x, cdf, e);
   return cdf + x * 0.39894228040143267794f * e;
 }
+// Two-at-a-time variants for bf16-storage epilogues: the polynomial parts compile to v_pk_*_f32 (two lanes of fp32
+// per issue slot) and the reciprocal is the 1-ulp v_rcp_f32 instead of the ~11-instruction IEEE division.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t rcp2_(f32x2_t v) {
+  f32x2_t r;
+  r[0] = __builtin_amdgcn_rcpf(v[0]);
+  r[1] = __builtin_amdgcn_rcpf(v[1]);
+  return r;
+}
+__device__ __forceinline__ f32x2_t exp2_2_(f32x2_t v) {
+  f32x2_t r;
+  r[0] = __builtin_amdgcn_exp2f(v[0]);
+  r[1] = __builtin_amdgcn_exp2f(v[1]);
+  return r;
+}
+__device__ __forceinline__ void gelu_parts_fast2(f32x2_t x, f32x2_t& cdf, f32x2_t& e) {
+  f32x2_t ax;
+  ax[0] = __builtin_fabsf(x[0]);
+  ax[1] = __builtin_fabsf(x[1]);
+  const f32x2_t z = ax * 0.70710678118654752440f;
+  const f32x2_t t = rcp2_(z * 0.3275911f + 1.0f);
+  e = exp2_2_(z * z * -1.44269504088896341f);
+  const f32x2_t poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const f32x2_t erf_abs = 1.0f - poly * e;
+  f32x2_t sg;
+  sg[0] = __builtin_copysignf(erf_abs[0], x[0]);
+  sg[1] = __builtin_copysignf(erf_abs[1], x[1]);
+  cdf = sg * 0.5f + 0.5f;
+}
+__device__ __forceinline__ f32x2_t act_gelu_fast2(f32x2_t x) {
+  f32x2_t cdf, e;
+  gelu_parts_fast2(x, cdf, e);
+  return x * cdf;
+}
+__device__ __forceinline__ f32x2_t act_gelu_grad_fast2(f32x2_t x) {
+  f32x2_t cdf, e;
+  gelu_parts_fast2(x, cdf, e);
+  return cdf + x * 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ f32x2_t sigmoid_fast2(f32x2_t x) { return rcp2_(exp2_2_(x * -1.44269504088896341f) + 1.0f); }
+__device__ __forceinline__ f32x2_t act_quickgelu_fast2(f32x2_t x) { return x * sigmoid_fast2(x * 1.702f); }
+__device__ __forceinline__ f32x2_t act_quickgelu_grad_fast2(f32x2_t x) {
+  const f32x2_t s = sigmoid_fast2(x * 1.702f);
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_quickgelu(float x) { return x * sigmoidf_(1.702f * x); }
 __device__ __forceinline__ float act_quickgelu_grad(float x) {

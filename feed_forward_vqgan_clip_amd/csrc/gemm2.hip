@@ -388,7 +388,11 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       compute(cur, cur + XTILE);
     }
   }
-  ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, m0, n0, wm, wn, lane, zo, zi,
+                                                       smem + (RING ? 2 : 1) * STAGE + wid * 4096);
+  else
+    ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
 
 // 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
@@ -458,7 +462,10 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
       }
     }
   }
-  ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
+  else
+    ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
 }
 
 uint16_t* g_zero_page[16] = {nullptr};
@@ -499,7 +506,8 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   if (split < 1) split = 1;
   dim3 grid(n_tiles, d.batch, split);
   constexpr int nthreads = 64 * 2 * (BN / 64);
-  constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128);
+  // stage ring + one 4 KiB row-store pad per wave (256x256: 128 + 32 = all 160 KiB of the CU)
+  constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128) + 2 * (BN / 64) * 4096;
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -542,6 +550,24 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.kseg && (!m8(d.xkso) || !m8(d.wkso))) return 0;
   const uint16_t* zero = zero_page();
   if (!zero) return 0;
+  {
+    // row-store epilogue (vec_ok = 2): 8 consecutive n per lane -> N % 8 and 16-byte aligned rows everywhere
+    static int rows_opt = -1;
+    if (rows_opt < 0) {
+      const char* e = getenv("FFVC_EPI_ROWS");
+      rows_opt = e ? atoi(e) : 1;
+    }
+    const bool out32 = d.flags & FFVC_F_OUT_F32;
+    bool ok = rows_opt && m8(d.N) && (out32 ? (d.y_sm % 4 == 0 && d.y_so % 4 == 0 && d.ybo % 4 == 0 && d.ybi % 4 == 0 && d.slab_stride % 4 == 0)
+                                            : (m8(d.y_sm) && m8(d.y_so) && m8(d.ybo) && m8(d.ybi) && m8(d.slab_stride)));
+    if (d.residual) {
+      const bool r32 = d.flags & FFVC_F_RES_F32;
+      ok = ok && (r32 ? (d.r_sm % 4 == 0 && d.r_so % 4 == 0 && d.rbo % 4 == 0 && d.rbi % 4 == 0)
+                      : (m8(d.r_sm) && m8(d.r_so) && m8(d.rbo) && m8(d.rbi)));
+    }
+    if (d.aux) ok = ok && m8(d.ldaux) && m8(d.abo) && m8(d.abi);
+    if (ok) vec_ok = 2;
+  }
   // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
   const int env_bm = opt_value(g_opt_gemm2_tile, "FFVC_GEMM2_BM", 1);
   if (env_bm == 0) return 0;
@@ -576,7 +602,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     const bool fills = (int64_t)(d.M / 256) * (d.N / 128) >= 256;
     if (geom_ok && (env_row == 2 || (env_row == 1 && fills && cfg != 512))) {
       const int tiles_n = d.N / 128, n_tiles = (d.M / 256) * tiles_n;
-      constexpr int lds = 264 * 128 + 128 * 128;
+      constexpr int lds = 264 * 128 + 128 * 128 + 4 * 4096;
       static bool attr = false;
       if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_row_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -119,4 +119,147 @@ __device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t 
   }
 }
 
+// ---- row-store epilogue --------------------------------------------------------------------------------------------
+// The MFMA C layout gives a lane 4 consecutive n of ONE row per register quad, 32 rows per wave instruction: stored
+// directly, every store touches 32 lines with 16 bytes each and the epilogue is store-issue bound (~7 B/clk/CU
+// measured).  Here each 32x32 block goes through a wave-private 4 KiB LDS pad (XOR-swizzled 16-byte chunks, no bank
+// conflicts either way) and comes back as 8 consecutive n per lane, 16 rows per instruction: one 16-byte store (bf16)
+// per lane, aux / residual reads coalesced the same way, activations evaluated two-at-a-time.
+template <typename T>
+__device__ __forceinline__ f32x2_t apply_act2(int act, f32x2_t v) {
+  if constexpr (sizeof(T) == 2) {
+    if (act == FFVC_ACT_GELU) return act_gelu_fast2(v);
+    if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_fast2(v);
+    return v;
+  } else {
+    f32x2_t r;
+    r[0] = apply_act<T>(act, v[0]);
+    r[1] = apply_act<T>(act, v[1]);
+    return r;
+  }
+}
+template <typename T>
+__device__ __forceinline__ f32x2_t apply_act_grad2(int act, f32x2_t pre) {
+  if constexpr (sizeof(T) == 2) {
+    if (act == FFVC_ACT_GELU) return act_gelu_grad_fast2(pre);
+    if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad_fast2(pre);
+    f32x2_t one = {1.0f, 1.0f};
+    return one;
+  } else {
+    f32x2_t r;
+    r[0] = apply_act_grad<T>(act, pre[0]);
+    r[1] = apply_act_grad<T>(act, pre[1]);
+    return r;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8 v, int n, int64_t yrow, int64_t rrow,
+                                             int64_t arow, int flags) {
+  if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
+    const f32x8 b = load8(p.bias + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] += b.v[j];
+  }
+  if (flags & FFVC_F_MUL_ACT_GRAD) {
+    const f32x8 pre = load8((const T*)p.aux + arow + n);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2_t g = apply_act_grad2<T>(p.act, f32x2_t{pre.v[j], pre.v[j + 1]});
+      v.v[j] *= g[0];
+      v.v[j + 1] *= g[1];
+    }
+  } else if (p.act != FFVC_ACT_NONE) {
+    if (flags & FFVC_F_WRITE_PREACT) store8((T*)p.aux + arow + n, v);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2_t a = apply_act2<T>(p.act, f32x2_t{v.v[j], v.v[j + 1]});
+      v.v[j] = a[0];
+      v.v[j + 1] = a[1];
+    }
+  }
+  if (p.residual) {
+    const f32x8 r = (flags & FFVC_F_RES_F32) ? load8((const float*)p.residual + rrow + n) : load8((const T*)p.residual + rrow + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] += r.v[j];
+  }
+  if (flags & FFVC_F_ATOMIC_OUT) {
+    float* yp = (float*)p.y + yrow + n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(yp + j, v.v[j]);
+  } else if (flags & FFVC_F_ACCUM_OUT) {
+    float* yp = (float*)p.y + yrow + n;
+    const f32x8 o = load8(yp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] += o.v[j];
+    store8(yp, v);
+  } else if (flags & FFVC_F_OUT_F32) {
+    store8((float*)p.y + yrow + n, v);
+  } else {
+    store8((T*)p.y + yrow + n, v);
+  }
+}
+
+// pad: this wave's 4 KiB of LDS.  Requires N % 8 == 0 and 16-byte aligned rows of y / aux / residual (host-checked).
+template <typename T, int MT>
+__device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0,
+                                                   int wm, int wn, int lane, int zo, int zi, unsigned char* pad) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int rr = lane >> 2, cc = lane & 3;
+  const int flags = p.flags;
+  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)blockIdx.z * p.slab_stride;
+  const int64_t rbz = zo * p.rbo + zi * p.rbi;
+  const int64_t abz = zo * p.abo + zi * p.abi;
+  unsigned char* wr = pad + l31 * 128;
+  const int wsw = l31 & 7;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mbase = m0 + wm * (32 * MT) + mt * 32;
+    float bias_m = 0.0f;
+    if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mbase + l31, p.M - 1)];
+    int64_t yrow[2], rrow[2], arow[2];
+    bool mok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mbase + rr + 16 * i;
+      mok[i] = m < p.M;
+      const int mm = mok[i] ? m : 0;
+      yrow[i] = ybz + (p.y_mi ? (int64_t)(mm / p.y_mi) * p.y_so + (int64_t)(mm % p.y_mi) * p.y_sm : (int64_t)mm * p.y_sm);
+      rrow[i] = rbz + (p.r_mi ? (int64_t)(mm / p.r_mi) * p.r_so + (int64_t)(mm % p.r_mi) * p.r_sm : (int64_t)mm * p.r_sm);
+      arow[i] = abz + (int64_t)mm * p.ldaux;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
+        *(f32x4_t*)(wr + (((2 * q + h) ^ wsw) << 4)) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int n = n0 + wn * 64 + nt * 32 + 8 * cc;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = rr + 16 * i;
+        const unsigned char* rd = pad + row * 128;
+        const f32x4_t a = *(const f32x4_t*)(rd + (((2 * cc) ^ (row & 7)) << 4));
+        const f32x4_t b = *(const f32x4_t*)(rd + (((2 * cc + 1) ^ (row & 7)) << 4));
+        f32x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v.v[j] = a[j];
+          v.v[4 + j] = b[j];
+        }
+        if (mok[i] && n < p.N) epilogue_oct<T>(p, v, n, yrow[i], rrow[i], arow[i], flags);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
 }  // namespace ffvc_gemm_detail

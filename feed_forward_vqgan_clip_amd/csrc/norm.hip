@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
                                                      const float* __restrict__ rstd, const XT* __restrict__ dres,
                                                      XT* __restrict__ dx, float* __restrict__ part_g,
                                                      float* __restrict__ part_b, int64_t rows, int dim,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, int acc_mode) {
   constexpr int NIT = LN_MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -178,9 +178,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < dim; i += 256) {
-      part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
-      part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
+    if (acc_mode) {   // part_g / part_b are the [dim] gradients themselves: one fp32 atomic per column and workgroup
+      for (int i = threadIdx.x; i < dim; i += 256) {
+        atomicAdd(part_g + i, ln_smem[i]);
+        atomicAdd(part_b + i, ln_smem[dim + i]);
+      }
+    } else {
+      for (int i = threadIdx.x; i < dim; i += 256) {
+        part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
+        part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
+      }
     }
   }
 }
@@ -743,9 +750,26 @@ extern "C" int ffvc_layernorm_bwd_blocks(int64_t rows) {
   return (int)(nb < 1 ? 1 : nb);
 }
 
+static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                         const float* rstd, const void* dres, void* dx, float* part_g, float* part_b, int64_t rows,
+                         int dim, void* stream, int acc_mode);
+
 extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                                   const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
                                   float* part_b, int64_t rows, int dim, void* stream) {
+  return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, part_g, part_b, rows, dim, stream, 0);
+}
+
+extern "C" int ffvc_layernorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                                      const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                                      float* dbeta, int64_t rows, int dim, void* stream) {
+  FFVC_CHECK_ARG(dgamma && dbeta, "ffvc_layernorm_bwd_acc: null gradient pointer");
+  return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, dim, stream, 1);
+}
+
+static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                         const float* rstd, const void* dres, void* dx, float* part_g, float* part_b, int64_t rows,
+                         int dim, void* stream, int acc_mode) {
   FFVC_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ffvc_layernorm_bwd: null pointer");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
   FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
@@ -758,11 +782,11 @@ extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, i
                 if (v4)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb);
+                                     dim, rpb, acc_mode);
                 else
                   hipLaunchKernelGGL((ln_bwd_kernel<1, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb);
+                                     dim, rpb, acc_mode);
               }));
   FFVC_LAUNCH_CHECK();
   return 0;

@@ -168,6 +168,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False):
     return dx, dg, db
 
 
+def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+    """-> dx; dgamma / dbeta (fp32 [dim], contiguous) are accumulated in place."""
+    _need_cuda(dy, x, gamma, dgamma, dbeta)
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    dx = torch.empty_like(x)
+    if dres is not None and dres.dtype != x.dtype:
+        raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
+    if dgamma.dtype != torch.float32 or dbeta.dtype != torch.float32 or not dgamma.is_contiguous() or not dbeta.is_contiguous():
+        raise TypeError("layernorm_bwd_acc: gradients must be contiguous fp32")
+    _call("ffvc_layernorm_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
+          gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
+          dbeta.data_ptr(), rows, dim, stream_ptr())
+    return dx
+
+
 def _gn_ws(B, HW, G, dev):
     n = _lib.load().ffvc_groupnorm_ws_bytes(B, HW, G)
     return torch.empty((n + 7) // 8, dtype=torch.float64, device=dev)

@@ -308,6 +308,9 @@ class _LNForkFn(Function):
         y, mean, rstd = K.layernorm_fwd(x, g, b, out_dtype, eps)
         ctx.save_for_backward(x, g, mean, rstd)
         ctx.train = gamma.requires_grad
+        # parameters that live in a ParamArena get their gradients accumulated straight into the flat bucket
+        ctx.params = (gamma, beta) if (ctx.train and getattr(gamma, "_ffvc_arena", None) is not None and
+                                       getattr(beta, "_ffvc_arena", None) is gamma._ffvc_arena) else None
         ctx.set_materialize_grads(False)
         return y, x.view_as(x)
 
@@ -319,6 +322,11 @@ class _LNForkFn(Function):
         dy = _contig(dy)
         if dres is not None:
             dres = _as(_contig(dres), x.dtype)
+        if ctx.params is not None:
+            gamma, beta = ctx.params
+            dx = K.layernorm_bwd_acc(dy, x, g, mean, rstd, _grad_buf(gamma), _grad_buf(beta), dres=dres)
+            gamma._ffvc_arena.grad_written(gamma, beta)
+            return dx, None, None, None, None
         dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=ctx.train)
         return dx, dg, db, None, None
 

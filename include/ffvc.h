@@ -130,6 +130,12 @@ int ffvc_layernorm_bwd_blocks(int64_t rows);
 int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                        const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
                        float* part_b, int64_t rows, int dim, void* stream);
+/* Same pass, but dgamma / dbeta ([dim] fp32, e.g. slices of the flat gradient bucket) are ACCUMULATED in place with one
+ * fp32 atomic per column and workgroup: no partial rows, no follow-up reduction launches (mlp_mixer_pytorch.py:24-25,
+ * cloob.py:153-174 LayerNorm parameter gradients under torch autograd). */
+int ffvc_layernorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                           const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                           float* dbeta, int64_t rows, int dim, void* stream);
 
 /* Self-modulated LayerNorm of the VitGAN generator (vitgan.py:8-21): y = gamma_s*w*LN(hl) + beta_s*w with scalar
  * parameters gamma_s/beta_s (device pointers) and the per-token modulation w; hl, w fp32 [rows, dim].
