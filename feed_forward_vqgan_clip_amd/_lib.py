@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libffvc_hip.so")
+LIB_PATH = os.environ.get("FFVC_LIB") or os.path.join(_HERE, "lib", "libffvc_hip.so")   # FFVC_LIB: A/B builds of the same ABI
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2

@@ -262,9 +262,27 @@ __device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const 
 //   256x128: 4 waves x 128x64, ONE stage (48 KiB), <=256 regs, 2 workgroups / CU alternate load / MFMA
 //   256x256: 8 waves x 128x64, 2-stage ring (128 KiB), <=256 regs, 1 workgroup / CU = 2 waves / SIMD; 128 FLOP per
 //            L2 byte, the only shape that is not capped by the ~53 B/clk a CU can pull from L2.
+#ifdef FFVC_NO_FRAG_PREFETCH_256
+constexpr bool FRAG_PREFETCH_256 = false;
+#else
+constexpr bool FRAG_PREFETCH_256 = true;   // 256-row tiles also fetch fragments one sub-step ahead (two register sets)
+#endif
+#ifndef FFVC_EXP_MODE
+#define FFVC_EXP_MODE 0     // timing experiments only (wrong results): 1 = no DMA after the first stage, 2 = no vmcnt wait / barrier
+#endif
+#ifdef FFVC_NO_DMA_SPREAD
+constexpr bool DMA_SPREAD = false;
+#else
+constexpr bool DMA_SPREAD = true;
+#endif
+#ifdef FFVC_EXP_SKIPFRAG
+constexpr bool EXP_SKIP = true;    // timing experiment only (wrong results): emulate the LDS traffic of 128x128 wave tiles
+#else
+constexpr bool EXP_SKIP = false;
+#endif
 template <int XMODE, int WMODE, int BM, int BN>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2_kernel(
-    const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero) {
+    const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero, int gm) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
   constexpr int NW = 2 * (BN / 64);                  // waves per workgroup
   constexpr int XTILE = BM * 128, WTILE = BN * 128;  // bytes
@@ -281,7 +299,21 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  // Tiles are walked in groups of `gm` tile-rows, column-major inside a group: the ~32 workgroups that run together on
+  // one XCD then cover a compact gm x (32/gm) block of C and share gm + 32/gm operand panels through that XCD's L2
+  // instead of 1 + 32 (row-major order), which is what the fabric behind the L2s has to deliver.
+  int tm, tn;
+  if (gm > 1) {
+    const int width = gm * tiles_n;
+    const int grp = tile / width, rem = tile - grp * width;
+    const int first = grp * gm;
+    const int gsz = min(n_tiles / tiles_n - first, gm);
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
   const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
@@ -315,8 +347,11 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
-  auto compute = [&](const unsigned char* sX, const unsigned char* sW) {
-    if constexpr (BM == 256) {
+  // `between(sub)` runs after the MFMAs of sub-step `sub` have been issued: the ring loop uses it to spread the next
+  // stage's DMA issue over the first sub-steps, so the matrix pipe already has work queued while a wave is busy issuing
+  // loads (issued in one burst right after the barrier, both waves of a SIMD leave the pipe idle for that long).
+  auto compute = [&](const unsigned char* sX, const unsigned char* sW, auto&& between) {
+    if constexpr (BM == 256 && !FRAG_PREFETCH_256) {
       // one fragment set (register budget): the partner wave on the SIMD covers the LDS latency
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
@@ -329,12 +364,14 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const int rx = wm * (32 * MT) + t * 32 + l31;
+          if (EXP_SKIP && t >= 2) { fb[t] = fb[t - 2]; continue; }
           fb[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[a], fb[b]);
+        between(sub);
       }
     } else {
       // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
@@ -359,6 +396,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+        between(sub);
       }
     }
   };
@@ -368,7 +406,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       sw.issue(smem + XTILE, k_begin + kt * BK, k_end, zero, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      compute(smem, smem + XTILE);
+      compute(smem, smem + XTILE, [](int) {});
       __syncthreads();
     }
   } else {
@@ -377,15 +415,26 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
     }
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      unsigned char* cur = smem + (kt & 1) * STAGE;
-      if (kt + 1 < nk) {
-        unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
-        sx.issue(nxt, k_begin + (kt + 1) * BK, k_end, zero, tid);
-        sw.issue(nxt + XTILE, k_begin + (kt + 1) * BK, k_end, zero, tid);
+      if (FFVC_EXP_MODE != 2 || kt == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
       }
-      compute(cur, cur + XTILE);
+      unsigned char* cur = smem + (kt & 1) * STAGE;
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      const bool more = (kt + 1 < nk) && FFVC_EXP_MODE != 1;
+      const int kn = k_begin + (kt + 1) * BK;
+      if (DMA_SPREAD) {
+        compute(cur, cur + XTILE, [&](int sub) {
+          if (more && sub == 0) sx.issue(nxt, kn, k_end, zero, tid);
+          if (more && sub == 1) sw.issue(nxt + XTILE, kn, k_end, zero, tid);
+        });
+      } else {
+        if (more) {
+          sx.issue(nxt, kn, k_end, zero, tid);
+          sw.issue(nxt + XTILE, kn, k_end, zero, tid);
+        }
+        compute(cur, cur + XTILE, [](int) {});
+      }
     }
   }
   if (vec_ok == 2)
@@ -513,8 +562,18 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
+  static int gm_opt = -1;
+  if (gm_opt < 0) {
+    const char* e = getenv("FFVC_TILE_GM");
+    gm_opt = e ? atoi(e) : 4;
+  }
+  // workgroups resident per XCD: 32 CUs x (1 | 2) -> aim at a square-ish block
+  // measured (profiles/r01_gemm_micro.txt): grouping only pays for very wide outputs (8192^3: +7 %); the step's own
+  // shapes (tiles_n <= 16) are neutral to slightly worse, so they keep the row-major order
+  int gm = gm_opt >= 0 && getenv("FFVC_TILE_GM") ? gm_opt : (tiles_n > 16 ? 4 : 1);
+  if (gm > tiles_m) gm = tiles_m;
   hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
-                     vec_ok, zero);
+                     vec_ok, zero, gm);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ffvc_set_error("gemm2 launch failed: %s", hipGetErrorString(e));

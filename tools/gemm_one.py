@@ -22,7 +22,7 @@ if kind == "conv":
     x, w, y = r(B, H, H, C), r(C, 3, 3, C), torch.empty(B, H, H, C, device=dev, dtype=dt)
     fn = lambda: K.gemm(x, w, y, B * H * H, C, 9 * C, ldw=9 * C, x_mode=K.OP_CONV3X3, conv=(H, H, C))  # noqa: E731
 elif kind == "nt":
-    M, N, Kd = 16384, 1024, 4096
+    M, N, Kd = [int(v) for v in os.environ.get("MNK", "16384,1024,4096").split(",")]
     x, w, y = r(M, Kd), r(N, Kd), torch.empty(M, N, device=dev, dtype=dt)
     fn = lambda: K.gemm(x, w, y, M, N, Kd, ldx=Kd, ldw=Kd)  # noqa: E731
 else:
