@@ -1,0 +1,340 @@
+// attention.hip — fused softmax attention for SHORT sequences (T <= 64 tokens, head dim 64, bf16 storage):
+// the CLIP ViT-B/32 image tower has 50 tokens per cutout (cloob.py:199-200, nn.MultiheadAttention inside
+// ResidualAttentionBlock), i.e. 6144 independent (cutout, head) problems of 50x50x64 per layer.  As batched GEMMs +
+// softmax passes those cost ~10 ms per step (128x128 tiles are 85 % padding, scores and probabilities round-trip
+// through HBM); here ONE wave owns one (cutout, head): scores, softmax and both products stay in registers.
+//
+// Layout trick: scores are computed TRANSPOSED (S^T = K Q^T), so that a lane owns one query column and the keys run
+// over the accumulator registers — row max / row sum are in-lane reductions plus one exchange between the two half
+// waves, and 8 consecutive accumulator registers are exactly the B fragment (k = key) of the next MFMA.  MFMA sums
+// over k in any order as long as both operands agree, so the A operand (V^T, K^T, dO^T or Q^T, staged transposed in
+// LDS) is simply read in the accumulator's key order (two 8-byte reads per fragment) instead of shuffling P.
+//
+// Numerics match the GEMM + softmax path it replaces: fp32 scores and statistics, probabilities rounded to bf16
+// before the second product and before the softmax gradient, fp32 accumulation everywhere.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 68;            // LDS row stride (bf16) of a transposed 64 x 64 panel: 136 B, 8-byte aligned rows
+constexpr int PANEL = 64 * TS;
+constexpr float LOG2E = 1.44269504088896341f;
+
+__device__ __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  union {
+    u32x4_t u;
+    bf16x8_t h;
+  } ua, ub;
+  ua.u = a;
+  ub.u = b;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+}
+
+// 8 consecutive features (k = 16 s + 8 h ...) of token `row` straight from global memory; rows >= T read as zero.
+__device__ __forceinline__ u32x4_t rowfrag(const uint16_t* base, int64_t ld, int row, int T, int s, int h) {
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+  return row < T ? *(const u32x4_t*)(base + (int64_t)row * ld + 16 * s + 8 * h) : z;
+}
+
+// acc[a][b][r] += sum_d A[rowA0 + 32 a + i(r)][d] * B[rowB0 + 32 b + lane%32][d],  i(r) = 8 (r/4) + 4 (lane/32) + r%4
+template <int NA, int NB>
+__device__ __forceinline__ void rows_product(f32x16_t (&acc)[NA][NB], const uint16_t* A, int rowA0, const uint16_t* B,
+                                             int rowB0, int64_t ld, int T, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u32x4_t fa[NA], fb[NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) fa[a] = rowfrag(A, ld, rowA0 + 32 * a + l31, T, s, h);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fb[b] = rowfrag(B, ld, rowB0 + 32 * b + l31, T, s, h);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mma(acc[a][b], fa[a], fb[b]);
+  }
+}
+
+// Xt[d][tok] (LDS, stride TS) <- X[tok][d] of one head (64 features), rows >= T zero.
+__device__ __forceinline__ void stage_transposed(uint16_t* Xt, const uint16_t* X, int64_t ld, int T, int lane) {
+  const int c = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row < T) v = *(const u32x4_t*)(X + (int64_t)row * ld + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Xt[(8 * c + 2 * e) * TS + row] = (uint16_t)(v[e] & 0xffffu);
+      Xt[(8 * c + 2 * e + 1) * TS + row] = (uint16_t)(v[e] >> 16);
+    }
+  }
+}
+
+__device__ __forceinline__ u32x4_t pack8(const f32x16_t& t, int first) {
+  u32x4_t r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = pack_bf16x2(t[first + 2 * e], t[first + 2 * e + 1]);
+  return r;
+}
+
+// acc[dt][bt][r] += sum_c Xt[32 dt + i(r)][c] * src[c / 32][bt]{c % 32, lane},  c over 64 (contraction index of the
+// source tiles' REGISTER dimension); NC = number of 32-wide contraction tiles present in src (1 or 2).
+template <int NC, int NB>
+__device__ __forceinline__ void lds_product(f32x16_t (&acc)[2][NB], const uint16_t* Xt, const f32x16_t (&src)[NC][NB],
+                                            int c0, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int sp = 0; sp < 2 * NC; ++sp) {
+    const int ct = sp >> 1, sg = sp & 1;
+    u32x4_t fa[2], fb[NB];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const uint16_t* p = Xt + (32 * dt + l31) * TS + c0 + 32 * ct + 16 * sg + 4 * h;
+      const u32x2_t lo = *(const u32x2_t*)p;
+      const u32x2_t hi = *(const u32x2_t*)(p + 8);
+      fa[dt] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fb[b] = pack8(src[ct][b], 8 * sg);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mma(acc[dt][b], fa[dt], fb[b]);
+  }
+}
+
+template <int NA, int NB>
+__device__ __forceinline__ void zero_tiles(f32x16_t (&t)[NA][NB]) {
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[a][b][r] = 0.0f;
+}
+
+__device__ __forceinline__ int reg_index(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }   // row inside a 32-tile
+
+// Softmax over the keys of transposed score tiles ST[kt][qt] (lane = query, registers = keys), in place, probabilities
+// rounded to bf16 precision (kept as float).  Returns per (lane, qt) the row maximum and 1 / row sum.
+__device__ __forceinline__ void softmax_transposed(f32x16_t (&ST)[2][2], int T, float scale, int lane, float (&mx)[2],
+                                                   float (&linv)[2]) {
+  const int h = lane >> 5;
+  const float c = scale * LOG2E;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * kt + reg_index(r, h) < T) m = fmaxf(m, ST[kt][qt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = (32 * kt + reg_index(r, h) < T) ? __builtin_amdgcn_exp2f((ST[kt][qt][r] - m) * c) : 0.0f;
+        ST[kt][qt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ST[kt][qt][r] = bf16_bits_to_f32(f32_to_bf16_bits(ST[kt][qt][r] * inv));
+    mx[qt] = m;
+    linv[qt] = inv;
+  }
+}
+
+// out[(row0 + 32 bt + lane%32) * ld + 32 dt + i(r)] = acc[dt][bt][r]  (4 consecutive features per store), rows < T
+template <int NB>
+__device__ __forceinline__ void store_transposed(uint16_t* out, int64_t ld, const f32x16_t (&acc)[2][NB], int row0, int T,
+                                                 int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int row = row0 + 32 * b + l31;
+    if (row >= T) continue;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[dt][b][4 * g + j];
+        store4(out + (int64_t)row * ld + 32 * dt + 8 * g + 4 * h, v);
+      }
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_small_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
+                                                           int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[PANEL];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  stage_transposed(Vt, V, ld, T, lane);
+  f32x16_t ST[2][2];
+  zero_tiles(ST);
+  rows_product<2, 2>(ST, Kp, 0, Q, 0, ld, T, lane);
+  float mx[2], linv[2];
+  softmax_transposed(ST, T, scale, lane, mx, linv);
+  __syncthreads();
+  f32x16_t OT[2][2];
+  zero_tiles(OT);
+  lds_product<2, 2>(OT, Vt, ST, 0, lane);
+  store_transposed<2>(o + (int64_t)b * T * D + hd * 64, D, OT, 0, T, lane);
+}
+
+// Backward.  Phase A works on transposed tiles (lane = query): dQ.  Phase B walks the two query tiles in the other
+// orientation (lane = key, registers = queries), re-deriving P from the row statistics kept in LDS: dV and dK.
+__global__ __launch_bounds__(64) void attn_small_bwd_kernel(const uint16_t* __restrict__ qkv,
+                                                           const uint16_t* __restrict__ dout,
+                                                           uint16_t* __restrict__ dqkv, int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t bufA[PANEL];   // K^T, later dO^T
+  __shared__ __attribute__((aligned(16))) uint16_t bufB[PANEL];   // Q^T
+  __shared__ __attribute__((aligned(16))) float stat[3][64];      // row max, 1 / row sum, delta per query
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const uint16_t* dO = dout + (int64_t)b * T * D + hd * 64;
+  uint16_t* dQ = dqkv + (int64_t)b * T * ld + hd * 64;
+  uint16_t* dK = dQ + D;
+  uint16_t* dV = dQ + 2 * D;
+  const float c = scale * LOG2E;
+
+  stage_transposed(bufA, Kp, ld, T, lane);
+  stage_transposed(bufB, Q, ld, T, lane);
+  {
+    f32x16_t PT[2][2], dPT[2][2];
+    zero_tiles(PT);
+    rows_product<2, 2>(PT, Kp, 0, Q, 0, ld, T, lane);
+    float mx[2], linv[2];
+    softmax_transposed(PT, T, scale, lane, mx, linv);
+    // dP^T[key][query] = sum_d V[key][d] dO[query][d]   (dO rows have their own stride D)
+    zero_tiles(dPT);
+    {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x4_t fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = rowfrag(V, ld, 32 * a + l31, T, s, h);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) fb[q] = rowfrag(dO, D, 32 * q + l31, T, s, h);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) mma(dPT[a][q], fa[a], fb[q]);
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float delta = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta += PT[kt][qt][r] * dPT[kt][qt][r];
+      delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dPT[kt][qt][r] = PT[kt][qt][r] * (dPT[kt][qt][r] - delta) * scale;   // dS^T
+      if (h == 0) {
+        stat[0][32 * qt + l31] = mx[qt];
+        stat[1][32 * qt + l31] = linv[qt];
+        stat[2][32 * qt + l31] = delta;
+      }
+    }
+    __syncthreads();
+    // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
+    f32x16_t dQT[2][2];
+    zero_tiles(dQT);
+    lds_product<2, 2>(dQT, bufA, dPT, 0, lane);
+    store_transposed<2>(dQ, ld, dQT, 0, T, lane);
+  }
+  __syncthreads();
+  stage_transposed(bufA, dO, D, T, lane);      // dO^T[d][query]
+  __syncthreads();
+
+  f32x16_t dVT[2][2], dKT[2][2];               // [d tile][key tile], lane = key
+  zero_tiles(dVT);
+  zero_tiles(dKT);
+#pragma unroll 1
+  for (int qt = 0; qt < 2; ++qt) {
+    if (32 * qt >= T) break;
+    f32x16_t S[1][2], dP[1][2];                // [.][key tile], registers = queries of tile qt
+    zero_tiles(S);
+    zero_tiles(dP);
+    rows_product<1, 2>(S, Q, 32 * qt, Kp, 0, ld, T, lane);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32x4_t fa = rowfrag(dO, D, 32 * qt + l31, T, s, h);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) mma(dP[0][kt], fa, rowfrag(V, ld, 32 * kt + l31, T, s, h));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q0 = 32 * qt + 8 * g + 4 * h;
+      const f32x4_t m4 = *(const f32x4_t*)&stat[0][q0];
+      const f32x4_t i4 = *(const f32x4_t*)&stat[1][q0];
+      const f32x4_t d4 = *(const f32x4_t*)&stat[2][q0];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const bool kok = 32 * kt + l31 < T;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float p = kok ? __builtin_amdgcn_exp2f((S[0][kt][r] - m4[j]) * c) * i4[j] : 0.0f;
+          p = bf16_bits_to_f32(f32_to_bf16_bits(p));
+          S[0][kt][r] = p;                                           // P[query][key]
+          dP[0][kt][r] = p * (dP[0][kt][r] - d4[j]) * scale;         // dS[query][key]
+        }
+      }
+    }
+    // dV^T[d][key] += sum_query dO^T[d][query] P[query][key];  dK^T[d][key] += sum_query Q^T[d][query] dS[query][key]
+    lds_product<1, 2>(dVT, bufA, S, 32 * qt, lane);
+    lds_product<1, 2>(dKT, bufB, dP, 32 * qt, lane);
+  }
+  store_transposed<2>(dV, ld, dVT, 0, T, lane);
+  store_transposed<2>(dK, ld, dKT, 0, T, lane);
+}
+
+}  // namespace
+
+extern "C" int ffvc_attn_small_fwd(const void* qkv, void* out, int B, int T, int heads, int head_dim, float scale,
+                                   void* stream) {
+  FFVC_CHECK_ARG(qkv && out && B > 0 && heads > 0, "ffvc_attn_small_fwd: bad args");
+  FFVC_CHECK_ARG(T >= 1 && T <= 64 && head_dim == 64, "ffvc_attn_small_fwd: needs T <= 64 and head_dim == 64 (T=%d, dh=%d)",
+                 T, head_dim);
+  FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ffvc_attn_small_fwd: misaligned pointers");
+  hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                     (uint16_t*)out, T, heads, scale);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int B, int T, int heads, int head_dim,
+                                   float scale, void* stream) {
+  FFVC_CHECK_ARG(qkv && dout && dqkv && B > 0 && heads > 0, "ffvc_attn_small_bwd: bad args");
+  FFVC_CHECK_ARG(T >= 1 && T <= 64 && head_dim == 64, "ffvc_attn_small_bwd: needs T <= 64 and head_dim == 64 (T=%d, dh=%d)",
+                 T, head_dim);
+  FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)dqkv % 8) == 0,
+                 "ffvc_attn_small_bwd: misaligned pointers");
+  hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                     (const uint16_t*)dout, (uint16_t*)dqkv, T, heads, scale);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}

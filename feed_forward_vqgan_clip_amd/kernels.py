@@ -7,6 +7,8 @@ current HIP stream.  Nothing here computes with torch ops.
 import ctypes
 from ctypes import byref, c_int32, c_int64
 
+import os
+
 import torch
 
 from . import _lib
@@ -439,6 +441,28 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
     gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
     _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
     return out
+
+
+def attn_small_ok(qkv, heads, causal):
+    """Shapes the fused short-sequence attention kernel covers."""
+    B, T, D3 = qkv.shape
+    return (qkv.dtype == torch.bfloat16 and not causal and T <= 64 and D3 == 3 * heads * 64 and
+            os.environ.get("FFVC_ATTN_SMALL", "1") != "0")
+
+
+def attn_small_fwd(qkv, heads, scale):
+    B, T, D3 = qkv.shape
+    o = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
+    _call("ffvc_attn_small_fwd", qkv.data_ptr(), o.data_ptr(), B, T, heads, 64, float(scale), stream_ptr())
+    return o
+
+
+def attn_small_bwd(qkv, do, heads, scale):
+    B, T, D3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, T, heads, 64, float(scale),
+          stream_ptr())
+    return dqkv
 
 
 def set_option(name, value):

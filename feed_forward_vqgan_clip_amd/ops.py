@@ -450,6 +450,12 @@ class _AttentionFn(Function):
         B, T, D3 = qkv.shape
         D = D3 // 3
         dh = D // heads
+        if K.attn_small_ok(qkv, heads, causal):          # ViT-B/32: 50 tokens -> one wave per (cutout, head)
+            ctx.save_for_backward(qkv)
+            ctx.cfg = (heads, scale)
+            ctx.small = True
+            return K.attn_small_fwd(qkv, heads, scale)
+        ctx.small = False
         Tp = _pad8(T)
         cdt = qkv.dtype
         BH = B * heads
@@ -469,6 +475,10 @@ class _AttentionFn(Function):
 
     @staticmethod
     def backward(ctx, do):
+        if ctx.small:
+            (qkv,) = ctx.saved_tensors
+            heads, scale = ctx.cfg
+            return K.attn_small_bwd(qkv, _as(_contig(do), qkv.dtype), heads, scale), None, None, None
         qkv, P = ctx.saved_tensors
         B, T, D, heads, dh, Tp, scale = ctx.cfg
         D3, BH, cdt = 3 * D, B * heads, qkv.dtype

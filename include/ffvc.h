@@ -167,6 +167,14 @@ int ffvc_softmax_fwd(const float* s, void* p, int p_dtype, int64_t rows, int col
 int ffvc_softmax_bwd(const void* p, const float* dp, void* ds, int p_dtype, int64_t rows, int cols, int ldp,
                      int lddp, float scale, void* stream);
 
+/* Fused attention for short sequences (T <= 64, head_dim == 64, bf16): one wave per (batch item, head), scores /
+ * softmax / both products in registers.  qkv: [B, T, 3*heads*64] (q | k | v sections, head-major inside each, the
+ * packed in_proj output of nn.MultiheadAttention, cloob.py:199-200), out / dout: [B, T, heads*64], dqkv like qkv.
+ * Non-causal.  The backward recomputes the probabilities from qkv (nothing but qkv is kept from the forward). */
+int ffvc_attn_small_fwd(const void* qkv, void* out, int B, int T, int heads, int head_dim, float scale, void* stream);
+int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int B, int T, int heads, int head_dim,
+                        float scale, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Glue kernels of the train step (main.py:715-837)
  * ------------------------------------------------------------------------- */

@@ -267,3 +267,38 @@ def test_augment_identity_params_equal_plain_cutouts(cuda):
     pooled = K.cutouts_fwd(xr, cut, 1, cut, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32).view(B, 3, cut, cut)
     fused = K.augment_fwd(pooled, prm["pinv"], prm["ainv"], prm["cmat"], prm["erase"], cutn, P, mean, std, torch.float32)
     assert _rel(fused, plain) < 1e-6
+
+
+@pytest.mark.parametrize("B,T,heads", [(3, 50, 12), (2, 64, 2), (5, 17, 1), (2, 33, 3)])
+def test_attention_small_fused(cuda, B, T, heads):
+    """Fused short-sequence attention (one wave per (item, head)) vs fp64 math on the same bf16 inputs, fwd + bwd,
+    and vs the GEMM + softmax path it replaces."""
+    from feed_forward_vqgan_clip_amd import ops
+    D = heads * 64
+    qkv = _mk((B, T, 3 * D), torch.bfloat16, cuda, 1, 0.7)
+    do = _mk((B, T, D), torch.bfloat16, cuda, 2)
+    scale = 64 ** -0.5
+    assert K.attn_small_ok(qkv, heads, False)
+    o = K.attn_small_fwd(qkv, heads, scale)
+    dqkv = K.attn_small_bwd(qkv, do, heads, scale)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = [t.view(B, T, heads, 64).transpose(1, 2) for t in x.split(D, dim=-1)]
+    p = (q @ k.transpose(-1, -2) * scale).softmax(-1)
+    ref = (p @ v).transpose(1, 2).reshape(B, T, D)
+    ref.backward(do.double())
+    assert _rel(o, ref) < 1.2e-2
+    assert _rel(dqkv, x.grad) < 2.5e-2
+    # the unfused path on the same inputs
+    import os
+    os.environ["FFVC_ATTN_SMALL"] = "0"
+    try:
+        x2 = qkv.clone().requires_grad_(True)
+        o2 = ops.attention(x2, heads, scale)
+        o2.backward(do)
+    finally:
+        os.environ.pop("FFVC_ATTN_SMALL")
+    assert _rel(o, o2) < 1.2e-2 and _rel(dqkv, x2.grad) < 2.5e-2
+    x3 = qkv.clone().requires_grad_(True)
+    o3 = ops.attention(x3, heads, scale)
+    o3.backward(do)
+    assert torch.equal(o3, o) and torch.equal(x3.grad, dqkv)
