@@ -146,6 +146,8 @@ def main():
                     "comma list, e.g. 'R'")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-prefetch-text", dest="prefetch_text", action="store_false",
+                    help="encode each step's prompts inside the step instead of one step ahead on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", type=int, default=0, help="print the N most expensive GEMM shapes (stderr)")
@@ -170,7 +172,7 @@ def main():
     cfg, stepper, sds = build(args, device)
 
     B = args.batch
-    toks = fmain.synthetic_tokens(B * (args.steps + args.warmup), seed=1234 + rank).to(device)
+    toks = fmain.synthetic_tokens(B * (args.steps + args.warmup + 1), seed=1234 + rank).to(device)
 
     def sync():
         if world > 1:
@@ -178,13 +180,16 @@ def main():
         torch.cuda.synchronize()
 
     it = 0
+    # every step also encodes the NEXT step's prompts (prefetched on a side stream under its backward pass): the timed
+    # region contains exactly one text-tower pass per step, like the reference's loop
+    batches = [toks[i * B:(i + 1) * B] for i in range(args.steps + args.warmup + 1)]
     for _ in range(args.warmup):
-        stepper(toks[it * B:(it + 1) * B])
+        stepper(batches[it], next_inp=batches[it + 1] if args.prefetch_text else None)
         it += 1
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = stepper(toks[it * B:(it + 1) * B])
+        loss, _ = stepper(batches[it], next_inp=batches[it + 1] if args.prefetch_text else None)
         it += 1
     sync()
     dt = time.perf_counter() - t0

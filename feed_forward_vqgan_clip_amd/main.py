@@ -253,9 +253,36 @@ class TrainStep:
         self.clip_grad_norm = config.get("clip_grad_norm")
         self.normalize_input = config.get("normalize_input", False)
         self.l2_coef, self.tv_coef = config.get("l2_coef", 0.0), config.get("tv_coef", 0.0)
+        self._prefetched, self._text_stream = None, None
 
     def features(self, t):
-        return self.perceptor.encode_text(t).float() if t.dtype == torch.long else t.float().cuda()
+        if t.dtype != torch.long:
+            return t.float().cuda()
+        pf = self._prefetched
+        if pf is not None and pf[0] == (t.data_ptr(), tuple(t.shape)):
+            self._prefetched = None
+            torch.cuda.current_stream().wait_event(pf[2])
+            pf[1].record_stream(torch.cuda.current_stream())
+            return pf[1]
+        return self.perceptor.encode_text(t).float()
+
+    def prefetch(self, tokens):
+        """Encode the NEXT batch's prompts (main.py:733, frozen text tower, no dependence on the weights being
+        trained) on its own HIP stream, so the small fp32 GEMMs fill idle CUs under the current step's backward pass
+        instead of sitting on the critical path.  The following `__call__` / `forward_loss` with the same token tensor
+        picks the result up."""
+        if tokens is None or tokens.dtype != torch.long or not tokens.is_cuda:
+            return
+        if self._text_stream is None:
+            self._text_stream = torch.cuda.Stream()
+        side = self._text_stream
+        side.wait_stream(torch.cuda.current_stream())
+        tokens.record_stream(side)
+        with torch.cuda.stream(side), torch.no_grad():
+            feats = self.perceptor.encode_text(tokens).float()
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._prefetched = ((tokens.data_ptr(), tuple(tokens.shape)), feats, ev, tokens)
 
     def forward_loss(self, inp, out=None, facs=None, noise=None, aug_params=None):
         """main.py:729-811 -> (loss, intermediates)."""
@@ -294,8 +321,9 @@ class TrainStep:
             loss = loss + self.tv_coef * tv_loss(xr.permute(0, 3, 1, 2))        # :769-773,831 (optional, plain autograd)
         return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats}
 
-    def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None):
+    def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None, next_inp=None):
         loss, mid = self.forward_loss(inp, out, facs, noise, aug_params)
+        self.prefetch(next_inp)                                                 # next batch's text tower under this backward
         self.opt.zero_grad()                                                    # :825
         loss.backward()                                                         # :832
         if self.clip_grad_norm:
@@ -361,10 +389,18 @@ def train(config_file):
     for epoch in range(net.epoch, config.epochs):
         sampler.set_epoch(epoch)
         order = list(iter(sampler))
+        nxt = None
         for i in range(0, len(order), bs):
-            sel = torch.tensor(order[i:i + bs])
-            inp, out = data[0][sel].cuda(), data[1][sel].cuda()
-            loss, mid = stepper(inp, None if data[0] is data[1] else out)
+            if nxt is None:
+                sel = torch.tensor(order[i:i + bs])
+                nxt = (data[0][sel].cuda(), data[1][sel].cuda())
+            inp, out = nxt
+            nxt = None
+            if i + bs < len(order):                      # one batch of look-ahead for the text-tower prefetch
+                sel = torch.tensor(order[i + bs:i + 2 * bs])
+                nxt = (data[0][sel].cuda(), data[1][sel].cuda())
+            loss, mid = stepper(inp, None if data[0] is data[1] else out,
+                                next_inp=nxt[0] if (nxt is not None and data[0] is data[1]) else None)
             if step % log_interval == 0 or log_f is None:
                 (loss_r,) = hvd.allreduce_scalars(loss)
             else:

@@ -310,3 +310,24 @@ def test_other_mappers_match_oracle(cuda, kind, cdt):
     params = dict(net.named_parameters())
     worst = max(_relrms(params[k].grad, v.grad) for k, v in sd.items() if v.grad.abs().max() > 1e-6)
     assert worst < (2e-3 if cdt == F32 else 1.5e-1), f"worst param-grad rel-rms {worst}"   # bf16 operands at dim_head 20
+
+
+def test_text_prefetch_matches_inline(cuda):
+    """The side-stream text-tower prefetch hands the same features to the step as the inline encode."""
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(F32)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    t = tok.cuda()
+    inline = stepper.features(t).clone()
+    stepper.prefetch(t)
+    assert stepper._prefetched is not None
+    got = stepper.features(t)
+    assert stepper._prefetched is None
+    torch.cuda.synchronize()
+    assert torch.equal(got, inline)
+    other = t.clone()                       # a different tensor must not pick the stale prefetch up
+    stepper.prefetch(t)
+    assert torch.equal(stepper.features(other), inline) and stepper._prefetched is not None
+    l1, _ = stepper.forward_loss(t, facs=facs.cuda(), noise=noise.cuda())
+    stepper._prefetched = None
+    l2, _ = stepper.forward_loss(t, facs=facs.cuda(), noise=noise.cuda())
+    assert abs(l1.item() - l2.item()) < 1e-6
