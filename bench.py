@@ -54,7 +54,7 @@ def build(args, device):
     vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
     perceptor = fclip.CLIP(clip_sd, cdt)
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
-    if hvd.size() > 1:
+    if hvd.is_distributed():
         opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
         hvd.broadcast_parameters(net, root_rank=0)
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
@@ -175,7 +175,7 @@ def main():
     toks = fmain.synthetic_tokens(B * (args.steps + args.warmup + 1), seed=1234 + rank).to(device)
 
     def sync():
-        if world > 1:
+        if hvd.is_distributed():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -193,7 +193,7 @@ def main():
         it += 1
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if hvd.is_distributed():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -267,7 +267,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(sds, args.cutn, augs=args.augs)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if hvd.is_distributed():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -25,7 +25,10 @@ def init(backend=None):
     if _STATE["init"]:
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    # FFVC_DP_FORCE=1: build the process group even for one rank, so the whole exchange path (RCCL communicator, async
+    # bucket all-reduces, barrier) can be exercised on a single-GPU box
+    _STATE["force"] = os.environ.get("FFVC_DP_FORCE") == "1"
+    if (world > 1 or _STATE["force"]) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -40,7 +43,7 @@ def init(backend=None):
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _STATE.get("force", False))
 
 
 def rank():
@@ -168,11 +171,22 @@ class DistributedOptimizer:
             self._launch(b)
 
     def _launch(self, b):
-        if torch.cuda.is_available():
-            from . import ops
-            ops.join_side_stream()      # the bucket's weight gradients were written on the side stream
         s, e, _ = self.buckets[b]
         g = self.arena.grads[s:e]
+        if g.is_cuda:
+            # The bucket's weight gradients were written on the wgrad side stream, the rest on the main stream.  The
+            # exchange is enqueued FROM the side stream (after it has picked up the main stream's progress), so RCCL
+            # waits for both — and the main stream, which carries the dgrad chain, never waits for anything here.
+            from . import ops
+            side = ops._side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._enqueue(b, g)
+            ops._SIDE["dirty"] = True
+        else:
+            self._enqueue(b, g)
+
+    def _enqueue(self, b, g):
         if self.wire_dtype is not None and self.wire_dtype != g.dtype:
             w = g.to(self.wire_dtype)
             self._wire[b] = w
@@ -190,6 +204,8 @@ class DistributedOptimizer:
                 h.wait()
                 if b in self._wire:
                     s, e, _ = self.buckets[b]
+                    if self._wire[b].is_cuda:
+                        self._wire[b].record_stream(torch.cuda.current_stream())
                     self.arena.grads[s:e].copy_(self._wire[b])
         self._handles, self._wire = {}, {}
         self._pending = [len(idxs) for _, _, idxs in self.buckets]

@@ -1,0 +1,116 @@
+"""Data-parallel path with the real HIP kernels: two processes share cuda:0 and exchange gradients over gloo (RCCL
+refuses two ranks on one device; the collective itself is torch.distributed's, everything around it — flat bucket,
+side-stream joins, bucket readiness from fused wgrad / LayerNorm kernels, 1/N folded into Adam — is ours).
+DP-equivalence: two ranks x 2 prompts == one process x 4 prompts on identical noise / augmentation draws."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CLIP_CFG = dict(embed_dim=32, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8,
+                context_length=16, vocab_size=96, transformer_width=64, transformer_heads=1, transformer_layers=2)
+VQ_CFG = dict(ch=64, ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64,
+              out_ch=3, embed_dim=64, n_embed=128)
+CUTN, B = 4, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(3)
+    tok = torch.zeros(B, 16, dtype=torch.long)
+    for i, L in enumerate([3, 6, 9, 12]):
+        tok[i, 0] = 94
+        tok[i, 1:L] = torch.randint(1, 94, (L - 1,), generator=g)
+        tok[i, L] = 95
+    facs = torch.rand(CUTN, B, generator=g) * 0.1
+    noise = torch.randn(CUTN, B, 3, 32, 32, generator=g)
+    return tok, facs, noise
+
+
+def _run(rank, world, steps=2):
+    """-> flat parameter vector after `steps` optimizer steps on this rank's shard."""
+    from feed_forward_vqgan_clip_amd import clip as fclip
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    from feed_forward_vqgan_clip_amd import main as fmain
+    from feed_forward_vqgan_clip_amd import vqgan as fvq
+    from feed_forward_vqgan_clip_amd.optim import FusedAdam
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=64, depth=2, dropout=0, cutn=CUTN, batch_size=B // world,
+                       repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32", clip_dim=32, clip_size=32,
+                       model_type="mlp_mixer", vq_image_size=12, augs=["R"])
+    torch.manual_seed(5 + rank)                       # replicas start DIFFERENT: the broadcast has to repair them
+    net = fmain.build_model(cfg, 64).cuda().prepare(torch.float32)
+    vq = fvq.VQGAN(fvq.random_state_dict(VQ_CFG, 12), VQ_CFG, torch.float32)
+    perceptor = fclip.CLIP(fclip.random_state_dict(CLIP_CFG, 11), torch.float32)
+    opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    if world > 1:
+        opt = hvd.DistributedOptimizer(opt, bucket_bytes=64 << 10)
+        assert len(opt.buckets) >= 2
+        hvd.broadcast_parameters(net, root_rank=0)
+        hvd.broadcast_optimizer_state(opt, root_rank=0)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    tok, facs, noise = _inputs()
+    shard = slice(rank * (B // world), (rank + 1) * (B // world))
+    args = dict(facs=facs[:, shard].reshape(-1).cuda(), noise=noise[:, shard].reshape(-1, 3, 32, 32).cuda())
+    # step 1 by hand, to look at the exchanged gradient (the bucket holds the SUM over ranks; 1/N lives in Adam)
+    loss, _ = stepper.forward_loss(tok[shard].cuda(), **args)
+    opt.zero_grad()
+    loss.backward()
+    if world > 1:
+        opt.synchronize()
+        opt._synced = True
+    torch.cuda.synchronize()
+    grads = (net._ffvc_arena.grads.detach() / world).cpu().numpy().copy()
+    opt.step()
+    for _ in range(steps - 1):
+        loss, _ = stepper(tok[shard].cuda(), **args)
+    torch.cuda.synchronize()
+    return net._ffvc_arena.params.detach().cpu().numpy().copy(), float(loss), grads
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    hvd.init(backend="gloo")
+    assert hvd.size() == world and hvd.rank() == rank
+    params, loss, grads = _run(rank, world)
+    (l,) = hvd.allreduce_scalars(torch.tensor(loss, device="cuda"))
+    q.put((rank, params, float(l), grads))
+
+
+def test_dp_world2_equals_single_process(cuda):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert (res[0][1] == res[1][1]).all(), "replicas diverged"   # replicas stay bit-identical
+    torch.manual_seed(0)
+    ref, ref_loss, ref_grads = _run(0, 1)                      # rank-0 seed (5), all four prompts, no exchange
+    g, rg = torch.from_numpy(res[0][3]).double(), torch.from_numpy(ref_grads).double()
+    assert (res[0][3] == res[1][3]).all(), "exchanged gradients differ between ranks"
+    relrms = ((g - rg).pow(2).mean().sqrt() / rg.pow(2).mean().sqrt()).item()
+    assert relrms < 1e-4, relrms                               # averaged shard gradients == full-batch gradient
+    # Adam turns round-off on zero-gradient parameters into +-lr steps, so parameters are compared where the gradient
+    # is significant; two steps of lr = 1e-3
+    sig = rg.abs() > 1e-3 * rg.abs().max()
+    err = (torch.from_numpy(res[0][1]) - torch.from_numpy(ref)).abs()[sig].max().item()
+    assert err < 1e-4, f"parameter deviation {err}"        # (gradient check above is the strict one)
+    assert abs(res[0][2] - ref_loss) < 1e-3 * abs(ref_loss) + 1e-6, (res[0][2], ref_loss)
