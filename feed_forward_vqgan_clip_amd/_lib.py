@@ -90,9 +90,9 @@ _SIGNATURES = {
     "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_layernorm_bwd_blocks": (c_int, [c_int64]),
     "ffvc_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ffvc_layernorm_bwd_acc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ffvc_groupnorm_ws_bytes": (c_int64, [c_int, c_int, c_int]),
     "ffvc_groupnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_int, c_int, c_float, c_int, c_int, c_void_p]),

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
                                                      const float* __restrict__ rstd, const XT* __restrict__ dres,
                                                      XT* __restrict__ dx, float* __restrict__ part_g,
                                                      float* __restrict__ part_b, int64_t rows, int dim,
-                                                     int rows_per_block, int acc_mode) {
+                                                     int rows_per_block, int acc_mode, uint16_t* __restrict__ dx_lo) {
   constexpr int NIT = LN_MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
           for (int j = 0; j < VEC; ++j) o[j] += r[j];
         }
         st_vec<VEC>(dx + row * dim + idx, o);
+        if (dx_lo) st_vec<VEC>(dx_lo + row * dim + idx, o);   // bf16 copy for the GEMM that consumes this gradient
       }
     }
   }
@@ -752,25 +753,26 @@ extern "C" int ffvc_layernorm_bwd_blocks(int64_t rows) {
 
 static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                          const float* rstd, const void* dres, void* dx, float* part_g, float* part_b, int64_t rows,
-                         int dim, void* stream, int acc_mode);
+                         int dim, void* stream, int acc_mode, void* dx_lo);
 
 extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                                   const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
-                                  float* part_b, int64_t rows, int dim, void* stream) {
-  return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, part_g, part_b, rows, dim, stream, 0);
+                                  float* part_b, void* dx_lo, int64_t rows, int dim, void* stream) {
+  return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, part_g, part_b, rows, dim, stream, 0, dx_lo);
 }
 
 extern "C" int ffvc_layernorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                                       const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
-                                      float* dbeta, int64_t rows, int dim, void* stream) {
+                                      float* dbeta, void* dx_lo, int64_t rows, int dim, void* stream) {
   FFVC_CHECK_ARG(dgamma && dbeta, "ffvc_layernorm_bwd_acc: null gradient pointer");
-  return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, dim, stream, 1);
+  return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, dim, stream, 1, dx_lo);
 }
 
 static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                          const float* rstd, const void* dres, void* dx, float* part_g, float* part_b, int64_t rows,
-                         int dim, void* stream, int acc_mode) {
+                         int dim, void* stream, int acc_mode, void* dx_lo) {
   FFVC_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ffvc_layernorm_bwd: null pointer");
+  FFVC_CHECK_ARG(!dx_lo || x_dtype == FFVC_F32, "ffvc_layernorm_bwd: dx_lo (bf16 copy) only next to an fp32 dx");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
   FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
   hipStream_t st = (hipStream_t)stream;
@@ -782,11 +784,11 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
                 if (v4)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode);
+                                     dim, rpb, acc_mode, (uint16_t*)dx_lo);
                 else
                   hipLaunchKernelGGL((ln_bwd_kernel<1, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode);
+                                     dim, rpb, acc_mode, (uint16_t*)dx_lo);
               }));
   FFVC_LAUNCH_CHECK();
   return 0;

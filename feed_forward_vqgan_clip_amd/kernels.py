@@ -145,8 +145,12 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False):
-    """-> (dx [x.dtype], dgamma|None, dbeta|None)."""
+def _dx_lo(x, want_lo):
+    return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want_lo and x.dtype == torch.float32) else None
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, want_lo=False):
+    """-> (dx [x.dtype], dgamma|None, dbeta|None).  want_lo: also write a bf16 copy of an fp32 dx (`dx._ffvc_lo`)."""
     _need_cuda(dy, x, gamma)
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -154,13 +158,16 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False):
     if dres is not None and dres.dtype != x.dtype:
         raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
     pg = pb = None
+    lo = _dx_lo(x, want_lo)
     if want_param_grads:
         nb = _lib.load().ffvc_layernorm_bwd_blocks(rows)
         pg = torch.empty(nb, dim, dtype=torch.float32, device=x.device)
         pb = torch.empty(nb, dim, dtype=torch.float32, device=x.device)
     _call("ffvc_layernorm_bwd", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
-          gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(pg), _ptr(pb), rows, dim,
-          stream_ptr())
+          gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(pg), _ptr(pb),
+          _ptr(lo), rows, dim, stream_ptr())
+    if lo is not None:
+        dx._ffvc_lo = lo
     if not want_param_grads:
         return dx, None, None
     dg = torch.empty(dim, dtype=torch.float32, device=x.device)
@@ -170,7 +177,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False):
     return dx, dg, db
 
 
-def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_lo=False):
     """-> dx; dgamma / dbeta (fp32 [dim], contiguous) are accumulated in place."""
     _need_cuda(dy, x, gamma, dgamma, dbeta)
     dim = x.shape[-1]
@@ -180,9 +187,12 @@ def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
         raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
     if dgamma.dtype != torch.float32 or dbeta.dtype != torch.float32 or not dgamma.is_contiguous() or not dbeta.is_contiguous():
         raise TypeError("layernorm_bwd_acc: gradients must be contiguous fp32")
+    lo = _dx_lo(x, want_lo)
     _call("ffvc_layernorm_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
           gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
-          dbeta.data_ptr(), rows, dim, stream_ptr())
+          dbeta.data_ptr(), _ptr(lo), rows, dim, stream_ptr())
+    if lo is not None:
+        dx._ffvc_lo = lo
     return dx
 
 

@@ -14,6 +14,7 @@ Conventions
     norm's backward kernel as `dres` instead of being added by autograd.
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -137,8 +138,16 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None):
         W.on_grad(W)
 
 
+_LN_LO = os.environ.get("FFVC_LN_LO", "1") != "0"      # A/B switch for the fused bf16 gradient copy
+
+
 def _as(t, dtype):
-    return t if t.dtype == dtype else K.cast(t, dtype)
+    if t.dtype == dtype:
+        return t
+    lo = getattr(t, "_ffvc_lo", None)          # a producer kernel already wrote the low-precision copy (LayerNorm bwd)
+    if lo is not None and lo.dtype == dtype and lo.shape == t.shape:
+        return lo
+    return K.cast(t, dtype)
 
 
 def _contig(t):
@@ -322,12 +331,14 @@ class _LNForkFn(Function):
         dy = _contig(dy)
         if dres is not None:
             dres = _as(_contig(dres), x.dtype)
+        # fp32 residual stream under bf16 compute: the gradient leaving here feeds a bf16 GEMM next -> emit its copy now
+        lo = _LN_LO and x.dtype == torch.float32 and dy.dtype == torch.bfloat16
         if ctx.params is not None:
             gamma, beta = ctx.params
-            dx = K.layernorm_bwd_acc(dy, x, g, mean, rstd, _grad_buf(gamma), _grad_buf(beta), dres=dres)
+            dx = K.layernorm_bwd_acc(dy, x, g, mean, rstd, _grad_buf(gamma), _grad_buf(beta), dres=dres, want_lo=lo)
             gamma._ffvc_arena.grad_written(gamma, beta)
             return dx, None, None, None, None
-        dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=ctx.train)
+        dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=ctx.train, want_lo=lo)
         return dx, dg, db, None, None
 
 

@@ -125,17 +125,18 @@ int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
 int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int64_t rows, int dim, float eps, void* stream);
 /* dx = LN'(dy) (+ dres, same dtype as x/dx).  If part_g/part_b are given they receive
- * ffvc_layernorm_bwd_blocks(rows) partial rows of dgamma/dbeta (reduce with ffvc_colsum). */
+ * ffvc_layernorm_bwd_blocks(rows) partial rows of dgamma/dbeta (reduce with ffvc_colsum).  dx_lo (optional, only with
+ * an fp32 dx): a bf16 copy of dx written in the same pass, for the GEMM that consumes this gradient. */
 int ffvc_layernorm_bwd_blocks(int64_t rows);
 int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                        const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
-                       float* part_b, int64_t rows, int dim, void* stream);
+                       float* part_b, void* dx_lo, int64_t rows, int dim, void* stream);
 /* Same pass, but dgamma / dbeta ([dim] fp32, e.g. slices of the flat gradient bucket) are ACCUMULATED in place with one
  * fp32 atomic per column and workgroup: no partial rows, no follow-up reduction launches (mlp_mixer_pytorch.py:24-25,
  * cloob.py:153-174 LayerNorm parameter gradients under torch autograd). */
 int ffvc_layernorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                            const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
-                           float* dbeta, int64_t rows, int dim, void* stream);
+                           float* dbeta, void* dx_lo, int64_t rows, int dim, void* stream);
 
 /* Self-modulated LayerNorm of the VitGAN generator (vitgan.py:8-21): y = gamma_s*w*LN(hl) + beta_s*w with scalar
  * parameters gamma_s/beta_s (device pointers) and the per-token modulation w; hl, w fp32 [rows, dim].
