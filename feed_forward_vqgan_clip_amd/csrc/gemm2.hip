@@ -444,6 +444,160 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
 
+// ---- persistent variant of the ring kernel ------------------------------------------------------------------------------
+// One workgroup per CU slot walks work items w = blockIdx.x, + gridDim.x, ... (tile x batch x K-split).  The K loop is
+// ONE stream of stages across work items: while the last stage of an item is being multiplied, the DMA state is
+// re-initialised for the next item and its first stage is already on its way into the free half of the ring, so the
+// epilogue (stores, activations) of item i overlaps the first loads of item i+1 and no workgroup launch / drain sits
+// between tiles.  MEASURED (round 1): 5-8 % slower than the one-workgroup-per-tile launch on every shape of the step
+// (static striding loses the hardware's dynamic tile dispatch, the first barrier of an item waits for the previous
+// item's stores because vmcnt counts stores, and the longer-lived DMA state costs registers) -> kept behind
+// FFVC_PERSIST=1 for further work, off by default.
+struct WorkItem {
+  int m0, n0, zo, zi, zs, k_begin, k_end;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ WorkItem decode_work(const ffvc_gemm_desc& p, int w, int tiles_n, int n_tiles, int nbatch,
+                                                int ksplit_len, int gm) {
+  const int rest = w / n_tiles, t_lin = w - rest * n_tiles;
+  const int zs = rest / nbatch, zb = rest - zs * nbatch;
+  const int q = n_tiles >> 3, r = n_tiles & 7, xcd = t_lin & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t_lin >> 3);
+  int tm, tn;
+  if (gm > 1) {
+    const int width = gm * tiles_n;
+    const int grp = tile / width, rem = tile - grp * width;
+    const int first = grp * gm;
+    const int gsz = min(n_tiles / tiles_n - first, gm);
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
+  WorkItem it;
+  it.m0 = tm * BM;
+  it.n0 = tn * BN;
+  it.zo = zb / p.batch_inner;
+  it.zi = zb - it.zo * p.batch_inner;
+  it.zs = zs;
+  it.k_begin = zs * ksplit_len;
+  it.k_end = min(p.K, it.k_begin + ksplit_len);
+  return it;
+}
+
+template <int XMODE, int WMODE, int BM, int BN>
+__global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2p_kernel(
+    const ffvc_gemm_desc p, int tiles_n, int n_tiles, int nbatch, int total, int ksplit_len, int vec_ok,
+    const uint16_t* zero, int gm) {
+  constexpr int MT = BM / 64;
+  constexpr int NW = 2 * (BN / 64);
+  constexpr int XTILE = BM * 128, WTILE = BN * 128;
+  constexpr int STAGE = XTILE + WTILE;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+  int w = blockIdx.x;
+  if (w >= total) return;
+
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM, NW>,
+                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM, NW>, KMajorDma<BM, NW>>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN, NW>, KMajorDma<BN, NW>>::type;
+  XDma sx;
+  WDma sw;
+  auto init_dma = [&](const WorkItem& it) {
+    const uint16_t* xb = (const uint16_t*)p.x + it.zo * p.xbo + it.zi * p.xbi;
+    const uint16_t* wb = (const uint16_t*)p.w + it.zo * p.wbo + it.zi * p.wbi;
+    if constexpr (XMODE == FFVC_OP_CONV3X3)
+      sx.init(xb, it.m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+    else if constexpr (XMODE == FFVC_OP_TRANS)
+      sx.init(xb, p.ldx, it.m0, p.M, tid);
+    else
+      sx.init(xb, p.ldx, it.m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
+    if constexpr (WMODE == FFVC_OP_TRANS)
+      sw.init(wb, p.ldw, it.n0, p.N, tid);
+    else
+      sw.init(wb, p.ldw, it.n0, p.N, p.kseg, p.wkso, tid, 0, 0);
+  };
+
+  f32x16_t acc[2][MT];
+  auto compute = [&](const unsigned char* sX, const unsigned char* sW, auto&& between) {
+    u32x4_t fa[2][2], fb[2][MT];
+    auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rw = wn * 64 + t * 32 + l31;
+        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int rx = wm * (32 * MT) + t * 32 + l31;
+        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+      }
+    };
+    fetch(0, fa[0], fb[0]);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < 3) fetch(sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+      between(sub);
+    }
+  };
+
+  WorkItem cur = decode_work<BM, BN>(p, w, tiles_n, n_tiles, nbatch, ksplit_len, gm);
+  init_dma(cur);
+  sx.issue(smem, cur.k_begin, cur.k_end, zero, tid);
+  sw.issue(smem + XTILE, cur.k_begin, cur.k_end, zero, tid);
+  int g = 0;                                        // running stage count: ring half = g & 1
+  while (true) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    const int nk = (cur.k_end - cur.k_begin + BK - 1) / BK;
+    const int wnext = w + gridDim.x;
+    const bool has_next = wnext < total;
+    WorkItem nxt = cur;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      unsigned char* cb = smem + (g & 1) * STAGE;
+      unsigned char* nb = smem + ((g + 1) & 1) * STAGE;
+      ++g;
+      const bool last = kt + 1 == nk;
+      int kn = cur.k_begin + (kt + 1) * BK, ke = cur.k_end;
+      if (last && has_next) {
+        // every load of the current item has been issued: the DMA state can move on to the next item now (fragment
+        // registers are dead here), its first stage then streams in under this stage's MFMAs and the epilogue
+        nxt = decode_work<BM, BN>(p, wnext, tiles_n, n_tiles, nbatch, ksplit_len, gm);
+        init_dma(nxt);
+        kn = nxt.k_begin;
+        ke = nxt.k_end;
+      }
+      const bool more = !last || has_next;
+      compute(cb, cb + XTILE, [&](int sub) {
+        if (more && sub == 0) sx.issue(nb, kn, ke, zero, tid);
+        if (more && sub == 1) sw.issue(nb + XTILE, kn, ke, zero, tid);
+      });
+    }
+    if (vec_ok == 2)
+      ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi,
+                                                         smem + 2 * STAGE + wid * 4096, cur.zs);
+    else
+      ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi, 1, cur.zs);
+    if (!has_next) break;
+    cur = nxt;
+    w = wnext;
+  }
+}
+
 // 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
 // (X 33 KiB + W 16 KiB) so that two workgroups share a CU and alternate DMA / MFMA phases.
 // K order: kh (3) x 64-channel block (Cin/64) x kw (3); the X tile is (re)loaded only when (kh, block) changes.
@@ -562,6 +716,14 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
+  static int persist = -1, n_cu = 0;
+  if (persist < 0) {
+    const char* e = getenv("FFVC_PERSIST");
+    persist = e ? atoi(e) : 0;   // opt-in: measured 5-8 % SLOWER than one workgroup per tile (profiles/r01_gemm_micro.txt)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
   static int gm_opt = -1;
   if (gm_opt < 0) {
     const char* e = getenv("FFVC_TILE_GM");
@@ -572,6 +734,29 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   // shapes (tiles_n <= 16) are neutral to slightly worse, so they keep the row-major order
   int gm = gm_opt >= 0 && getenv("FFVC_TILE_GM") ? gm_opt : (tiles_n > 16 ? 4 : 1);
   if (gm > tiles_m) gm = tiles_m;
+  constexpr bool ring = !(BM == 256 && BN == 128);
+  if constexpr (ring) {
+    if (persist) {
+      const int64_t total = (int64_t)n_tiles * d.batch * split;
+      const int slots = n_cu * ((BM == 256) ? 1 : 2);
+      int pgrid = total < slots ? (int)total : slots;
+      static bool pattr_set = false;
+      if (!pattr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm2p_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        pattr_set = true;
+      }
+      if (total < (1ll << 31)) {
+        hipLaunchKernelGGL((gemm2p_kernel<XMODE, WMODE, BM, BN>), dim3(pgrid), dim3(nthreads), lds, st, d, tiles_n, n_tiles,
+                           d.batch, (int)total, ksplit_len, vec_ok, zero, gm);
+        hipError_t pe = hipGetLastError();
+        if (pe != hipSuccess) {
+          ffvc_set_error("gemm2p launch failed: %s", hipGetErrorString(pe));
+          return -(int)pe - 1000;
+        }
+        return 1;
+      }
+    }
+  }
   hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
                      vec_ok, zero, gm);
   hipError_t e = hipGetLastError();

@@ -83,10 +83,11 @@ __device__ __forceinline__ void epilogue_quad(const ffvc_gemm_desc& p, f32x4_t v
 
 template <typename T, int MT = 2, bool VEC_ONLY = false>
 __device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0, int wm,
-                                              int wn, int lane, int zo, int zi, int vec_ok) {
+                                              int wn, int lane, int zo, int zi, int vec_ok, int zs = -1) {
   const int l31 = lane & 31, h = lane >> 5;
   const int flags = p.flags;
-  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)blockIdx.z * p.slab_stride;
+  if (zs < 0) zs = blockIdx.z;    // split-K slab index (explicit for persistent kernels)
+  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)zs * p.slab_stride;
   const int64_t rbz = zo * p.rbo + zi * p.rbi;
   const int64_t abz = zo * p.abo + zi * p.abi;
 #pragma unroll
@@ -203,11 +204,13 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8 v, i
 // pad: this wave's 4 KiB of LDS.  Requires N % 8 == 0 and 16-byte aligned rows of y / aux / residual (host-checked).
 template <typename T, int MT>
 __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0,
-                                                   int wm, int wn, int lane, int zo, int zi, unsigned char* pad) {
+                                                   int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
+                                                   int zs = -1) {
   const int l31 = lane & 31, h = lane >> 5;
   const int rr = lane >> 2, cc = lane & 3;
   const int flags = p.flags;
-  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)blockIdx.z * p.slab_stride;
+  if (zs < 0) zs = blockIdx.z;
+  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)zs * p.slab_stride;
   const int64_t rbz = zo * p.rbo + zi * p.rbi;
   const int64_t abz = zo * p.abo + zi * p.abi;
   unsigned char* wr = pad + l31 * 128;
