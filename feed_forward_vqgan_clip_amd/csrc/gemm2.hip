@@ -450,9 +450,9 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 // re-initialised for the next item and its first stage is already on its way into the free half of the ring, so the
 // epilogue (stores, activations) of item i overlaps the first loads of item i+1 and no workgroup launch / drain sits
 // between tiles.  MEASURED (round 1): 5-8 % slower than the one-workgroup-per-tile launch on every shape of the step
-// (static striding loses the hardware's dynamic tile dispatch, the first barrier of an item waits for the previous
-// item's stores because vmcnt counts stores, and the longer-lived DMA state costs registers) -> kept behind
-// FFVC_PERSIST=1 for further work, off by default.
+// (static striding loses the hardware's dynamic tile dispatch and the longer-lived DMA state costs registers; a counted
+// vmcnt wait that lets the next item start without draining the previous item's stores did not change that) -> kept
+// behind FFVC_PERSIST=1|2 for further work, off by default.
 struct WorkItem {
   int m0, n0, zo, zi, zs, k_begin, k_end;
 };
@@ -490,7 +490,7 @@ __device__ __forceinline__ WorkItem decode_work(const ffvc_gemm_desc& p, int w, 
 template <int XMODE, int WMODE, int BM, int BN>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2p_kernel(
     const ffvc_gemm_desc p, int tiles_n, int n_tiles, int nbatch, int total, int ksplit_len, int vec_ok,
-    const uint16_t* zero, int gm) {
+    const uint16_t* zero, int gm, int exact) {
   constexpr int MT = BM / 64;
   constexpr int NW = 2 * (BN / 64);
   constexpr int XTILE = BM * 128, WTILE = BN * 128;
@@ -566,7 +566,18 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     const bool has_next = wnext < total;
     WorkItem nxt = cur;
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // First stage of a follow-up item: its DMA loads were issued BEFORE the previous item's epilogue stores.  vmcnt
+      // retires in issue order and counts stores too, so waiting for "at most 4*MT operations outstanding" (every
+      // wave issues at least that many row stores per epilogue when all tiles are interior: `exact`) releases the
+      // wave as soon as the loads have landed, without draining the stores.
+      if (kt == 0 && g > 0 && exact) {
+        if constexpr (MT == 4)
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __syncthreads();
       unsigned char* cb = smem + (g & 1) * STAGE;
       unsigned char* nb = smem + ((g + 1) & 1) * STAGE;
@@ -719,7 +730,7 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   static int persist = -1, n_cu = 0;
   if (persist < 0) {
     const char* e = getenv("FFVC_PERSIST");
-    persist = e ? atoi(e) : 0;   // opt-in: measured 5-8 % SLOWER than one workgroup per tile (profiles/r01_gemm_micro.txt)
+    persist = e ? atoi(e) : 0;   // 0 off | 1 every ring launch | 2 short reductions (K <= 512) with interior tiles only
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
@@ -736,7 +747,8 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   if (gm > tiles_m) gm = tiles_m;
   constexpr bool ring = !(BM == 256 && BN == 128);
   if constexpr (ring) {
-    if (persist) {
+    const bool interior = (d.M % BM) == 0 && (d.N % BN) == 0 && vec_ok == 2 && !(d.flags & (FFVC_F_OUT_F32 | FFVC_F_ACCUM_OUT | FFVC_F_ATOMIC_OUT));
+    if (persist == 1 || (persist == 2 && d.K <= 512 && interior && (int64_t)n_tiles * d.batch * split > n_cu)) {
       const int64_t total = (int64_t)n_tiles * d.batch * split;
       const int slots = n_cu * ((BM == 256) ? 1 : 2);
       int pgrid = total < slots ? (int)total : slots;
@@ -747,7 +759,7 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
       }
       if (total < (1ll << 31)) {
         hipLaunchKernelGGL((gemm2p_kernel<XMODE, WMODE, BM, BN>), dim3(pgrid), dim3(nthreads), lds, st, d, tiles_n, n_tiles,
-                           d.batch, (int)total, ksplit_len, vec_ok, zero, gm);
+                           d.batch, (int)total, ksplit_len, vec_ok, zero, gm, interior ? 1 : 0);
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) {
           ffvc_set_error("gemm2p launch failed: %s", hipGetErrorString(pe));
