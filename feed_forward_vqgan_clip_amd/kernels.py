@@ -46,6 +46,23 @@ def _need_cuda(*ts):
             raise _lib.FFVCError("ffvc kernels need CUDA(HIP) tensors; there is no CPU fallback")
 
 
+def _req(dtype, *ts, contiguous=True):
+    """Launcher-side contract of the raw-pointer ABI: device tensor, expected dtype, contiguous (None is allowed)."""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.FFVCError("ffvc kernels need CUDA(HIP) tensors; there is no CPU fallback")
+        if t.dtype != dtype:
+            raise TypeError(f"ffvc launcher: expected a {dtype} tensor, got {t.dtype}")
+        if contiguous and not t.is_contiguous():
+            raise TypeError("ffvc launcher: expected a contiguous tensor")
+
+
+def _req_f32(*ts):
+    _req(torch.float32, *ts)
+
+
 def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, bias=None,
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
@@ -134,6 +151,7 @@ def _call(name, *args):
 
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     """x: (..., dim) fp32|bf16 contiguous -> (y[out_dtype], mean, rstd)."""
+    _req_f32(gamma, beta)
     _need_cuda(x, gamma, beta)
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -151,6 +169,7 @@ def _dx_lo(x, want_lo):
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, want_lo=False):
     """-> (dx [x.dtype], dgamma|None, dbeta|None).  want_lo: also write a bf16 copy of an fp32 dx (`dx._ffvc_lo`)."""
+    _req_f32(gamma, mean, rstd)
     _need_cuda(dy, x, gamma)
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -179,6 +198,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, w
 
 def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_lo=False):
     """-> dx; dgamma / dbeta (fp32 [dim], contiguous) are accumulated in place."""
+    _req_f32(gamma, mean, rstd, dgamma, dbeta)
     _need_cuda(dy, x, gamma, dgamma, dbeta)
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -203,6 +223,8 @@ def _gn_ws(B, HW, G, dev):
 
 def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True):
     """x: NHWC (B, H, W, C) -> (y, mean[B,G], rstd[B,G])."""
+    _req_f32(gamma, beta)
+    _need_cuda(x)
     _need_cuda(x, gamma, beta)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -216,6 +238,8 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True):
 
 
 def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True):
+    _req_f32(gamma, beta, mean, rstd)
+    _need_cuda(dy, x, dres)
     _need_cuda(dy, x)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -228,12 +252,16 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True):
 
 
 def softmax_fwd(s, p, rows, cols, lds, ldp, scale=1.0, causal=False, q_len=0):
+    _req_f32(s)
+    _need_cuda(p)
     _call("ffvc_softmax_fwd", s.data_ptr(), p.data_ptr(), dtype_code(p.dtype), rows, cols, lds, ldp, scale, int(causal),
           q_len, stream_ptr())
     return p
 
 
 def softmax_bwd(p, dp, ds, rows, cols, ldp, lddp, scale=1.0):
+    _req_f32(dp)
+    _need_cuda(p, ds)
     _call("ffvc_softmax_bwd", p.data_ptr(), dp.data_ptr(), ds.data_ptr(), dtype_code(p.dtype), rows, cols, ldp, lddp,
           scale, stream_ptr())
     return ds
@@ -243,6 +271,7 @@ def softmax_bwd(p, dp, ds, rows, cols, ldp, lddp, scale=1.0):
 # glue
 # ---------------------------------------------------------------------------
 def cast(src, dtype):
+    _need_cuda(src)
     if src.dtype == dtype:
         return src
     _need_cuda(src)
@@ -253,6 +282,7 @@ def cast(src, dtype):
 
 
 def cast_into(src, dst):
+    _need_cuda(src, dst)
     _call("ffvc_cast", src.data_ptr(), dtype_code(src.dtype), dst.data_ptr(), dtype_code(dst.dtype), src.numel(),
           stream_ptr())
     return dst
@@ -260,6 +290,7 @@ def cast_into(src, dst):
 
 def transpose(src, out_dtype=None, out=None, pad_to=0):
     """src: (..., R, C) contiguous -> (..., C, max(R, pad_to)) (batched over leading dims; pad columns are zero)."""
+    _need_cuda(src, out)
     _need_cuda(src)
     R, C = src.shape[-2], src.shape[-1]
     Rp = max(R, pad_to)
@@ -314,6 +345,10 @@ def sln_bwd(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dres=None):
 
 
 def colsum(x, out, accumulate=False, ld=None):
+    _req_f32(out)
+    _need_cuda(x)
+    if out.numel() < x.shape[-1]:
+        raise ValueError('colsum: out is shorter than the number of columns')
     rows, cols = x.shape[0], x.shape[-1]
     rows = x.numel() // cols
     _call("ffvc_colsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), rows, cols, ld or cols, int(accumulate),
@@ -322,6 +357,7 @@ def colsum(x, out, accumulate=False, ld=None):
 
 
 def clamp_fwd(x, out_dtype, mul, add, lo, hi):
+    _need_cuda(x)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     _call("ffvc_clamp_fwd", x.data_ptr(), dtype_code(x.dtype), y.data_ptr(), dtype_code(out_dtype), x.numel(), mul, add,
           lo, hi, stream_ptr())
@@ -329,6 +365,7 @@ def clamp_fwd(x, out_dtype, mul, add, lo, hi):
 
 
 def clamp_bwd(x, g, mul, add, lo, hi):
+    _need_cuda(x, g)
     dx = torch.empty_like(x)
     _call("ffvc_clamp_bwd", x.data_ptr(), dtype_code(x.dtype), g.data_ptr(), dtype_code(g.dtype), dx.data_ptr(),
           x.numel(), mul, add, lo, hi, stream_ptr())
@@ -336,6 +373,7 @@ def clamp_bwd(x, g, mul, add, lo, hi):
 
 
 def sumpool2x2(src):
+    _need_cuda(src)
     B, H2, W2, C = src.shape
     dst = torch.empty(B, H2 // 2, W2 // 2, C, dtype=src.dtype, device=src.device)
     _call("ffvc_sumpool2x2", src.data_ptr(), dst.data_ptr(), dtype_code(src.dtype), B, H2 // 2, W2 // 2, C, stream_ptr())
@@ -343,6 +381,7 @@ def sumpool2x2(src):
 
 
 def rownorm_sq(x):
+    _req_f32(x)
     rows, dim = x.numel() // x.shape[-1], x.shape[-1]
     out = torch.empty(rows, dtype=torch.float32, device=x.device)
     _call("ffvc_rownorm_sq", x.data_ptr(), out.data_ptr(), rows, dim, stream_ptr())
@@ -350,6 +389,7 @@ def rownorm_sq(x):
 
 
 def vq_argmin(dot, xnorm, cnorm):
+    _req_f32(dot, xnorm, cnorm)
     rows, ncodes = dot.shape
     idx = torch.empty(rows, dtype=torch.int64, device=dot.device)
     _call("ffvc_vq_argmin", dot.data_ptr(), xnorm.data_ptr(), cnorm.data_ptr(), idx.data_ptr(), rows, ncodes, ncodes,
@@ -366,6 +406,7 @@ def gather_rows(table, idx, out_dtype, pos=None, period=0):
 
 
 def eot_gather(x, tokens):
+    _need_cuda(x, tokens)
     B, L, D = x.shape
     out = torch.empty(B, D, dtype=torch.float32, device=x.device)
     _call("ffvc_eot_gather", x.data_ptr(), dtype_code(x.dtype), tokens.data_ptr(), out.data_ptr(), B, L, D, stream_ptr())
@@ -373,6 +414,7 @@ def eot_gather(x, tokens):
 
 
 def cutouts_fwd(xr, cut, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
+    _req_f32(xr, noise, facs)
     B, H, W, _ = xr.shape
     g = cut // patch
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=xr.device)
@@ -382,6 +424,8 @@ def cutouts_fwd(xr, cut, cutn, patch, mean, std, out_dtype, noise=None, facs=Non
 
 
 def cutouts_bwd(xr, gout, cut, cutn, patch, std):
+    _req_f32(xr)
+    _need_cuda(gout)
     B, H, W, _ = xr.shape
     dxr = torch.empty_like(xr)
     _call("ffvc_cutouts_bwd", xr.data_ptr(), gout.data_ptr(), dtype_code(gout.dtype), dxr.data_ptr(), B, H, W, cut, cutn,
@@ -401,22 +445,30 @@ def spherical_loss(embed, feats, coef=1.0, want_grad=True):
 
 
 def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _req_f32(p, g, m, v)
+    _need_cuda(shadow)
     _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
           dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
           stream_ptr())
 
 
 def sumsq(x, out):
+    _req_f32(x, out)
     _call("ffvc_sumsq", x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr())
     return out
 
 
 def axpby(x, y, a, b):
+    _req_f32(x, y)
     _call("ffvc_axpby", x.data_ptr(), y.data_ptr(), x.numel(), a, b, stream_ptr())
     return y
 
 
 def rowsum(x, out, period, accumulate=False):
+    _req_f32(out)
+    _need_cuda(x)
+    if out.numel() < period:
+        raise ValueError('rowsum: out is shorter than the period')
     cols = x.shape[-1]
     _call("ffvc_rowsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), x.numel() // cols, cols, period,
           int(accumulate), stream_ptr())
@@ -424,6 +476,7 @@ def rowsum(x, out, period, accumulate=False):
 
 
 def copy_rows(src, src_stride, dst, dst_stride, rows, cols):
+    _req(torch.float32, src, dst, contiguous=False)      # row-strided views by design (explicit strides)
     _call("ffvc_copy_rows", src.data_ptr(), src_stride, dst.data_ptr(), dst_stride, rows, cols, stream_ptr())
     return dst
 
@@ -437,6 +490,7 @@ def im2col3x3(x, out_dtype, Kp):
 
 
 def mul_dev_scalar(x, s):
+    _req_f32(x, s)
     y = torch.empty_like(x)
     _call("ffvc_mul_dev_scalar", x.data_ptr(), s.data_ptr(), y.data_ptr(), x.numel(), stream_ptr())
     return y
@@ -461,6 +515,7 @@ def attn_small_ok(qkv, heads, causal):
 
 
 def attn_small_fwd(qkv, heads, scale):
+    _req(torch.bfloat16, qkv)
     B, T, D3 = qkv.shape
     o = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
     _call("ffvc_attn_small_fwd", qkv.data_ptr(), o.data_ptr(), B, T, heads, 64, float(scale), stream_ptr())
@@ -468,6 +523,9 @@ def attn_small_fwd(qkv, heads, scale):
 
 
 def attn_small_bwd(qkv, do, heads, scale):
+    _req(torch.bfloat16, qkv, do)
+    if do.shape[:2] != qkv.shape[:2] or do.shape[2] * 3 != qkv.shape[2]:
+        raise ValueError('attn_small_bwd: dout shape does not match qkv')
     B, T, D3 = qkv.shape
     dqkv = torch.empty_like(qkv)
     _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, T, heads, 64, float(scale),
@@ -481,6 +539,8 @@ def set_option(name, value):
 
 
 def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
+    _req_f32(pooled, pinv, ainv, cmat, noise, facs)
+    _req(torch.int32, erase)
     B, _, S, _ = pooled.shape
     g = S // patch
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
@@ -491,6 +551,9 @@ def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dty
 
 
 def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std):
+    _req_f32(pinv, ainv, cmat)
+    _req(torch.int32, erase)
+    _need_cuda(gout)
     dpooled = torch.empty(B, 3, S, S, dtype=torch.float32, device=gout.device)
     _call("ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
           erase.data_ptr(), dpooled.data_ptr(), B, S, cutn, patch, std[0], std[1], std[2], stream_ptr())

@@ -97,7 +97,18 @@ def test_dp_world2_equals_single_process(cuda):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    res = []
+    import queue as _queue
+    import time as _time
+    deadline = _time.time() + 600
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a worker died with exit code {dead}"          # fail fast instead of waiting out the timeout
+            assert _time.time() < deadline, "workers timed out"
+    res.sort(key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

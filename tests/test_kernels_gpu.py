@@ -302,3 +302,35 @@ def test_attention_small_fused(cuda, B, T, heads):
     o3 = ops.attention(x3, heads, scale)
     o3.backward(do)
     assert torch.equal(o3, o) and torch.equal(x3.grad, dqkv)
+
+
+def test_bad_arguments_fail_loudly(cuda):
+    """Every entry point validates its arguments and reports through ffvc_last_error (no silent fallback)."""
+    from feed_forward_vqgan_clip_amd._lib import FFVCError
+    x = _mk((4, 65, 3 * 64), torch.bfloat16, cuda, 1)                       # T = 65 > 64: outside the fused attention
+    assert not K.attn_small_ok(x, 1, False)
+    with pytest.raises(FFVCError, match="T <= 64"):
+        K.attn_small_fwd(x, 1, 0.125)
+    with pytest.raises(FFVCError):
+        K.layernorm_fwd(_mk((4, 5000), torch.float32, cuda, 1), _mk((5000,), torch.float32, cuda, 2),
+                        _mk((5000,), torch.float32, cuda, 3), torch.bfloat16)     # dim > 64 * LN_MAXE
+    with pytest.raises((FFVCError, TypeError)):
+        K.colsum(_mk((8, 8), torch.float32, cuda, 1), torch.zeros(8, dtype=torch.bfloat16, device=cuda))
+    with pytest.raises((FFVCError, RuntimeError, TypeError)):
+        K.cast(torch.zeros(4), torch.bfloat16)                                # CPU tensor: there is no CPU path
+
+
+def test_degenerate_sizes(cuda):
+    """Smallest legal problems: one row, one token, one image."""
+    y, mean, rstd = K.layernorm_fwd(_mk((1, 8), torch.float32, cuda, 1), torch.ones(8, device=cuda), torch.zeros(8, device=cuda),
+                                    torch.float32)
+    assert abs(y.mean().item()) < 1e-5
+    qkv = _mk((1, 1, 192), torch.bfloat16, cuda, 2)                           # one token attends to itself: o == v
+    o = K.attn_small_fwd(qkv, 1, 0.125)
+    assert torch.equal(o.view(-1), qkv.view(-1)[128:])
+    dq = K.attn_small_bwd(qkv, o, 1, 0.125)
+    assert dq[..., :128].abs().max().item() == 0 and torch.equal(dq.view(-1)[128:], o.view(-1))
+    m = _mk((1, 4), torch.bfloat16, cuda, 3)
+    out = torch.zeros(4, device=cuda)
+    K.colsum(m, out)
+    assert torch.equal(out, m.float().view(-1))
