@@ -128,6 +128,69 @@ __device__ __forceinline__ void store8(float* p, const f32x8& r) {
   *(f32x4_t*)(p + 4) = b;
 }
 
+// Non-temporal (streaming) variants for one-pass HBM-bound kernels (`nt` cache policy): enabled per file with
+// -DFFVC_STREAM_NT=1.
+#if defined(FFVC_STREAM_NT) && FFVC_STREAM_NT
+__device__ __forceinline__ f32x4_t load4s(const uint16_t* p) {
+  u32x2_t v = __builtin_nontemporal_load((const u32x2_t*)p);
+  f32x4_t r;
+  r[0] = __uint_as_float(v[0] << 16);
+  r[1] = __uint_as_float(v[0] & 0xffff0000u);
+  r[2] = __uint_as_float(v[1] << 16);
+  r[3] = __uint_as_float(v[1] & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ f32x4_t load4s(const float* p) { return __builtin_nontemporal_load((const f32x4_t*)p); }
+__device__ __forceinline__ void store4s(uint16_t* p, f32x4_t v) {
+  u32x2_t o;
+  o[0] = pack_bf16x2(v[0], v[1]);
+  o[1] = pack_bf16x2(v[2], v[3]);
+  __builtin_nontemporal_store(o, (u32x2_t*)p);
+}
+__device__ __forceinline__ void store4s(float* p, f32x4_t v) { __builtin_nontemporal_store(v, (f32x4_t*)p); }
+__device__ __forceinline__ f32x8 load8s(const uint16_t* p) {
+  u32x4_t u = __builtin_nontemporal_load((const u32x4_t*)p);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __uint_as_float(u[i] << 16);
+    r.v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+  }
+  return r;
+}
+__device__ __forceinline__ f32x8 load8s(const float* p) {
+  f32x4_t a = __builtin_nontemporal_load((const f32x4_t*)p), b = __builtin_nontemporal_load((const f32x4_t*)(p + 4));
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[i] = a[i];
+    r.v[4 + i] = b[i];
+  }
+  return r;
+}
+__device__ __forceinline__ void store8s(uint16_t* p, const f32x8& r) {
+  u32x4_t u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = pack_bf16x2(r.v[2 * i], r.v[2 * i + 1]);
+  __builtin_nontemporal_store(u, (u32x4_t*)p);
+}
+__device__ __forceinline__ void store8s(float* p, const f32x8& r) {
+  f32x4_t a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = r.v[i];
+    b[i] = r.v[4 + i];
+  }
+  __builtin_nontemporal_store(a, (f32x4_t*)p);
+  __builtin_nontemporal_store(b, (f32x4_t*)(p + 4));
+}
+#else
+#define load4s load4
+#define store4s store4
+#define load8s load8
+#define store8s store8
+#endif
+
 // ---- wave / block reductions ---------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
