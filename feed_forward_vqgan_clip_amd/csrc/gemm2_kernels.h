@@ -1,0 +1,679 @@
+// gemm2_kernels.h — kernel templates and launchers of the LDS-DMA GEMM path; included by gemm2.hip (K-major x
+// K-major, conv row tile, dispatch) and gemm2_modes.hip (the other operand-mode pairs) so the two translation
+// units compile in parallel.  See gemm2.hip for the design notes.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int EPC = 8;                         // bf16 per 16-byte chunk
+// An operand tile of ROWS rows is ROWS x 128 B (K-major) == 64 x (2*ROWS) B (reduction-major): ROWS/32 DMA pieces
+// per thread per K step.  The W tile is always 128 rows; the X tile 128 or 256 (block tile BM x 128).
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+__device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)lds_wave_base, 16, 0, 0);
+}
+
+// ---- K-major operand: 4 DMA pieces per thread per K step ------------------------------------------------
+// piece j of wave w covers LDS chunk positions p = (4j + w) * 64 + lane; line = p >> 4, slot = p & 15,
+// source chunk c' = slot ^ (line & 15): row = 2 * line + (c' >> 3), k-chunk = c' & 7.
+template <int ROWS, int NW>
+struct KMajorDma {
+  static constexpr int NP = ROWS / (8 * NW);   // 1-KiB DMA pieces per thread per K step
+  // position p = (4j + w) * 64 + lane  ->  line = p >> 4 = 16 j + 4 w + (lane >> 4), so (line & 15) and therefore the
+  // source k-chunk are the SAME for every piece j, and the source row advances by exactly 32 per piece: the whole
+  // per-thread state is one row pointer, the k-chunk offset and the first row index.
+  const uint16_t* row0p;   // pointer to (first row, k = 0)
+  int64_t step;            // elements between piece j and j + 1 (32 rows), when the row map is linear
+  int r0, rows, kc;
+  int kseg, mi;
+  int64_t kso, ld, so;
+  const uint16_t* base;
+  __device__ __forceinline__ void init(const uint16_t* base_, int64_t ld_, int row0, int rows_, int kseg_, int64_t kso_,
+                                       int tid, int mi_, int64_t so_) {
+    const int lane = tid & 63, w = tid >> 6;
+    const int line = 4 * w + (lane >> 4);        // + 4*NW per piece: (line & 15) is piece-independent (4*NW % 16 == 0)
+    const int cp = (lane & 15) ^ (line & 15);
+    r0 = row0 + 2 * line + (cp >> 3);
+    kc = (cp & 7) * EPC;
+    rows = rows_;
+    kseg = kseg_;
+    kso = kso_;
+    ld = ld_;
+    mi = mi_;
+    so = so_;
+    base = base_;
+    step = (8 * NW) * ld_;
+    const int rr = r0 < rows ? r0 : 0;
+    row0p = base + (int64_t)rr * ld_;
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+    const int64_t koff = (kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0) + kc;
+    const bool kok = k0 + kc + EPC <= kend;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int r = r0 + (8 * NW) * j;
+      const bool ok = kok && r < rows;
+      const uint16_t* src;
+      if (mi)
+        src = base + (int64_t)(r / mi) * so + (int64_t)(r % mi) * ld + koff;
+      else
+        src = row0p + j * step + koff;
+      dma16(ok ? (const void*)src : (const void*)zero, tile + (NW * j + w) * 1024);
+    }
+  }
+};
+
+// ---- implicit im2col (3x3, pad 1, optional fused nearest 2x upsample) ------------------------------------
+template <int ROWS, int NW>
+struct ConvDma {
+  static constexpr int NP = ROWS / (8 * NW);
+  const uint16_t* base;
+  int pix[NP], oy[NP], ox[NP], kc[NP];
+  bool rvalid[NP];
+  int H, W, Win, Cin, ups;
+  __device__ __forceinline__ void init(const uint16_t* base_, int row0, int rows, int H_, int W_, int Cin_, int ups_,
+                                       int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    base = base_;
+    H = H_;
+    W = W_;
+    Cin = Cin_;
+    ups = ups_;
+    Win = W_ >> ups_;
+    const int Hin = H_ >> ups_;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = (NW * j + w) * 64 + lane;
+      const int line = p >> 4, cp = (p & 15) ^ (line & 15);
+      const int r = row0 + 2 * line + (cp >> 3);
+      kc[j] = (cp & 7) * EPC;
+      rvalid[j] = r < rows;
+      const int rr = rvalid[j] ? r : 0;
+      const int b = rr / (H * W);
+      const int rem = rr - b * (H * W);
+      oy[j] = rem / W;
+      ox[j] = rem - oy[j] * W;
+      pix[j] = b * Hin * Win;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int /*kend*/, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+    const int tap = k0 / Cin;
+    const int ci0 = k0 - tap * Cin;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
+      const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (NW * j + w) * 1024);
+    }
+  }
+};
+
+// ---- 3x3 conv, haloed row tile ----------------------------------------------------------------------------
+// When 256 % W == 0 a 256-pixel output tile is R = 256/W whole image rows.  For one kernel row kh and one
+// 64-channel block the LDS tile holds those R input rows WITH a one-pixel halo on both sides:
+//     tile_row = seg * (W + 2) + (ix + 1),   ix = -1 .. W,   seg = 0 .. R-1        (<= 264 rows of 128 B)
+// and serves the three kw taps by fragment reads shifted by kw rows: the activation is fetched from L2 3x per
+// (kh, channel block) less often than with the generic im2col loader (9 taps -> 3 row loads).
+struct ConvRowDma {
+  static constexpr int NP = 9;      // ceil(264 * 8 / 256) 1-KiB pieces per thread
+  const uint16_t* base;
+  int rowinfo[NP];                  // (seg << 16) | (ix + 1), or -1 when the position is beyond the tile
+  int kc;
+  int H, W, Win, Hin, Cin, ups, img, oy0;
+  __device__ __forceinline__ void init(const uint16_t* base_, int m0, int H_, int W_, int Cin_, int ups_, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    base = base_;
+    H = H_;
+    W = W_;
+    Cin = Cin_;
+    ups = ups_;
+    Win = W_ >> ups_;
+    Hin = H_ >> ups_;
+    img = m0 / (H * W);
+    oy0 = (m0 - img * (H * W)) / W;
+    const int line = 4 * w + (lane >> 4);
+    const int cp = (lane & 15) ^ (line & 15);
+    kc = (cp & 7) * EPC;
+    const int r0 = 2 * line + (cp >> 3);
+    const int tr = (256 / W) * (W + 2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int r = r0 + 32 * j;
+      rowinfo[j] = r < tr ? (((r / (W + 2)) << 16) | (r % (W + 2))) : -1;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int kh, int ci0, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      if (rowinfo[j] < 0) continue;                      // exec-masked lanes simply do not write
+      const int seg = rowinfo[j] >> 16, ix = (rowinfo[j] & 0xffff) - 1;
+      const int iy = oy0 + seg + kh - 1;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int64_t off = ((int64_t)((img * Hin + (iy >> ups)) * Win + (ix >> ups))) * Cin + ci0 + kc;
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (4 * j + w) * 1024);
+    }
+  }
+};
+
+// ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
+// source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
+template <int ROWS, int NW>
+struct TransDma {
+  static constexpr int NP = ROWS / (8 * NW);
+  static constexpr int CPR = ROWS / 8;      // 16-byte chunks per k-row
+  const uint16_t* colp[NP];
+  int krow[NP];
+  bool cvalid[NP];
+  int64_t ld;
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld_, int col0, int cols, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    ld = ld_;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = (NW * j + w) * 64 + lane;
+      krow[j] = p / CPR;
+      const int c = col0 + (((p % CPR) ^ ((krow[j] & 3) << 2)) * EPC);
+      cvalid[j] = c + EPC <= cols;
+      colp[j] = base + (cvalid[j] ? c : 0);
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int k = k0 + krow[j];
+      const bool ok = cvalid[j] && k < kend;
+      dma16(ok ? (const void*)(colp[j] + (int64_t)k * ld) : (const void*)zero, tile + (NW * j + w) * 1024);
+    }
+  }
+};
+
+// ---- fragment reads (one 16-byte chunk = 8 bf16, k = 16*sub + 8*h + e) -----------------------------------
+__device__ __forceinline__ u32x4_t frag_kmajor(const unsigned char* tile, int row, int sub, int lane) {
+  const int line = row >> 1;
+  const int cp = (((row & 1) << 3) | (2 * sub + (lane >> 5))) ^ (line & 15);
+  return *(const u32x4_t*)(tile + line * 256 + cp * 16);
+}
+template <int ROWS>
+__device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row, int sub, int lane) {
+  constexpr int RS = ROWS * 2;   // bytes per k-row
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const int c = lane & 15;
+  const int i = (row - (lane & 31)) + 16 * ((lane >> 4) & 1) + (c & 3) * 4;      // column of this lane's 4 elements
+  const int k = 16 * sub + 8 * (lane >> 5) + (c >> 2);                          // k & 3 == c >> 2 for both reads
+  const int slot = (i >> 3) ^ ((k & 3) << 2);
+  const unsigned char* a0 = tile + k * RS + slot * 16 + (i & 7) * 2;
+  union {
+    s16x4_t hh[2];
+    u32x4_t v;
+  } u;
+  u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * RS));
+  return u.v;
+}
+
+__device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  union {
+    u32x4_t u;
+    bf16x8_t h;
+  } ua, ub;
+  ua.u = a;
+  ub.u = b;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+}
+
+// Tile configurations (BM x BN, waves as 2(M) x BN/64(N), wave tile (BM/2) x 64):
+//   128x128: 4 waves x 64x64,  2-stage ring (64 KiB),  2 workgroups / CU            -- small / ragged grids
+//   256x128: 4 waves x 128x64, ONE stage (48 KiB), <=256 regs, 2 workgroups / CU alternate load / MFMA
+//   256x256: 8 waves x 128x64, 2-stage ring (128 KiB), <=256 regs, 1 workgroup / CU = 2 waves / SIMD; 128 FLOP per
+//            L2 byte, the only shape that is not capped by the ~53 B/clk a CU can pull from L2.
+#ifdef FFVC_NO_FRAG_PREFETCH_256
+constexpr bool FRAG_PREFETCH_256 = false;
+#else
+constexpr bool FRAG_PREFETCH_256 = true;   // 256-row tiles also fetch fragments one sub-step ahead (two register sets)
+#endif
+#ifndef FFVC_EXP_MODE
+#define FFVC_EXP_MODE 0     // timing experiments only (wrong results): 1 = no DMA after the first stage, 2 = no vmcnt wait / barrier
+#endif
+#ifdef FFVC_NO_DMA_SPREAD
+constexpr bool DMA_SPREAD = false;
+#else
+constexpr bool DMA_SPREAD = true;
+#endif
+#ifdef FFVC_EXP_SKIPFRAG
+constexpr bool EXP_SKIP = true;    // timing experiment only (wrong results): emulate the LDS traffic of 128x128 wave tiles
+#else
+constexpr bool EXP_SKIP = false;
+#endif
+template <int XMODE, int WMODE, int BM, int BN>
+__global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2_kernel(
+    const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero, int gm) {
+  constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
+  constexpr int NW = 2 * (BN / 64);                  // waves per workgroup
+  constexpr int XTILE = BM * 128, WTILE = BN * 128;  // bytes
+  constexpr int STAGE = XTILE + WTILE;
+  constexpr bool RING = !(BM == 256 && BN == 128);   // 2-stage ring except for the single-stage 256x128 variant
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // Tiles are walked in groups of `gm` tile-rows, column-major inside a group: the ~32 workgroups that run together on
+  // one XCD then cover a compact gm x (32/gm) block of C and share gm + 32/gm operand panels through that XCD's L2
+  // instead of 1 + 32 (row-major order), which is what the fabric behind the L2s has to deliver.
+  int tm, tn;
+  if (gm > 1) {
+    const int width = gm * tiles_n;
+    const int grp = tile / width, rem = tile - grp * width;
+    const int first = grp * gm;
+    const int gsz = min(n_tiles / tiles_n - first, gm);
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+  const int k_begin = blockIdx.z * ksplit_len;
+  const int k_end = min(p.K, k_begin + ksplit_len);
+  const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
+  const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
+
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM, NW>,
+                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM, NW>, KMajorDma<BM, NW>>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN, NW>, KMajorDma<BN, NW>>::type;
+  XDma sx;
+  WDma sw;
+  if constexpr (XMODE == FFVC_OP_CONV3X3)
+    sx.init(xb, m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  else if constexpr (XMODE == FFVC_OP_TRANS)
+    sx.init(xb, p.ldx, m0, p.M, tid);
+  else
+    sx.init(xb, p.ldx, m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
+  if constexpr (WMODE == FFVC_OP_TRANS)
+    sw.init(wb, p.ldw, n0, p.N, tid);
+  else
+    sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid, 0, 0);
+
+  f32x16_t acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  // `between(sub)` runs after the MFMAs of sub-step `sub` have been issued: the ring loop uses it to spread the next
+  // stage's DMA issue over the first sub-steps, so the matrix pipe already has work queued while a wave is busy issuing
+  // loads (issued in one burst right after the barrier, both waves of a SIMD leave the pipe idle for that long).
+  auto compute = [&](const unsigned char* sX, const unsigned char* sW, auto&& between) {
+    if constexpr (BM == 256 && !FRAG_PREFETCH_256) {
+      // one fragment set (register budget): the partner wave on the SIMD covers the LDS latency
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        u32x4_t fa[2], fb[MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rw = wn * 64 + t * 32 + l31;
+          fa[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int rx = wm * (32 * MT) + t * 32 + l31;
+          if (EXP_SKIP && t >= 2) { fb[t] = fb[t - 2]; continue; }
+          fb[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[a], fb[b]);
+        between(sub);
+      }
+    } else {
+      // fragments are fetched one sub-step ahead of the MFMAs that consume them (two register sets)
+      u32x4_t fa[2][2], fb[2][MT];
+      auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rw = wn * 64 + t * 32 + l31;
+          a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int rx = wm * (32 * MT) + t * 32 + l31;
+          b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+        }
+      };
+      fetch(0, fa[0], fb[0]);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        if (sub < 3) fetch(sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+        between(sub);
+      }
+    }
+  };
+  if constexpr (!RING) {
+    for (int kt = 0; kt < nk; ++kt) {
+      sx.issue(smem, k_begin + kt * BK, k_end, zero, tid);
+      sw.issue(smem + XTILE, k_begin + kt * BK, k_end, zero, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(smem, smem + XTILE, [](int) {});
+      __syncthreads();
+    }
+  } else {
+    if (nk > 0) {
+      sx.issue(smem, k_begin, k_end, zero, tid);
+      sw.issue(smem + XTILE, k_begin, k_end, zero, tid);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      if (FFVC_EXP_MODE != 2 || kt == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      unsigned char* cur = smem + (kt & 1) * STAGE;
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      const bool more = (kt + 1 < nk) && FFVC_EXP_MODE != 1;
+      const int kn = k_begin + (kt + 1) * BK;
+      if (DMA_SPREAD) {
+        compute(cur, cur + XTILE, [&](int sub) {
+          if (more && sub == 0) sx.issue(nxt, kn, k_end, zero, tid);
+          if (more && sub == 1) sw.issue(nxt + XTILE, kn, k_end, zero, tid);
+        });
+      } else {
+        if (more) {
+          sx.issue(nxt, kn, k_end, zero, tid);
+          sw.issue(nxt + XTILE, kn, k_end, zero, tid);
+        }
+        compute(cur, cur + XTILE, [](int) {});
+      }
+    }
+  }
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, m0, n0, wm, wn, lane, zo, zi,
+                                                       smem + (RING ? 2 : 1) * STAGE + wid * 4096);
+  else
+    ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
+}
+
+#ifdef FFVC_BUILD_PERSIST   // opt-in build (adds ~2 min of compile time): make CXXEXTRA=-DFFVC_BUILD_PERSIST
+// ---- persistent variant of the ring kernel ------------------------------------------------------------------------------
+// One workgroup per CU slot walks work items w = blockIdx.x, + gridDim.x, ... (tile x batch x K-split).  The K loop is
+// ONE stream of stages across work items: while the last stage of an item is being multiplied, the DMA state is
+// re-initialised for the next item and its first stage is already on its way into the free half of the ring, so the
+// epilogue (stores, activations) of item i overlaps the first loads of item i+1 and no workgroup launch / drain sits
+// between tiles.  MEASURED (round 1): 5-8 % slower than the one-workgroup-per-tile launch on every shape of the step
+// (static striding loses the hardware's dynamic tile dispatch and the longer-lived DMA state costs registers; a counted
+// vmcnt wait that lets the next item start without draining the previous item's stores did not change that) -> kept
+// behind FFVC_PERSIST=1|2 for further work, off by default.
+struct WorkItem {
+  int m0, n0, zo, zi, zs, k_begin, k_end;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ WorkItem decode_work(const ffvc_gemm_desc& p, int w, int tiles_n, int n_tiles, int nbatch,
+                                                int ksplit_len, int gm) {
+  const int rest = w / n_tiles, t_lin = w - rest * n_tiles;
+  const int zs = rest / nbatch, zb = rest - zs * nbatch;
+  const int q = n_tiles >> 3, r = n_tiles & 7, xcd = t_lin & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t_lin >> 3);
+  int tm, tn;
+  if (gm > 1) {
+    const int width = gm * tiles_n;
+    const int grp = tile / width, rem = tile - grp * width;
+    const int first = grp * gm;
+    const int gsz = min(n_tiles / tiles_n - first, gm);
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
+  WorkItem it;
+  it.m0 = tm * BM;
+  it.n0 = tn * BN;
+  it.zo = zb / p.batch_inner;
+  it.zi = zb - it.zo * p.batch_inner;
+  it.zs = zs;
+  it.k_begin = zs * ksplit_len;
+  it.k_end = min(p.K, it.k_begin + ksplit_len);
+  return it;
+}
+
+template <int XMODE, int WMODE, int BM, int BN>
+__global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2p_kernel(
+    const ffvc_gemm_desc p, int tiles_n, int n_tiles, int nbatch, int total, int ksplit_len, int vec_ok,
+    const uint16_t* zero, int gm, int exact) {
+  constexpr int MT = BM / 64;
+  constexpr int NW = 2 * (BN / 64);
+  constexpr int XTILE = BM * 128, WTILE = BN * 128;
+  constexpr int STAGE = XTILE + WTILE;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+  int w = blockIdx.x;
+  if (w >= total) return;
+
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM, NW>,
+                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM, NW>, KMajorDma<BM, NW>>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN, NW>, KMajorDma<BN, NW>>::type;
+  XDma sx;
+  WDma sw;
+  auto init_dma = [&](const WorkItem& it) {
+    const uint16_t* xb = (const uint16_t*)p.x + it.zo * p.xbo + it.zi * p.xbi;
+    const uint16_t* wb = (const uint16_t*)p.w + it.zo * p.wbo + it.zi * p.wbi;
+    if constexpr (XMODE == FFVC_OP_CONV3X3)
+      sx.init(xb, it.m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+    else if constexpr (XMODE == FFVC_OP_TRANS)
+      sx.init(xb, p.ldx, it.m0, p.M, tid);
+    else
+      sx.init(xb, p.ldx, it.m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
+    if constexpr (WMODE == FFVC_OP_TRANS)
+      sw.init(wb, p.ldw, it.n0, p.N, tid);
+    else
+      sw.init(wb, p.ldw, it.n0, p.N, p.kseg, p.wkso, tid, 0, 0);
+  };
+
+  f32x16_t acc[2][MT];
+  auto compute = [&](const unsigned char* sX, const unsigned char* sW, auto&& between) {
+    u32x4_t fa[2][2], fb[2][MT];
+    auto fetch = [&](int sub, u32x4_t (&a)[2], u32x4_t (&b)[MT]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rw = wn * 64 + t * 32 + l31;
+        a[t] = (WMODE == FFVC_OP_TRANS) ? frag_trans<BN>(sW, rw, sub, lane) : frag_kmajor(sW, rw, sub, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int rx = wm * (32 * MT) + t * 32 + l31;
+        b[t] = (XMODE == FFVC_OP_TRANS) ? frag_trans<BM>(sX, rx, sub, lane) : frag_kmajor(sX, rx, sub, lane);
+      }
+    };
+    fetch(0, fa[0], fb[0]);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < 3) fetch(sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+      between(sub);
+    }
+  };
+
+  WorkItem cur = decode_work<BM, BN>(p, w, tiles_n, n_tiles, nbatch, ksplit_len, gm);
+  init_dma(cur);
+  sx.issue(smem, cur.k_begin, cur.k_end, zero, tid);
+  sw.issue(smem + XTILE, cur.k_begin, cur.k_end, zero, tid);
+  int g = 0;                                        // running stage count: ring half = g & 1
+  while (true) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    const int nk = (cur.k_end - cur.k_begin + BK - 1) / BK;
+    const int wnext = w + gridDim.x;
+    const bool has_next = wnext < total;
+    WorkItem nxt = cur;
+    for (int kt = 0; kt < nk; ++kt) {
+      // First stage of a follow-up item: its DMA loads were issued BEFORE the previous item's epilogue stores.  vmcnt
+      // retires in issue order and counts stores too, so waiting for "at most 4*MT operations outstanding" (every
+      // wave issues at least that many row stores per epilogue when all tiles are interior: `exact`) releases the
+      // wave as soon as the loads have landed, without draining the stores.
+      if (kt == 0 && g > 0 && exact) {
+        if constexpr (MT == 4)
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      unsigned char* cb = smem + (g & 1) * STAGE;
+      unsigned char* nb = smem + ((g + 1) & 1) * STAGE;
+      ++g;
+      const bool last = kt + 1 == nk;
+      int kn = cur.k_begin + (kt + 1) * BK, ke = cur.k_end;
+      if (last && has_next) {
+        // every load of the current item has been issued: the DMA state can move on to the next item now (fragment
+        // registers are dead here), its first stage then streams in under this stage's MFMAs and the epilogue
+        nxt = decode_work<BM, BN>(p, wnext, tiles_n, n_tiles, nbatch, ksplit_len, gm);
+        init_dma(nxt);
+        kn = nxt.k_begin;
+        ke = nxt.k_end;
+      }
+      const bool more = !last || has_next;
+      compute(cb, cb + XTILE, [&](int sub) {
+        if (more && sub == 0) sx.issue(nb, kn, ke, zero, tid);
+        if (more && sub == 1) sw.issue(nb + XTILE, kn, ke, zero, tid);
+      });
+    }
+    if (vec_ok == 2)
+      ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi,
+                                                         smem + 2 * STAGE + wid * 4096, cur.zs);
+    else
+      ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi, 1, cur.zs);
+    if (!has_next) break;
+    cur = nxt;
+    w = wnext;
+  }
+}
+
+#endif  // FFVC_BUILD_PERSIST
+
+template <int XMODE, int WMODE, int BM, int BN>
+int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
+  const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
+  const int n_tiles = tiles_m * tiles_n;
+  int split = d.split_k < 1 ? 1 : d.split_k;
+  const int ksteps = ceil_div(d.K, BK);
+  if (split > ksteps) split = ksteps < 1 ? 1 : ksteps;
+  const int ksplit_len = ceil_div(ksteps, split) * BK;
+  split = ceil_div(d.K, ksplit_len);
+  if (split < 1) split = 1;
+  dim3 grid(n_tiles, d.batch, split);
+  constexpr int nthreads = 64 * 2 * (BN / 64);
+  // stage ring + one 4 KiB row-store pad per wave (256x256: 128 + 32 = all 160 KiB of the CU)
+  constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128) + 2 * (BN / 64) * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  static int persist = -1, n_cu = 0;
+  if (persist < 0) {
+    const char* e = getenv("FFVC_PERSIST");
+    persist = e ? atoi(e) : 0;   // 0 off | 1 every ring launch | 2 short reductions (K <= 512) with interior tiles only
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  static int gm_opt = -1;
+  if (gm_opt < 0) {
+    const char* e = getenv("FFVC_TILE_GM");
+    gm_opt = e ? atoi(e) : 4;
+  }
+  // workgroups resident per XCD: 32 CUs x (1 | 2) -> aim at a square-ish block
+  // measured (profiles/r01_gemm_micro.txt): grouping only pays for very wide outputs (8192^3: +7 %); the step's own
+  // shapes (tiles_n <= 16) are neutral to slightly worse, so they keep the row-major order
+  int gm = gm_opt >= 0 && getenv("FFVC_TILE_GM") ? gm_opt : (tiles_n > 16 ? 4 : 1);
+  if (gm > tiles_m) gm = tiles_m;
+#ifdef FFVC_BUILD_PERSIST
+  constexpr bool ring = !(BM == 256 && BN == 128);
+  if constexpr (ring) {
+    const bool interior = (d.M % BM) == 0 && (d.N % BN) == 0 && vec_ok == 2 && !(d.flags & (FFVC_F_OUT_F32 | FFVC_F_ACCUM_OUT | FFVC_F_ATOMIC_OUT));
+    if (persist == 1 || (persist == 2 && d.K <= 512 && interior && (int64_t)n_tiles * d.batch * split > n_cu)) {
+      const int64_t total = (int64_t)n_tiles * d.batch * split;
+      const int slots = n_cu * ((BM == 256) ? 1 : 2);
+      int pgrid = total < slots ? (int)total : slots;
+      static bool pattr_set = false;
+      if (!pattr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm2p_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        pattr_set = true;
+      }
+      if (total < (1ll << 31)) {
+        hipLaunchKernelGGL((gemm2p_kernel<XMODE, WMODE, BM, BN>), dim3(pgrid), dim3(nthreads), lds, st, d, tiles_n, n_tiles,
+                           d.batch, (int)total, ksplit_len, vec_ok, zero, gm, interior ? 1 : 0);
+        hipError_t pe = hipGetLastError();
+        if (pe != hipSuccess) {
+          ffvc_set_error("gemm2p launch failed: %s", hipGetErrorString(pe));
+          return -(int)pe - 1000;
+        }
+        return 1;
+      }
+    }
+  }
+#else
+  (void)persist;
+#endif
+  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
+                     vec_ok, zero, gm);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ffvc_set_error("gemm2 launch failed: %s", hipGetErrorString(e));
+    return -(int)e - 1000;
+  }
+  return 1;
+}
+
+// cfg: 128 -> 128x128, 256 -> 256x128, 512 -> 256x256
+template <int XMODE, int WMODE>
+int launch2_cfg(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg) {
+  if (cfg == 512) return launch2<XMODE, WMODE, 256, 256>(d, st, vec_ok, zero);
+  if (cfg == 256) return launch2<XMODE, WMODE, 256, 128>(d, st, vec_ok, zero);
+  return launch2<XMODE, WMODE, 128, 128>(d, st, vec_ok, zero);
+}
+
+
+}  // namespace
