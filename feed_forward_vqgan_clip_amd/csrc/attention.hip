@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void attn_small_fwd_kernel(const uint16_t* __re
 
 // Backward.  Phase A works on transposed tiles (lane = query): dQ.  Phase B walks the two query tiles in the other
 // orientation (lane = key, registers = queries), re-deriving P from the row statistics kept in LDS: dV and dK.
-__global__ __launch_bounds__(64) void attn_small_bwd_kernel(const uint16_t* __restrict__ qkv,
+__global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* __restrict__ qkv,
                                                            const uint16_t* __restrict__ dout,
                                                            uint16_t* __restrict__ dqkv, int T, int heads, float scale) {
   __shared__ __attribute__((aligned(16))) uint16_t bufA[PANEL];   // K^T, later dO^T
