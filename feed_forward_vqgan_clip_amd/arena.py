@@ -47,6 +47,7 @@ class ParamArena:
         self._index = {id(p): i for i, p in enumerate(ps)}
         self._packs = []          # (Weights, param index) needing a transposed shadow
         self._grad_cbs = []
+        self._tplan = None
         module._ffvc_arena = self
 
     # -- shadows ------------------------------------------------------------
@@ -67,8 +68,10 @@ class ParamArena:
         """Re-derive the shadows from the fp32 masters (after load_state_dict / an optimizer step)."""
         if cast and self.cdt != torch.float32:
             K.cast_into(self.params, self.shadow)
-        for W in self._packs:
-            K.transpose(W.sh, out=W.sht)
+        if self._packs and self.shadow.is_cuda:
+            if self._tplan is None or self._tplan.n != len(self._packs):
+                self._tplan = K.TransposePlan([(W.sh, W.sht) for W in self._packs])
+            self._tplan.run()                   # every W^T shadow in one launch
 
     # -- gradients ----------------------------------------------------------
     def zero_grad(self):

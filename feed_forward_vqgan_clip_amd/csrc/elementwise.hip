@@ -57,6 +57,36 @@ __global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ s
   }
 }
 
+// Many independent transposes in ONE launch (the W^T shadows of every trainable weight after an optimizer step: 177
+// matrices for the 32-layer Mixer).  tile_prefix[i] = number of 64x64 tiles of items 0..i-1.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const ffvc_tr_item* __restrict__ items,
+                                                              const int* __restrict__ tile_prefix, int n_items) {
+  __shared__ T tile[64][66];
+  int lo = 0, hi = n_items - 1;
+  const int g = blockIdx.x;
+  while (lo < hi) {                       // last item whose prefix <= g
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_prefix[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  const ffvc_tr_item it = items[lo];
+  const int t = g - tile_prefix[lo];
+  const int tiles_x = (it.cols + 63) >> 6;
+  const int r0 = (t / tiles_x) * 64, c0 = (t % tiles_x) * 64;
+  const T* s = (const T*)it.src;
+  T* d = (T*)it.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < it.rows && c < it.cols) tile[i][tx] = s[(int64_t)r * it.cols + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < it.cols && r < it.rows) d[(int64_t)c * it.rows + r] = tile[tx][i];
+  }
+}
+
 // ---------------------------- column sums ----------------------------------
 // out[c] (+)= sum_r x[r, c]   (bias gradients; reduction of LayerNorm partials)
 // block = 64 column-quads x 4 row-lanes (8/16-byte loads); gridDim.y strips of rows, atomics combine strips.
@@ -671,6 +701,18 @@ extern "C" int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst
   DISPATCH_DT(src_dtype, ST, DISPATCH_DT(dst_dtype, DT,
               hipLaunchKernelGGL((transpose_kernel<ST, DT>), grid, dim3(256), 0, st, (const ST*)src, (DT*)dst, rows,
                                  cols, src_batch_stride, dst_batch_stride, dst_ld)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_transpose_multi(const ffvc_tr_item* items, const int* tile_prefix, int n_items, int total_tiles,
+                                    int dtype, void* stream) {
+  FFVC_CHECK_ARG(items && tile_prefix && n_items > 0 && total_tiles > 0, "ffvc_transpose_multi: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FFVC_BF16)
+    hipLaunchKernelGGL((transpose_multi_kernel<uint16_t>), dim3(total_tiles), dim3(256), 0, st, items, tile_prefix, n_items);
+  else
+    hipLaunchKernelGGL((transpose_multi_kernel<float>), dim3(total_tiles), dim3(256), 0, st, items, tile_prefix, n_items);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -302,6 +302,36 @@ def transpose(src, out_dtype=None, out=None, pad_to=0):
     return out
 
 
+class TransposePlan:
+    """Device-side table for `ffvc_transpose_multi`: pairs of contiguous 2-D tensors (src [R, C] -> dst [C, R])."""
+
+    def __init__(self, pairs):
+        import numpy as np
+        if not pairs:
+            raise ValueError("TransposePlan: no matrices")
+        dt = pairs[0][0].dtype
+        items = np.zeros(len(pairs), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4")])
+        prefix = np.zeros(len(pairs), dtype=np.int32)
+        total = 0
+        for i, (src, dst) in enumerate(pairs):
+            _need_cuda(src, dst)
+            R, C = src.shape
+            if src.dtype != dt or dst.dtype != dt or tuple(dst.shape) != (C, R) or not src.is_contiguous() or not dst.is_contiguous():
+                raise TypeError("TransposePlan: need contiguous [R, C] -> [C, R] pairs of one dtype")
+            items[i] = (src.data_ptr(), dst.data_ptr(), R, C)
+            prefix[i] = total
+            total += ((R + 63) // 64) * ((C + 63) // 64)
+        dev = pairs[0][0].device
+        self.items = torch.from_numpy(items.view(np.uint8).copy()).to(dev)
+        self.prefix = torch.from_numpy(prefix).to(dev)
+        self.n, self.total, self.dtype = len(pairs), total, dtype_code(dt)
+        self._keep = pairs                                   # the table holds raw pointers: keep the tensors alive
+
+    def run(self):
+        _call("ffvc_transpose_multi", self.items.data_ptr(), self.prefix.data_ptr(), self.n, self.total, self.dtype,
+              stream_ptr())
+
+
 def copy2d(src, src_ld, rows, cols, dst_cols, out_dtype, dst_ld=None):
     """dst[r, c] = src[r, c] (c < cols) else 0, for c < dst_cols."""
     dst_ld = dst_ld or dst_cols

@@ -185,6 +185,17 @@ int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t 
  * vitgan.py:82) */
 int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int batch, int rows, int cols,
                    int64_t src_batch_stride, int64_t dst_batch_stride, int dst_ld, void* stream);
+
+/* n_items independent transposes dst[c][r] = src[r][c] (same element type) in one launch; `items` and `tile_prefix`
+ * (tile_prefix[i] = number of 64x64 tiles of items 0..i-1; total_tiles = their sum) are DEVICE arrays the caller builds
+ * once.  Used for the W^T shadows of all trainable weights after an optimizer step (arena.refresh). */
+typedef struct ffvc_tr_item {
+  const void* src;
+  void* dst;
+  int32_t rows, cols;
+} ffvc_tr_item;
+int ffvc_transpose_multi(const ffvc_tr_item* items, const int* tile_prefix, int n_items, int total_tiles, int dtype,
+                         void* stream);
 /* dst[r, c] = c < cols ? src[r, c] : 0, c < dst_cols; independent leading dims (pad / unpad per-head blocks) */
 int ffvc_copy2d(const void* src, int src_dtype, int64_t src_ld, void* dst, int dst_dtype, int64_t dst_ld, int64_t rows,
                 int cols, int dst_cols, void* stream);

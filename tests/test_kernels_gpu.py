@@ -334,3 +334,13 @@ def test_degenerate_sizes(cuda):
     out = torch.zeros(4, device=cuda)
     K.colsum(m, out)
     assert torch.equal(out, m.float().view(-1))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_transpose_multi(cuda, dt):
+    shapes = [(1024, 256), (70, 130), (1, 5), (64, 64), (129, 63)]
+    pairs = [(_mk(s, dt, cuda, i), torch.zeros(s[1], s[0], dtype=dt, device=cuda)) for i, s in enumerate(shapes)]
+    plan = K.TransposePlan(pairs)
+    plan.run()
+    for src, dst in pairs:
+        assert torch.equal(dst, src.t().contiguous())
