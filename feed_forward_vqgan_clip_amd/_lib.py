@@ -23,6 +23,7 @@ F_OUT_F32 = 32
 F_TR_SAFE = 64
 F_UPSAMPLE2X = 128
 F_ACCUM_OUT = 256
+F_GN_SUMS = 512
 
 
 class GemmDesc(Structure):
@@ -75,6 +76,9 @@ class GemmDesc(Structure):
         ("x_mi", c_int32),
         ("x_so", c_int64),
         ("slab_stride", c_int64),
+        ("gn_sums", c_void_p),
+        ("gn_hw", c_int32),
+        ("gn_cpg", c_int32),
     ]
 
 
@@ -97,6 +101,8 @@ _SIGNATURES = {
     "ffvc_groupnorm_ws_bytes": (c_int64, [c_int, c_int, c_int]),
     "ffvc_groupnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "ffvc_groupnorm_fwd_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "ffvc_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_softmax_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_int, c_int,

@@ -169,6 +169,16 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     if (d.aux) ok = ok && m8(d.ldaux) && m8(d.abo) && m8(d.abi);
     if (ok) vec_ok = 2;
   }
+  if (d.flags & FFVC_F_GN_SUMS) {
+    const bool gok = vec_ok == 2 && d.gn_sums && d.gn_hw > 0 && (d.gn_hw % 256) == 0 && d.gn_cpg >= 4 &&
+                     (d.gn_cpg % 4) == 0 && (d.N % d.gn_cpg) == 0 && d.batch == 1 && d.split_k <= 1 && d.y_mi == 0 &&
+                     (d.M % d.gn_hw) == 0 && !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT));
+    if (!gok) {
+      ffvc_set_error("ffvc_gemm: FFVC_F_GN_SUMS needs the row-store epilogue, gn_hw %% 256 == 0, gn_cpg %% 4 == 0 "
+                     "(gn_hw=%d gn_cpg=%d N=%d)", d.gn_hw, d.gn_cpg, d.N);
+      return FFVC_E_BADARG;
+    }
+  }
   // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
   const int env_bm = opt_value(g_opt_gemm2_tile, "FFVC_GEMM2_BM", 1);
   if (env_bm == 0) return 0;

@@ -155,7 +155,7 @@ __device__ __forceinline__ f32x2_t apply_act_grad2(int act, f32x2_t pre) {
 }
 
 template <typename T>
-__device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8 v, int n, int64_t yrow, int64_t rrow,
+__device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,
                                              int64_t arow, int flags) {
   if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
     const f32x8 b = load8(p.bias + n);
@@ -215,6 +215,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
   const int64_t abz = zo * p.abo + zi * p.abi;
   unsigned char* wr = pad + l31 * 128;
   const int wsw = l31 & 7;
+  const bool gn = flags & FFVC_F_GN_SUMS;
+  float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [nt][4-channel half]
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int mbase = m0 + wm * (32 * MT) + mt * 32;
@@ -256,12 +258,43 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
           v.v[j] = a[j];
           v.v[4 + j] = b[j];
         }
-        if (mok[i] && n < p.N) epilogue_oct<T>(p, v, n, yrow[i], rrow[i], arow[i], flags);
+        if (mok[i] && n < p.N) {
+          epilogue_oct<T>(p, v, n, yrow[i], rrow[i], arow[i], flags);
+          if (gn) {   // moments of the fp32 values before the bf16 store (the rounding noise adds ~1e-6 of E[x^2])
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              gs1[nt][j >> 2] += v.v[j];
+              gs2[nt][j >> 2] += v.v[j] * v.v[j];
+            }
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+  }
+  if (gn) {
+    // lanes with the same (lane & 3) own the same 8 columns: fold the 16 row-lanes, then one fp64 atomic pair per
+    // (column half, nt) into sums[image][group][2]; a tile lies inside one image (gn_hw is a multiple of the tile rows)
+    const int64_t img = (int64_t)(m0 / p.gn_hw) * (p.N / p.gn_cpg);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float a = gs1[nt][hf], b = gs2[nt][hf];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        const int n = n0 + wn * 64 + nt * 32 + 8 * cc + 4 * hf;
+        if (rr == 0 && n < p.N) {
+          double* o2 = p.gn_sums + (img + n / p.gn_cpg) * 2;
+          atomicAdd(o2, (double)a);
+          atomicAdd(o2 + 1, (double)b);
+        }
+      }
   }
 }
 

@@ -849,6 +849,26 @@ extern "C" int ffvc_groupnorm_fwd(const void* x, void* y, const float* gamma, co
   return 0;
 }
 
+extern "C" int ffvc_groupnorm_fwd_sums(const void* x, void* y, const float* gamma, const float* beta, float* mean,
+                                       float* rstd, const double* sums, int B, int HW, int C, int G, float eps, int swish,
+                                       int dtype, void* stream) {
+  FFVC_CHECK_ARG(x && y && gamma && beta && mean && rstd && sums, "ffvc_groupnorm_fwd_sums: null pointer");
+  if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_fwd_sums")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  int bpi = 4096 / (B < 1 ? 1 : B);
+  if (bpi > HW / 64) bpi = HW / 64;
+  if (bpi < 1) bpi = 1;
+  const int rpb = (HW + bpi - 1) / bpi;
+  const int nblk = (HW + rpb - 1) / rpb;
+  // the producer's sums have the layout of ONE chunk of partial moments: ws[B][1][G][2]
+  DISPATCH_DT(dtype, T, {
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta, sums, mean,
+                       rstd, HW, C, G, 1, eps, swish, rpb);
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                   const float* mean, const float* rstd, const void* dres, void* dx, void* ws, int B,
                                   int HW, int C, int G, int swish, int dtype, void* stream) {

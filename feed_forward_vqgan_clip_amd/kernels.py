@@ -66,7 +66,7 @@ def _req_f32(*ts):
 def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, bias=None,
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
-         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0):
+         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0, gn_sums=None):
     """Enqueue `ffvc_gemm`. See include/ffvc.h for the index maps.
 
     y_map / r_map = (mi, so, sm): row offset(m) = (m // mi) * so + (m % mi) * sm (mi = 0: m * sm).
@@ -114,6 +114,12 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     if x_map is not None:
         d.x_mi, d.x_so = x_map
     d.slab_stride = slab_stride
+    if gn_sums is not None:                       # (fp64 [images, groups, 2] zeroed buffer, pixels per image, channels per group)
+        buf, hw, cpg = gn_sums
+        if buf.dtype != torch.float64 or not buf.is_cuda or not buf.is_contiguous():
+            raise TypeError("gemm: gn_sums buffer must be a contiguous fp64 device tensor")
+        d.gn_sums, d.gn_hw, d.gn_cpg = buf.data_ptr(), hw, cpg
+        d.flags |= _lib.F_GN_SUMS
     lib = _lib.load()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -221,8 +227,18 @@ def _gn_ws(B, HW, G, dev):
     return torch.empty((n + 7) // 8, dtype=torch.float64, device=dev)
 
 
-def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True):
-    """x: NHWC (B, H, W, C) -> (y, mean[B,G], rstd[B,G])."""
+def gn_sums_ok(M, N, HW, dtype, G=32):
+    """Can the GEMM that produces an (M = images*HW, N = C) NHWC tensor also accumulate its GroupNorm moments?"""
+    return (dtype == torch.bfloat16 and HW % 256 == 0 and M % HW == 0 and N % G == 0 and (N // G) % 4 == 0 and
+            os.environ.get("FFVC_GN_FUSE", "1") != "0")
+
+
+def gn_sums_buffer(images, G, device):
+    return torch.zeros(images, G, 2, dtype=torch.float64, device=device)
+
+
+def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None):
+    """x: NHWC (B, H, W, C) -> (y, mean[B,G], rstd[B,G]).  sums: moments already accumulated by the producer GEMM."""
     _req_f32(gamma, beta)
     _need_cuda(x)
     _need_cuda(x, gamma, beta)
@@ -231,6 +247,12 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True):
     y = torch.empty_like(x)
     mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    if sums is not None:
+        if sums.dtype != torch.float64 or tuple(sums.shape) != (B, G, 2):
+            raise TypeError("groupnorm_fwd: sums must be fp64 [B, G, 2]")
+        _call("ffvc_groupnorm_fwd_sums", x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), sums.data_ptr(), B, HW, C, G, eps, int(swish), dtype_code(x.dtype), stream_ptr())
+        return y, mean, rstd
     ws = _gn_ws(B, HW, G, x.device)
     _call("ffvc_groupnorm_fwd", x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
           rstd.data_ptr(), ws.data_ptr(), B, HW, C, G, eps, int(swish), dtype_code(x.dtype), stream_ptr())

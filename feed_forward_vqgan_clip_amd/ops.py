@@ -141,6 +141,23 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None):
 _LN_LO = os.environ.get("FFVC_LN_LO", "1") != "0"      # A/B switch for the fused bf16 gradient copy
 
 
+def _gn_request(gn, y, images, hw, C):
+    """Moments buffer for a producer whose NHWC output `y` goes into GroupNorm(32) next (None if not fusable)."""
+    if not gn or y.dtype != torch.bfloat16 or not K.gn_sums_ok(images * hw, C, hw, y.dtype):
+        return None
+    sums = K.gn_sums_buffer(images, 32, y.device)
+    y._ffvc_gn = sums
+    return sums
+
+
+def carry_gn(src, dst):
+    """Views / reshapes of a producer's output keep its GroupNorm moments."""
+    g = getattr(src, "_ffvc_gn", None)
+    if g is not None:
+        dst._ffvc_gn = g
+    return dst
+
+
 def _as(t, dtype):
     if t.dtype == dtype:
         return t
@@ -159,12 +176,14 @@ def _contig(t):
 # ---------------------------------------------------------------------------
 class _LinearFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, W, out_dtype):
+    def forward(ctx, x, weight, bias, residual, W, out_dtype, gn_hw=0):
         cdt = W.sh.dtype
         x = _contig(x)
         rows = x.numel() // W.K
         y = torch.empty(*x.shape[:-1], W.N, dtype=out_dtype or cdt, device=x.device)
-        K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual)
+        sums = _gn_request(gn_hw > 0, y, rows // gn_hw if gn_hw else 0, gn_hw, W.N)
+        K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual,
+               gn_sums=None if sums is None else (sums, gn_hw, W.N // 32))
         ctx.W, ctx.rows = W, rows
         ctx.train = weight is not None and weight.requires_grad
         ctx.has_res = residual is not None
@@ -185,11 +204,12 @@ class _LinearFn(Function):
         if ctx.train:
             (x,) = ctx.saved_tensors
             _wgrad(dyt, x, W, rows)
-        return dx, None, None, (dy if ctx.has_res else None), None, None
+        return dx, None, None, (dy if ctx.has_res else None), None, None, None
 
 
-def linear(x, W, residual=None, out_dtype=None):
-    return _LinearFn.apply(x, W.weight, W.bias, residual, W, out_dtype)
+def linear(x, W, residual=None, out_dtype=None, gn_hw=0):
+    """gn_hw > 0: the rows are NHWC pixels (gn_hw per image) feeding a GroupNorm(32) next (see conv3x3)."""
+    return _LinearFn.apply(x, W.weight, W.bias, residual, W, out_dtype, gn_hw)
 
 
 # ---------------------------------------------------------------------------
@@ -358,7 +378,10 @@ class _GNForkFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, swish):
         x = _contig(x)
-        y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish)
+        sums = getattr(x, "_ffvc_gn", None)          # moments accumulated by the GEMM that produced x
+        if sums is not None and tuple(sums.shape) != (x.shape[0], 32, 2):
+            sums = None
+        y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish, sums=sums)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.swish = swish
         ctx.set_materialize_grads(False)
@@ -409,13 +432,15 @@ class ConvWeights:
 
 class _Conv3x3Fn(Function):
     @staticmethod
-    def forward(ctx, x, residual, P, upsample, out_dtype):
+    def forward(ctx, x, residual, P, upsample, out_dtype, gn):
         x = _contig(x)
         B, Hin, Win, Cin = x.shape
         H, W = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
         y = torch.empty(B, H, W, P.Cout, dtype=out_dtype or x.dtype, device=x.device)
+        sums = _gn_request(gn, y, B, H * W, P.Cout)
         K.gemm(x, P.w, y, B * H * W, P.Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=P.bias,
-               residual=residual, conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0)
+               residual=residual, conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0,
+               gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
         ctx.P, ctx.upsample, ctx.geom, ctx.cdt = P, upsample, (B, H, W, Cin), x.dtype
         ctx.has_res = residual is not None
         return y
@@ -440,11 +465,12 @@ class _Conv3x3Fn(Function):
         dres = None
         if ctx.has_res:
             dres = dy
-        return dx, dres, None, None, None
+        return dx, dres, None, None, None, None
 
 
-def conv3x3(x, P, residual=None, upsample=False, out_dtype=None):
-    return _Conv3x3Fn.apply(x, residual, P, upsample, out_dtype)
+def conv3x3(x, P, residual=None, upsample=False, out_dtype=None, gn=False):
+    """gn=True: the output feeds a GroupNorm(32) next -> its moments are accumulated by this GEMM's epilogue."""
+    return _Conv3x3Fn.apply(x, residual, P, upsample, out_dtype, gn)
 
 
 # ---------------------------------------------------------------------------

@@ -88,10 +88,10 @@ class _Res:
 
     def __call__(self, x):
         xn, xid = ops.groupnorm_fork(x, *self.n1, True)
-        h = ops.conv3x3(xn, self.conv1)
+        h = ops.conv3x3(xn, self.conv1, gn=True)                   # -> norm2: moments from the conv epilogue
         hn, _ = ops.groupnorm_fork(h, *self.n2, True)
         sc = xid if self.nin is None else ops.linear(xid, self.nin)
-        return ops.conv3x3(hn, self.conv2, residual=sc)
+        return ops.conv3x3(hn, self.conv2, residual=sc, gn=True)   # block output -> the next block's norm
 
 
 class _Attn:
@@ -109,7 +109,8 @@ class _Attn:
         hn, xid = ops.groupnorm_fork(x, *self.norm, False)
         qkv = ops.linear(hn.view(B, H * W, C), self.qkv)
         o = ops.attention(qkv, 1, float(C) ** -0.5)
-        return ops.linear(o, self.proj, residual=xid.view(B, H * W, C)).view(B, H, W, C)
+        out = ops.linear(o, self.proj, residual=xid.view(B, H * W, C), gn_hw=H * W)
+        return ops.carry_gn(out, out.view(B, H, W, C))
 
 
 class VQGAN:
@@ -151,14 +152,14 @@ class VQGAN:
     def decode_nhwc(self, z_q):
         """z_q: (B, S, S, C) compute dtype -> (B, 16S, 16S, 3) fp32 in [-1, 1]-ish (VQModel.decode)."""
         h = ops.linear(z_q, self.post_quant)
-        h = ops.conv3x3(h, self.conv_in)
+        h = ops.conv3x3(h, self.conv_in, gn=True)
         for m in self.mid:
             h = m(h)
         for stages, up in self.levels:
             for s in stages:
                 h = s(h)
             if up is not None:
-                h = ops.conv3x3(h, up, upsample=True)
+                h = ops.conv3x3(h, up, upsample=True, gn=True)
         hn, _ = ops.groupnorm_fork(h, *self.norm_out, True)
         return ops.conv3x3(hn, self.conv_out, out_dtype=torch.float32)
 

@@ -52,6 +52,7 @@ extern "C" {
 #define FFVC_F_OUT_F32 32       /* y is fp32 (else in_dtype)                    */
 #define FFVC_F_TR_SAFE 64       /* transposed bf16 fragments via scalar LDS gathers (debug/verification) */
 #define FFVC_F_UPSAMPLE2X 128   /* conv: input is nearest-2x upsampled on the fly */
+#define FFVC_F_GN_SUMS 512      /* also accumulate GroupNorm moments of the stored output (see gn_sums below) */
 #define FFVC_F_ACCUM_OUT 256    /* y += acc with plain read-modify-write (fp32 y, split_k == 1: one owner per element) */
 
 /*
@@ -112,6 +113,12 @@ typedef struct ffvc_gemm_desc {
   /* split-K through partial slabs: K-slice z stores its fp32 partial tile at y + z*slab_stride (plain vector
    * stores); combine with ffvc_slab_reduce.  0 = off. */
   int64_t slab_stride;
+  /* FFVC_F_GN_SUMS: the rows of y are pixels of NHWC images with gn_hw pixels each and N channels in groups of
+   * gn_cpg consecutive channels; gn_sums[image][group][2] (fp64, zeroed by the caller) receives sum and sum of squares
+   * of the fp32 values just before the store (taming Normalize statistics of the NEXT layer, computed where the tensor is produced
+   * instead of by a separate read pass).  bf16 LDS-DMA path only; gn_hw % 256 == 0, gn_cpg % 4 == 0. */
+  double* gn_sums;
+  int32_t gn_hw, gn_cpg;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
@@ -155,6 +162,11 @@ int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const float* w, 
 int64_t ffvc_groupnorm_ws_bytes(int B, int HW, int G);
 int ffvc_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
                        void* ws, int B, int HW, int C, int G, float eps, int swish, int dtype, void* stream);
+/* Same, with the per-(image, group) sums already accumulated by the producing GEMM (FFVC_F_GN_SUMS): only the
+ * normalise / affine / swish pass runs. */
+int ffvc_groupnorm_fwd_sums(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                            const double* sums, int B, int HW, int C, int G, float eps, int swish, int dtype,
+                            void* stream);
 /* dx = GN'(swish'(.) * dy) (+ dres); gamma/beta gradients are not produced (decoder is frozen, main.py:88). */
 int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                        const float* rstd, const void* dres, void* dx, void* ws, int B, int HW, int C, int G,

@@ -238,3 +238,41 @@ def test_conv_row_tile_kernel(cuda, W, Cin, Cout, ups):
         xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(xn, w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
     assert _rel(y, ref) < 1e-2
+
+
+@pytest.mark.parametrize("kind", ["conv_row", "conv_generic", "linear_residual"])
+def test_gn_sums_from_epilogue(cuda, kind):
+    """FFVC_F_GN_SUMS: per-(image, group) sum / sum of squares of the STORED output, accumulated by the epilogue."""
+    torch.manual_seed(0)
+    B, G = 3, 32
+    if kind == "linear_residual":
+        HW, Kd, C = 256, 64, 128
+        x = torch.randn(B * HW, Kd, device=cuda).bfloat16()
+        w = (torch.randn(C, Kd, device=cuda) * 0.1).bfloat16()
+        res = torch.randn(B * HW, C, device=cuda).bfloat16()
+        y = torch.empty(B * HW, C, device=cuda, dtype=torch.bfloat16)
+        sums = K.gn_sums_buffer(B, G, cuda)
+        K.gemm(x, w, y, B * HW, C, Kd, ldx=Kd, ldw=Kd, residual=res, gn_sums=(sums, HW, C // G))
+    else:
+        H, Cin, C = (64, 128, 128) if kind == "conv_row" else (16, 64, 256)
+        HW = H * H
+        x = torch.randn(B, H, H, Cin, device=cuda).bfloat16()
+        w = (torch.randn(C, 3, 3, Cin, device=cuda) * 0.05).bfloat16()
+        bias = torch.randn(C, device=cuda)
+        y = torch.empty(B, H, H, C, device=cuda, dtype=torch.bfloat16)
+        sums = K.gn_sums_buffer(B, G, cuda)
+        K.gemm(x, w, y, B * HW, C, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=bias, conv=(H, H, Cin),
+               gn_sums=(sums, HW, C // G))
+    yd = y.double().view(B, HW, G, C // G)
+    ref = torch.stack([yd.sum(dim=(1, 3)), (yd * yd).sum(dim=(1, 3))], dim=-1)
+    # the kernel sums the fp32 values BEFORE the bf16 rounding of y: per element the difference is <= 2^-9 |x|, random sign
+    n = HW * (C // G)
+    noise = 4.0 * (n ** 0.5) * 2.0 ** -9 * (ref[..., 1] / n).sqrt()
+    assert ((sums[..., 0] - ref[..., 0]).abs() <= noise + 1e-3).all()
+    assert ((sums[..., 1] - ref[..., 1]).abs() / ref[..., 1]).max().item() < 1e-3
+    # and GroupNorm from those sums == GroupNorm with its own statistics pass
+    gamma, beta = torch.randn(C, device=cuda), torch.randn(C, device=cuda)
+    yv = y.view(B, -1, 1, C) if kind == "linear_residual" else y
+    a = K.groupnorm_fwd(yv, gamma, beta, swish=True)
+    b = K.groupnorm_fwd(yv, gamma, beta, swish=True, sums=sums)
+    assert _rel(b[0], a[0]) < 1e-2 and _rel(b[1], a[1]) < 2e-3 and _rel(b[2], a[2]) < 2e-3
