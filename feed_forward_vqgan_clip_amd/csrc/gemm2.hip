@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int px = wm * 128 + t * 32 + l31;
-    xrow[t] = (px / W) * (W + 2) + (px % W);
+    const int Wt = W < 256 ? W : 256;               // tile row width (a segment of the image row when W > 256)
+    xrow[t] = (px / Wt) * (Wt + 2) + (px % Wt);
   }
   unsigned char* sX = smem;
   unsigned char* sW = smem + XTILE;
@@ -208,7 +209,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) {
     const int env_row = opt_value(g_opt_conv_row, "FFVC_CONV_ROW", 1);
     const int W = d.conv_W;
-    const bool geom_ok = (W == 64 || W == 128 || W == 256) && ((int64_t)d.conv_H * W) % 256 == 0 && d.batch == 1 &&
+    const bool geom_ok = (W == 64 || W == 128 || (W >= 256 && W % 256 == 0)) && ((int64_t)d.conv_H * W) % 256 == 0 && d.batch == 1 &&
                          d.split_k <= 1 && (d.N % 128) == 0 && (d.M % 256) == 0;
     const bool fills = (int64_t)(d.M / 256) * (d.N / 128) >= 256;
     if (geom_ok && (env_row == 2 || (env_row == 1 && fills && cfg != 512))) {

@@ -133,7 +133,9 @@ struct ConvRowDma {
   const uint16_t* base;
   int rowinfo[NP];                  // (seg << 16) | (ix + 1), or -1 when the position is beyond the tile
   int kc;
-  int H, W, Win, Hin, Cin, ups, img, oy0;
+  int H, W, Win, Hin, Cin, ups, img, oy0, x0;
+  // A 256-pixel tile is 256 / Wt whole rows of width Wt = W (W <= 256) or one 256-pixel segment of a wider row
+  // (W a multiple of 256: x0 = first column of the segment); each tile row carries one halo pixel on either side.
   __device__ __forceinline__ void init(const uint16_t* base_, int m0, int H_, int W_, int Cin_, int ups_, int tid) {
     const int lane = tid & 63, w = tid >> 6;
     base = base_;
@@ -144,16 +146,19 @@ struct ConvRowDma {
     Win = W_ >> ups_;
     Hin = H_ >> ups_;
     img = m0 / (H * W);
-    oy0 = (m0 - img * (H * W)) / W;
+    const int rem = m0 - img * (H * W);
+    oy0 = rem / W;
+    const int Wt = W < 256 ? W : 256;
+    x0 = W > 256 ? rem - oy0 * W : 0;
     const int line = 4 * w + (lane >> 4);
     const int cp = (lane & 15) ^ (line & 15);
     kc = (cp & 7) * EPC;
     const int r0 = 2 * line + (cp >> 3);
-    const int tr = (256 / W) * (W + 2);
+    const int tr = (256 / Wt) * (Wt + 2);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int r = r0 + 32 * j;
-      rowinfo[j] = r < tr ? (((r / (W + 2)) << 16) | (r % (W + 2))) : -1;
+      rowinfo[j] = r < tr ? (((r / (Wt + 2)) << 16) | (r % (Wt + 2))) : -1;
     }
   }
   __device__ __forceinline__ void issue(unsigned char* tile, int kh, int ci0, const uint16_t* zero, int tid) {
@@ -161,7 +166,7 @@ struct ConvRowDma {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       if (rowinfo[j] < 0) continue;                      // exec-masked lanes simply do not write
-      const int seg = rowinfo[j] >> 16, ix = (rowinfo[j] & 0xffff) - 1;
+      const int seg = rowinfo[j] >> 16, ix = x0 + (rowinfo[j] & 0xffff) - 1;
       const int iy = oy0 + seg + kh - 1;
       const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const int64_t off = ((int64_t)((img * Hin + (iy >> ups)) * Win + (ix >> ups))) * Cin + ci0 + kc;

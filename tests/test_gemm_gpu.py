@@ -216,11 +216,12 @@ def test_splitk_slabs(cuda, dt):
 
 
 @pytest.mark.parametrize("W,Cin,Cout,ups", [(64, 128, 128, False), (128, 64, 256, False), (256, 128, 128, False),
-                                           (64, 128, 128, True), (128, 256, 128, True)])
+                                           (64, 128, 128, True), (128, 256, 128, True), (512, 64, 128, False),
+                                           (512, 128, 128, True), (768, 64, 128, False)])
 def test_conv_row_tile_kernel(cuda, W, Cin, Cout, ups):
     """Haloed row-tile conv fast path (forced) vs F.conv2d, incl. image borders and the fused 2x upsample."""
     dt = torch.bfloat16
-    B, H = (1, W) if W >= 128 else (2, 64)
+    B, H = (1, min(W, 128)) if W >= 128 else (2, 64)        # wide images (W > 256): a tile is a 256-pixel row segment
     Hin, Win = (H // 2, W // 2) if ups else (H, W)
     x = _mk((B, Hin, Win, Cin), dt, cuda, 1)
     w = _mk((Cout, 3, 3, Cin), dt, cuda, 2, 0.05)
