@@ -112,10 +112,10 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
         grads = torch.autograd.grad(loss, plist)
         with torch.no_grad():
             ostep.adam_step(plist, grads, state, 1e-3, step)
-        return float(loss)
+        return float(loss.detach())
 
     t0 = time.time()
-    one(1)                       # first step doubles as warm-up (allocator, MKL threads)
+    loss0 = one(1)               # first step doubles as warm-up (allocator, MKL threads); its loss is the parity reference
     first = time.time() - t0
     n, t0 = 0, time.time()
     while first + (time.time() - t0) < seconds_budget and n < 3:
@@ -125,9 +125,39 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
         n, dt = 1, first
     else:
         dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} full oracle train step(s) (fwd+loss+bwd+Adam, fp32) at batch {B}, cutn {cutn}, same cfg2 "
-                      f"models/shapes; {dt:.2f} s/step"}
+    out = {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"{n} full oracle train step(s) (fwd+loss+bwd+Adam, fp32) at batch {B}, cutn {cutn}, same cfg2 "
+                     f"models/shapes; {dt:.2f} s/step"}
+    return out, {"loss": loss0, "tok": tok, "facs": facs.view(-1), "noise": noise, "aug_params": prm}
+
+
+def full_size_parity(args, sds, ref):
+    """The oracle's first-step loss (computed by the cpu_baseline leg above) against the HIP path on the SAME full-size
+    weights and inputs, in both compute modes: the north-star parity figure at the benchmark's own model sizes."""
+    from feed_forward_vqgan_clip_amd import clip as fclip
+    from feed_forward_vqgan_clip_amd import main as fmain
+    from feed_forward_vqgan_clip_amd import vqgan as fvq
+    from feed_forward_vqgan_clip_amd.optim import FusedAdam
+    mixer_sd, vq_sd, clip_sd = sds
+    res = {"loss_oracle_fp32": ref["loss"]}
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
+                       batch_size=1, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
+                       model_type="mlp_mixer", vq_image_size=16, augs=None if args.augs == "default" else args.augs.split(","))
+    prm = ref["aug_params"]
+    for name, cdt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        net = fmain.build_model(cfg, 256)
+        net.load_state_dict(mixer_sd)
+        net = net.cuda().prepare(cdt)
+        stepper = fmain.TrainStep(cfg, net, fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt),
+                                  FusedAdam(net.parameters(), lr=1e-3))
+        with torch.no_grad():
+            loss, _ = stepper.forward_loss(ref["tok"].cuda(), facs=ref["facs"].cuda(), noise=ref["noise"].cuda(),
+                                           aug_params=None if prm is None else {k: v.cuda() for k, v in prm.items()})
+        res[f"loss_hip_{name}"] = float(loss)
+        res[f"rel_{name}"] = abs(float(loss) - ref["loss"]) / abs(ref["loss"])
+        del stepper, net
+        torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -264,7 +294,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del stepper
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(sds, args.cutn, augs=args.augs)
+        out["cpu_baseline"], ref = cpu_baseline(sds, args.cutn, augs=args.augs)
+        out["parity_full_size"] = full_size_parity(args, sds, ref)
     if rank == 0:
         print(json.dumps(out))
     if hvd.is_distributed():
