@@ -40,15 +40,15 @@ void ffvc_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __uint_as_float(((uint32_t)b) << 16);
 }
-__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, two values per instruction) — the software
+// sequence costs ~10 VALU instructions per pair, which shows in every bf16 epilogue.
+typedef __attribute__((ext_vector_type(2))) float f32pair_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  const f32pair_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16pair_t));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return (uint16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
 // Storage-type traits: T = uint16_t (bf16 bits) or float.
 template <typename T>
