@@ -282,6 +282,15 @@ __device__ __forceinline__ float act_quickgelu_grad(float x) {
   const float s = sigmoidf_(1.702f * x);
   return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+// bf16-storage variants: v_exp_f32 + v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float sigmoid_fast_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+template <typename T>
+__device__ __forceinline__ float act_swish_t(float x) { return x * (sizeof(T) == 2 ? sigmoid_fast_(x) : sigmoidf_(x)); }
+template <typename T>
+__device__ __forceinline__ float act_swish_grad_t(float x) {
+  const float s = sizeof(T) == 2 ? sigmoid_fast_(x) : sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
 __device__ __forceinline__ float act_swish(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float act_swish_grad(float x) {
   const float s = sigmoidf_(x);

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float u = v.v[j] * sc[j] + sh[j];
-        v.v[j] = swish ? act_swish(u) : u;
+        v.v[j] = swish ? act_swish_t<T>(u) : u;
       }
       store8s(y + off, v);
     } else {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float u = v[j] * sc[j] + sh[j];
-        v[j] = swish ? act_swish(u) : u;
+        v[j] = swish ? act_swish_t<T>(u) : u;
       }
       store4(y + off, v);
     }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
       for (int j = 0; j < EPC; ++j) {
         const float xh = (xv[j] - mu[j]) * rs[j];
         float d = dv[j];
-        if (swish) d *= act_swish_grad(xh * gm[j] + bt[j]);
+        if (swish) d *= act_swish_grad_t<T>(xh * gm[j] + bt[j]);
         d *= gm[j];
         a1[j] += d;
         a2[j] += d * xh;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     for (int j = 0; j < EPC; ++j) {
       const float xh = (xv[j] - mu[j]) * rs[j];
       float d = dv[j];
-      if (swish) d *= act_swish_grad(xh * gm[j] + bt[j]);
+      if (swish) d *= act_swish_grad_t<T>(xh * gm[j] + bt[j]);
       d *= gm[j];
       o[j] = rs[j] * (d - m1[j] - xh * m2[j]) + rv[j];
     }
