@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
                                                       float* __restrict__ dhl, float* __restrict__ dw,
                                                       float* __restrict__ part_g, float* __restrict__ part_b,
                                                       float* __restrict__ part_s, int64_t rows, int dim,
-                                                      int rows_per_block) {
+                                                      int rows_per_block, int acc_mode) {
   constexpr int NIT = LN_MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] + [2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -349,6 +349,14 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
     atomicAdd(&ln_smem[2 * dim + 1], sb);
   }
   __syncthreads();
+  if (acc_mode) {   // part_g / part_b / part_s[0], part_s[1] are the gradients themselves: accumulate with fp32 atomics
+    for (int i = threadIdx.x; i < dim; i += 256) {
+      atomicAdd(part_g + i, ln_smem[i]);
+      atomicAdd(part_b + i, ln_smem[dim + i]);
+    }
+    if (threadIdx.x < 2) atomicAdd(part_s + threadIdx.x, ln_smem[2 * dim + threadIdx.x]);
+    return;
+  }
   for (int i = threadIdx.x; i < dim; i += 256) {
     part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
     part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
@@ -940,10 +948,10 @@ extern "C" int ffvc_sln_fwd(const float* hl, const float* w, const float* gamma,
   return 0;
 }
 
-extern "C" int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
-                            const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
-                            const float* rstd, const float* dres, float* dhl, float* dw, float* part_g, float* part_b,
-                            float* part_s, int64_t rows, int dim, void* stream) {
+static int sln_bwd_launch(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
+                          const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
+                          const float* rstd, const float* dres, float* dhl, float* dw, float* part_g, float* part_b,
+                          float* part_s, int64_t rows, int dim, void* stream, int acc_mode) {
   FFVC_CHECK_ARG(dy && hl && w && gamma && beta && gamma_s && beta_s && mean && rstd && dhl && dw && part_g && part_b &&
                      part_s, "ffvc_sln_bwd: null pointer");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_sln_bwd: dim=%d unsupported", dim);
@@ -954,11 +962,27 @@ extern "C" int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const
   DISPATCH_DT(dy_dtype, DYT, {
     if (dim % 4 == 0)
       hipLaunchKernelGGL((sln_bwd_kernel<4, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
-                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb);
+                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode);
     else
       hipLaunchKernelGGL((sln_bwd_kernel<1, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
-                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb);
+                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode);
   });
   FFVC_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
+                            const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
+                            const float* rstd, const float* dres, float* dhl, float* dw, float* part_g, float* part_b,
+                            float* part_s, int64_t rows, int dim, void* stream) {
+  return sln_bwd_launch(dy, dy_dtype, hl, w, gamma, beta, gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b,
+                        part_s, rows, dim, stream, 0);
+}
+
+extern "C" int ffvc_sln_bwd_acc(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
+                                const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
+                                const float* rstd, const float* dres, float* dhl, float* dw, float* dgamma, float* dbeta,
+                                float* dscalars, int64_t rows, int dim, void* stream) {
+  return sln_bwd_launch(dy, dy_dtype, hl, w, gamma, beta, gamma_s, beta_s, mean, rstd, dres, dhl, dw, dgamma, dbeta,
+                        dscalars, rows, dim, stream, 1);
 }

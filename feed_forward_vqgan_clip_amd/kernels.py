@@ -396,6 +396,19 @@ def sln_bwd(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dres=None):
     return dhl, dw, dg, db, dsc[0:1], dsc[1:2]
 
 
+def sln_bwd_acc(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dgamma, dbeta, dscalars, dres=None):
+    """-> (dhl, dw); dgamma / dbeta ([dim]) and dscalars ([2] = {dgamma_s, dbeta_s}) are accumulated in place."""
+    _req_f32(hl, w, gamma, beta, gs, bs, mean, rstd, dgamma, dbeta, dscalars, dres)
+    _need_cuda(dy)
+    dim = hl.shape[-1]
+    rows = hl.numel() // dim
+    dhl, dw = torch.empty_like(hl), torch.empty_like(w)
+    _call("ffvc_sln_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), hl.data_ptr(), w.data_ptr(), gamma.data_ptr(),
+          beta.data_ptr(), gs.data_ptr(), bs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dhl.data_ptr(),
+          dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dscalars.data_ptr(), rows, dim, stream_ptr())
+    return dhl, dw
+
+
 def colsum(x, out, accumulate=False, ld=None):
     _req_f32(out)
     _need_cuda(x)

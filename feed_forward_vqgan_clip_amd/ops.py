@@ -731,6 +731,9 @@ class _SLNForkFn(Function):
         y, mean, rstd = K.sln_fwd(hl, w, g, b, gsd, bsd, out_dtype)
         ctx.save_for_backward(hl, w, g, b, gsd, bsd, mean, rstd)
         ctx.sshape = gs.shape
+        arena = getattr(gamma, "_ffvc_arena", None)
+        ctx.params = (gamma, beta, gs, bs) if (arena is not None and gamma.requires_grad and all(
+            getattr(p, "_ffvc_arena", None) is arena for p in (beta, gs, bs))) else None
         ctx.set_materialize_grads(False)
         return y, hl.view_as(hl)
 
@@ -741,6 +744,15 @@ class _SLNForkFn(Function):
             return dres, None, None, None, None, None, None
         if dres is not None:
             dres = _as(_contig(dres), torch.float32)
+        if ctx.params is not None:              # gradients straight into the flat bucket (see _LNForkFn)
+            gamma, beta, gs, bs = ctx.params
+            sc = torch.zeros(2, dtype=torch.float32, device=hl.device)
+            dhl, dw = K.sln_bwd_acc(_contig(dy), hl, w, g, b, gsd, bsd, mean, rstd, _grad_buf(gamma), _grad_buf(beta), sc,
+                                    dres=dres)
+            _grad_buf(gs).view(-1).add_(sc[0:1])          # the two scalar parameters live apart in the bucket
+            _grad_buf(bs).view(-1).add_(sc[1:2])
+            gamma._ffvc_arena.grad_written(gamma, beta, gs, bs)
+            return dhl, dw, None, None, None, None, None
         dhl, dw, dg, db, dgs, dbs = K.sln_bwd(_contig(dy), hl, w, g, b, gsd, bsd, mean, rstd, dres=dres)
         return dhl, dw, dg, db, dgs.view(ctx.sshape), dbs.view(ctx.sshape), None
 

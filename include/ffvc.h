@@ -155,6 +155,12 @@ int ffvc_sln_fwd(const float* hl, const float* w, const float* gamma, const floa
 int ffvc_sln_bwd(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma, const float* beta,
                  const float* gamma_s, const float* beta_s, const float* mean, const float* rstd, const float* dres,
                  float* dhl, float* dw, float* part_g, float* part_b, float* part_s, int64_t rows, int dim, void* stream);
+/* Same pass, dgamma / dbeta ([dim]) and dscalars ({dgamma_s, dbeta_s}) ACCUMULATED in place (fp32 atomics), like
+ * ffvc_layernorm_bwd_acc: no partial rows, no reduction launches. */
+int ffvc_sln_bwd_acc(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma, const float* beta,
+                     const float* gamma_s, const float* beta_s, const float* mean, const float* rstd, const float* dres,
+                     float* dhl, float* dw, float* dgamma, float* dbeta, float* dscalars, int64_t rows, int dim,
+                     void* stream);
 
 /* GroupNorm(G groups, affine) on NHWC [B, HW, C] with optional fused swish x*sigmoid(x):
  * taming Normalize()/nonlinearity() [upstream taming-transformers 0.0.6, SURVEY.md App. A.1].

@@ -10,6 +10,23 @@ import torch.multiprocessing as mp
 from torch import nn
 
 
+def _collect(q, procs, limit=150.0):
+    """Results of all ranks, failing fast when a rank died and after `limit` seconds (a hung rendezvous must not eat
+    the GPU budget of the caller)."""
+    import queue as _queue
+    import time as _time
+    res, deadline = [], _time.time() + limit
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a worker died with exit code {dead}"
+            assert _time.time() < deadline, f"ranks did not report within {limit:.0f} s"
+    res.sort(key=lambda t: t[0])
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -61,18 +78,15 @@ def test_dp_equivalence_world2(wire):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, wire, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = []
-    import queue as _queue
-    import time as _time
-    deadline = _time.time() + 120
-    while len(res) < len(procs):
-        try:
-            res.append(q.get(timeout=2))
-        except _queue.Empty:
-            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
-            assert not dead, f"a worker died with exit code {dead}"
-            assert _time.time() < deadline, "workers timed out"
-    res.sort(key=lambda t: t[0])
+    try:
+        res = _collect(q, procs)
+    finally:
+        for p in procs:                      # never leave a rank behind (it would keep the device / the port)
+            if p.is_alive():
+                p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
