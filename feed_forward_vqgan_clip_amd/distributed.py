@@ -35,6 +35,10 @@ def init(backend=None):
             torch.cuda.set_device(local_rank())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # single-node gloo: bind to loopback instead of resolving the (often unresolvable) container hostname,
+            # which can stall the rendezvous for minutes
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank())
