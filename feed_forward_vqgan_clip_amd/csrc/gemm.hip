@@ -24,6 +24,8 @@
 //     the very same staging/fragment code: a 16-byte chunk is 8 bf16 (one MFMA) or 4 f32 (four).
 //   * workgroup id -> tile map is XCD-aware (consecutive ids round-robin over the 8 XCDs, so
 //     each XCD gets a contiguous run of tiles that share operand panels in its private L2).
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok);   // gemm2.hip: 1 = handled, 0 = not eligible, <0 error
@@ -302,7 +304,7 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const u32x4_t& a
 
 template <typename T, int XMODE, int WMODE, bool TRSAFE>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, int tiles_n,
-                                                        int n_tiles, int ksplit_len, int vec_ok) {
+                                                        int n_tiles, int ksplit_len, int vec_ok, int gm) {
   using Tr = GemmTraits<T>;
   constexpr int BK = Tr::BK;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
@@ -320,7 +322,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ffvc_gemm_desc p, 
     const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  // wide outputs: walk the tiles in groups of gm tile-rows (column-major inside a group) so that the tiles an XCD works
+  // on at the same time form a compact block and share operand panels through its L2 (1 + 32 panels -> 8 + 4)
+  int tm, tn;
+  if (gm > 1) {
+    const int width = gm * tiles_n;
+    const int grp = tile / width, rem = tile - grp * width;
+    const int first = grp * gm;
+    const int gsz = min(n_tiles / tiles_n - first, gm);
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
   const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
@@ -400,8 +415,15 @@ int launch(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   split = ceil_div(d.K, ksplit_len);
   if (split < 1) split = 1;
   dim3 grid(n_tiles, d.batch, split);
+  static int gm_opt = -2;
+  if (gm_opt == -2) {
+    const char* e = getenv("FFVC_V1_GM");
+    gm_opt = e ? atoi(e) : -1;
+  }
+  int gm = gm_opt >= 0 ? gm_opt : ((tiles_n > 8 && tiles_m >= 2) ? 4 : 1);
+  if (gm > tiles_m) gm = tiles_m;
   hipLaunchKernelGGL((gemm_kernel<T, XMODE, WMODE, TRSAFE>), grid, dim3(NTHREADS), 0, st, d, tiles_n,
-                     n_tiles, ksplit_len, vec_ok);
+                     n_tiles, ksplit_len, vec_ok, gm);
   FFVC_LAUNCH_CHECK();
   return 0;
 }
