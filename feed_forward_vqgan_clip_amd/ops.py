@@ -12,6 +12,10 @@ Conventions
     materialises or adds weight gradients.
   * "fork" norms return (normed, identity) so that the skip connection's gradient re-enters the
     norm's backward kernel as `dres` instead of being added by autograd.
+  * producer -> consumer hints ride on the tensor OBJECT (autograd hands the same Python object from one
+    Function to the next): `t._ffvc_lo` = bf16 copy of an fp32 gradient written by LayerNorm backward (picked up
+    by `_as`), `t._ffvc_gn` = GroupNorm moments accumulated by the GEMM that produced `t` (picked up by
+    `_GNForkFn`).  A consumer that does not find the attribute (a view, a clone) simply does the work itself.
 """
 import math
 import os
