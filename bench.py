@@ -249,11 +249,14 @@ def main():
         out["step_tflop"] = tf_step
         out["step_mfma_frac"] = tf_step / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS
 
-    if rank == 0 and not args.no_roofline:
-        # one extra, event-bracketed step: per-launch HIP events on the launch stream (torch's current stream)
-        K.PROFILE = []
+    if not args.no_roofline:
+        # one extra, event-bracketed step: per-launch HIP events on the launch stream (torch's current stream).  EVERY
+        # rank runs it (its gradient all-reduces are collectives: a step on rank 0 alone would hang the others); only
+        # rank 0 keeps the per-launch events
+        K.PROFILE = [] if rank == 0 else None
         stepper(toks[:B])
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         prof, K.PROFILE = K.PROFILE, None
         agg = {}
         shapes = {}

@@ -30,7 +30,9 @@ def init(backend=None):
     _STATE["force"] = os.environ.get("FFVC_DP_FORCE") == "1"
     if (world > 1 or _STATE["force"]) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # FFVC_DP_BACKEND=gloo + FFVC_SHARE_DEVICE=1: several ranks on ONE GPU (RCCL refuses that) — lets a single-GPU
+            # box run the complete N-rank bench / train path for validation
+            backend = os.environ.get("FFVC_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -59,6 +61,8 @@ def size():
 
 
 def local_rank():
+    if os.environ.get("FFVC_SHARE_DEVICE") == "1":
+        return 0
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 

@@ -401,7 +401,7 @@ def train(config_file):
                 nxt = (data[0][sel].cuda(), data[1][sel].cuda())
             loss, mid = stepper(inp, None if data[0] is data[1] else out,
                                 next_inp=nxt[0] if (nxt is not None and data[0] is data[1]) else None)
-            if step % log_interval == 0 or log_f is None:
+            if step % log_interval == 0:                 # a collective: EVERY rank takes it at the same steps
                 (loss_r,) = hvd.allreduce_scalars(loss)
             else:
                 loss_r = loss
