@@ -414,6 +414,9 @@ int launch(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   const int ksplit_len = ceil_div(ksteps, split) * BK;
   split = ceil_div(d.K, ksplit_len);
   if (split < 1) split = 1;
+  // Partial slabs: the caller sized and will reduce exactly d.split_k slabs, so launch that many K slices; a slice
+  // whose K range is empty runs zero K steps and stores a zero tile (never leave a slab unwritten).
+  if (d.slab_stride != 0 && d.split_k > split) split = d.split_k;
   dim3 grid(n_tiles, d.batch, split);
   static int gm_opt = -2;
   if (gm_opt == -2) {

@@ -607,6 +607,9 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   const int ksplit_len = ceil_div(ksteps, split) * BK;
   split = ceil_div(d.K, ksplit_len);
   if (split < 1) split = 1;
+  // Partial slabs: the caller sized and will reduce exactly d.split_k slabs, so launch that many K slices; a slice
+  // whose K range is empty runs zero K steps and stores a zero tile (never leave a slab unwritten).
+  if (d.slab_stride != 0 && d.split_k > split) split = d.split_k;
   dim3 grid(n_tiles, d.batch, split);
   constexpr int nthreads = 64 * 2 * (BN / 64);
   // stage ring + one 4 KiB row-store pad per wave (256x256: 128 + 32 = all 160 KiB of the CU)

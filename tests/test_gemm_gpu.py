@@ -277,3 +277,19 @@ def test_gn_sums_from_epilogue(cuda, kind):
     a = K.groupnorm_fwd(yv, gamma, beta, swish=True)
     b = K.groupnorm_fwd(yv, gamma, beta, swish=True, sums=sums)
     assert _rel(b[0], a[0]) < 1e-2 and _rel(b[1], a[1]) < 2e-3 and _rel(b[2], a[2]) < 2e-3
+
+
+@pytest.mark.parametrize("dt,Kred,sk", [(torch.bfloat16, 65536, 48), (torch.float32, 65536, 48), (torch.bfloat16, 1000, 7)])
+def test_splitk_slabs_all_written(cuda, dt, Kred, sk):
+    """Regression: ceil(K / ceil(ksteps/split)*BK) can be < split_k (48 -> 47 at K=65536), and the
+    trailing slab used to stay unwritten while ffvc_slab_reduce summed it.  Poison the caching allocator with NaNs so
+    a recycled, unwritten slab cannot hide behind freshly zeroed VRAM."""
+    M, N = 256, 128
+    x, w = _mk((M, Kred), dt, cuda, 1, 0.1), _mk((N, Kred), dt, cuda, 2, 0.1)
+    out = _mk((M, N), torch.float32, cuda, 3)
+    ref = out.double() + x.double() @ w.double().T
+    poison = torch.full((sk, M, N), float("nan"), dtype=torch.float32, device=cuda)
+    del poison                                   # the next torch.empty(sk, M, N) recycles this block
+    K.gemm_splitk_accumulate(x, w, out, M, N, Kred, sk, ldx=Kred, ldw=Kred)
+    assert torch.isfinite(out).all(), "an unwritten split-K slab leaked into the reduction"
+    assert _rel(out, ref) < 1e-4           # fp32 accumulation order over up to 65536 terms
