@@ -133,7 +133,12 @@ _SIGNATURES = {
     "ffvc_spherical_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                     c_void_p]),
     "ffvc_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float,
-                          c_float, c_int, c_float, c_void_p]),
+                          c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "ffvc_clip_coef": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "ffvc_mean_sq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ffvc_mean_sq_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ffvc_tv_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_tv_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_rowsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "ffvc_copy_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "ffvc_im2col3x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

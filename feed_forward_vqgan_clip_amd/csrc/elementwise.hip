@@ -431,7 +431,9 @@ template <typename ST>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, ST* __restrict__ shadow,
                                                    int64_t n, float lr, float b1, float b2, float eps, float bc1,
-                                                   float bc2_sqrt, float gscale) {
+                                                   float bc2_sqrt, float gscale, float* __restrict__ ema, float ema_w,
+                                                   const float* __restrict__ dev_scale) {
+  if (dev_scale) gscale *= dev_scale[0];      // global-norm clip coefficient computed on the device (no host sync)
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4_t pv = load4(p + i * 4), gv = load4(g + i * 4), mv = load4(m + i * 4), vv = load4(v + i * 4);
@@ -447,6 +449,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     store4(m + i * 4, mv);
     store4(v + i * 4, vv);
     if (shadow) store4(shadow + i * 4, pv);
+    if (ema) {   // torch_ema: shadow -= (1 - decay) * (shadow - param), after the optimizer step (main.py:843-844)
+      f32x4_t ev = load4(ema + i * 4);
+      ev -= ema_w * (ev - pv);
+      store4(ema + i * 4, ev);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
@@ -458,6 +465,61 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     v[i] = vv;
     p[i] = pp;
     if (shadow) ElemTraits<ST>::store(shadow + i, pp);
+    if (ema) ema[i] -= ema_w * (ema[i] - pp);
+  }
+}
+
+// ---- optional regularisers of the step (main.py:758-762 l2 = mean(z^2); :423-428,769-773 tv_loss) -------------------
+// out[0] += scale * sum x^2  (out zeroed by the launcher)
+__global__ __launch_bounds__(256) void mean_sq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                      float scale) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += x[i] * x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+__global__ __launch_bounds__(256) void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        float* __restrict__ y, int64_t n, float c) {
+  const float f = g[0] * c;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * f;
+}
+// x: NHWC fp32 (B, H, W, C).  out[0] += 0.5 * (sum_h |x[h+1]-x[h]| / Nh + sum_w |x[w+1]-x[w]| / Nw)
+__global__ __launch_bounds__(256) void tv_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H,
+                                                     int W, int C, float inv_nh, float inv_nw) {
+  __shared__ float red[4];
+  const int64_t n = (int64_t)B * H * W * C, rowc = (int64_t)W * C;
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i / C;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const float v = x[i];
+    if (h + 1 < H) a += fabsf(x[i + rowc] - v) * inv_nh;
+    if (w + 1 < W) a += fabsf(x[i + C] - v) * inv_nw;
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, 0.5f * (red[0] + red[1] + red[2] + red[3]));
+}
+__device__ __forceinline__ float sgn_(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+__global__ __launch_bounds__(256) void tv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                     float* __restrict__ dx, int B, int H, int W, int C, float inv_nh,
+                                                     float inv_nw) {
+  const int64_t n = (int64_t)B * H * W * C, rowc = (int64_t)W * C;
+  const float gg = 0.5f * g[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i / C;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const float v = x[i];
+    float d = 0.f;
+    if (h > 0) d += sgn_(v - x[i - rowc]) * inv_nh;
+    if (h + 1 < H) d -= sgn_(x[i + rowc] - v) * inv_nh;
+    if (w > 0) d += sgn_(v - x[i - C]) * inv_nw;
+    if (w + 1 < W) d -= sgn_(x[i + C] - v) * inv_nw;
+    dx[i] = gg * d;
   }
 }
 
@@ -854,10 +916,11 @@ extern "C" int ffvc_spherical_loss(const float* embed, const float* feats, float
 }
 
 extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n,
-                         float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+                         float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* ema,
+                         float ema_weight, const float* dev_scale, void* stream) {
   FFVC_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "ffvc_adam: bad args");
   FFVC_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
-                     ((uintptr_t)v % 16) == 0 && ((uintptr_t)shadow % 16) == 0,
+                     ((uintptr_t)v % 16) == 0 && ((uintptr_t)shadow % 16) == 0 && ((uintptr_t)ema % 16) == 0,
                  "ffvc_adam: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const float bc1 = 1.0f - powf(beta1, (float)step);
@@ -865,10 +928,61 @@ extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* sha
   const int grid = ew_grid(n / 4 + 1, 256);
   if (shadow && shadow_dtype == FFVC_BF16)
     hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (uint16_t*)shadow, n, lr, beta1,
-                       beta2, eps, bc1, bc2s, grad_scale);
+                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
   else
     hipLaunchKernelGGL((adam_kernel<float>), dim3(grid), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2,
-                       eps, bc1, bc2s, grad_scale);
+                       eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_mean_sq(const float* x, float* out, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(x && out && n > 0, "ffvc_mean_sq: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return FFVC_E_BADARG;
+  hipLaunchKernelGGL(mean_sq_kernel, dim3(ew_grid(n, 2048)), dim3(256), 0, st, x, out, n, 1.0f / (float)n);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_mean_sq_bwd(const float* x, const float* g, float* dx, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(x && g && dx && n > 0, "ffvc_mean_sq_bwd: bad args");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, g, dx, n,
+                     2.0f / (float)n);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_tv_loss_fwd(const float* x, float* out, int B, int H, int W, int C, void* stream) {
+  FFVC_CHECK_ARG(x && out && B > 0 && H > 1 && W > 1 && C > 0, "ffvc_tv_loss_fwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return FFVC_E_BADARG;
+  const int64_t n = (int64_t)B * H * W * C;
+  const float inh = 1.0f / ((float)B * C * (H - 1) * W), inw = 1.0f / ((float)B * C * H * (W - 1));
+  hipLaunchKernelGGL(tv_fwd_kernel, dim3(ew_grid(n, 2048)), dim3(256), 0, st, x, out, B, H, W, C, inh, inw);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_tv_loss_bwd(const float* x, const float* g, float* dx, int B, int H, int W, int C, void* stream) {
+  FFVC_CHECK_ARG(x && g && dx && B > 0 && H > 1 && W > 1 && C > 0, "ffvc_tv_loss_bwd: bad args");
+  const int64_t n = (int64_t)B * H * W * C;
+  const float inh = 1.0f / ((float)B * C * (H - 1) * W), inw = 1.0f / ((float)B * C * H * (W - 1));
+  hipLaunchKernelGGL(tv_bwd_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, g, dx, B, H, W, C, inh,
+                     inw);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float gscale, float* __restrict__ out) {
+  const float total = sqrtf(sumsq[0]) * fabsf(gscale);        // norm of the gradients as the optimizer will see them
+  out[0] = fminf(1.0f, max_norm / (total + 1e-6f));           // torch.nn.utils.clip_grad_norm_ (main.py:833-834)
+  out[1] = total;
+}
+
+extern "C" int ffvc_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* out, void* stream) {
+  FFVC_CHECK_ARG(sumsq && out && max_norm > 0.f, "ffvc_clip_coef: bad args");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, grad_scale, out);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

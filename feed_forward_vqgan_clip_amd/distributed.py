@@ -141,6 +141,23 @@ class DistributedOptimizer:
         cur, cur_end, cur_bytes = [], None, 0
         for i in reversed(range(len(a.plist))):
             o, n = a.param_range(a.plist[i])
+            if n * 4 >= 2 * bucket_bytes:
+                # One tensor larger than two buckets (Mixer `proj.weight` = 134 MB, the LAST gradient of the backward
+                # pass): close the running bucket and cut the tensor into bucket-sized slices that all become ready
+                # together and go out back to back, so RCCL pipelines them over the links instead of one long ring pass
+                # serialised behind a single launch.
+                if cur:
+                    self.buckets.append((a.param_range(a.plist[cur[-1]])[0], cur_end, cur))
+                    cur, cur_end, cur_bytes = [], None, 0
+                end = self._aligned_end(i)
+                nsl = (n * 4 + bucket_bytes - 1) // bucket_bytes
+                per = ((end - o + nsl - 1) // nsl + 63) // 64 * 64
+                cuts = [min(o + k * per, end) for k in range(nsl + 1)]
+                cuts[-1] = end
+                for k in reversed(range(nsl)):
+                    if cuts[k] < cuts[k + 1]:
+                        self.buckets.append((cuts[k], cuts[k + 1], [i]))
+                continue
             if cur_end is None:
                 cur_end = self._aligned_end(i)
             cur.append(i)
@@ -150,10 +167,10 @@ class DistributedOptimizer:
                 cur, cur_end, cur_bytes = [], None, 0
         if cur:
             self.buckets.append((a.param_range(a.plist[cur[-1]])[0], cur_end, cur))
-        self._bucket_of = {}
+        self._bucket_of = {}                # id(param) -> [bucket indices] (several for a sliced tensor)
         for b, (_, _, idxs) in enumerate(self.buckets):
             for i in idxs:
-                self._bucket_of[id(a.plist[i])] = b
+                self._bucket_of.setdefault(id(a.plist[i]), []).append(b)
         self._pending = [len(idxs) for _, _, idxs in self.buckets]
         self._seen = set()
         self._handles = {}
@@ -173,10 +190,10 @@ class DistributedOptimizer:
         if not is_distributed() or id(p) in self._seen:
             return
         self._seen.add(id(p))
-        b = self._bucket_of[id(p)]
-        self._pending[b] -= 1
-        if self._pending[b] == 0:
-            self._launch(b)
+        for b in self._bucket_of[id(p)]:
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -250,6 +267,18 @@ class DistributedOptimizer:
             self.arena.grads.div_(size())
         self._prescaled = False
         return self.opt.step()
+
+    def __getattr__(self, name):
+        # everything else (loss_scale, enable_ema, ema_state_dict, ...) is the wrapped optimizer's business
+        if name in ("opt", "arena"):
+            raise AttributeError(name)
+        return getattr(self.opt, name)
+
+    def __setattr__(self, name, value):
+        if name == "loss_scale" and "opt" in self.__dict__:
+            setattr(self.opt, name, value)
+        else:
+            object.__setattr__(self, name, value)
 
     def state_dict(self):
         return self.opt.state_dict()

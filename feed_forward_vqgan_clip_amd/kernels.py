@@ -509,12 +509,53 @@ def spherical_loss(embed, feats, coef=1.0, want_grad=True):
     return loss, dembed
 
 
-def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    _req_f32(p, g, m, v)
+def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0, ema=None, ema_weight=0.0, dev_scale=None):
+    """ema (fp32, same layout as p): torch_ema update folded into the pass, ema -= ema_weight * (ema - p_new).
+    dev_scale (fp32 device scalar): multiplied into grad_scale on the device (clip_grad_norm_ coefficient)."""
+    _req_f32(p, g, m, v, ema, dev_scale)
     _need_cuda(shadow)
     _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
           dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
-          stream_ptr())
+          _ptr(ema), float(ema_weight), _ptr(dev_scale), stream_ptr())
+
+
+def clip_coef(sumsq_buf, max_norm, grad_scale):
+    """-> fp32 [2] device tensor: (clip coefficient, total gradient norm)."""
+    _req_f32(sumsq_buf)
+    out = torch.empty(2, dtype=torch.float32, device=sumsq_buf.device)
+    _call("ffvc_clip_coef", sumsq_buf.data_ptr(), float(max_norm), float(grad_scale), out.data_ptr(), stream_ptr())
+    return out
+
+
+def mean_sq(x):
+    _req_f32(x)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    _call("ffvc_mean_sq", x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr())
+    return out
+
+
+def mean_sq_bwd(x, g):
+    _req_f32(x, g)
+    dx = torch.empty_like(x)
+    _call("ffvc_mean_sq_bwd", x.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(), stream_ptr())
+    return dx
+
+
+def tv_loss_fwd(x):
+    """x: NHWC fp32 (B, H, W, C) -> scalar tv_loss (main.py:423-428)."""
+    _req_f32(x)
+    B, H, W, C = x.shape
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    _call("ffvc_tv_loss_fwd", x.data_ptr(), out.data_ptr(), B, H, W, C, stream_ptr())
+    return out
+
+
+def tv_loss_bwd(x, g):
+    _req_f32(x, g)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _call("ffvc_tv_loss_bwd", x.data_ptr(), g.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr())
+    return dx
 
 
 def sumsq(x, out):

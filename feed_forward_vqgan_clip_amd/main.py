@@ -141,9 +141,8 @@ class MakeCutouts(nn.Module):
 
 
 def tv_loss(Y_hat):
-    """main.py:423-428 (optional regulariser, tv_coef defaults to 0; plain autograd ops, off the default path)."""
-    return 0.5 * (torch.abs(Y_hat[:, :, 1:, :] - Y_hat[:, :, :-1, :]).mean() +
-                  torch.abs(Y_hat[:, :, :, 1:] - Y_hat[:, :, :, :-1]).mean())
+    """main.py:423-428 on an NCHW batch, computed by ffvc_tv_loss_fwd/bwd on the NHWC view."""
+    return ops.tv_loss_nhwc(Y_hat.permute(0, 2, 3, 1).float())
 
 
 def _cdt(config):
@@ -178,16 +177,37 @@ def synthetic_tokens(n, seed=0, context_length=77):
     return toks
 
 
-def load_dataset(path):
-    """main.py:1293-1306.  `.pkl` files (token tensor or (inp, out) feature tuple) load as in the reference;
-    `synthetic:<n>[:seed]` yields seeded token rows; raw text needs the CLIP BPE vocabulary, which is not shipped."""
+def load_dataset(path, bpe_path=None):
+    """main.py:1293-1306.  `.pkl` files (token tensor or (inp, out) feature tuple) load as in the reference; a text file
+    (one prompt per line) or a glob of text files is tokenised with the CLIP BPE tokenizer (tokenizer.py; the vocabulary
+    file is not shipped: FFVC_BPE_VOCAB / bpe_path); `synthetic:<n>[:seed]` yields seeded token rows."""
     if path.startswith("synthetic:"):
         parts = path.split(":")
         return synthetic_tokens(int(parts[1]), int(parts[2]) if len(parts) > 2 else 0)
     if path.endswith("pkl"):
         return torch.load(path, weights_only=False)
-    raise NotImplementedError("text prompts need clip.tokenize (BPE vocabulary not available offline); pre-tokenise to "
-                              "a .pkl or use path: synthetic:<n>  (SURVEY.md §8f row n4)")
+    from . import tokenizer
+    if "*" in path:
+        from glob import glob
+        texts = [open(f).read().strip() for f in sorted(glob(path))]
+    else:
+        texts = [t.strip() for t in open(path).readlines()]
+    return tokenizer.tokenize(texts, truncate=True, bpe_path=bpe_path)
+
+
+def tokenize(paths, out="tokenized.pkl", max_length=None, batch_size=None, bpe_path=None):
+    """main.py:395-421: tokenise a prompt file / glob once and save the int64 rows to a `.pkl` dataset."""
+    from . import tokenizer
+    if "*" in paths:
+        from glob import glob
+        texts = [open(f).read().strip() for f in sorted(glob(paths))]
+    else:
+        texts = [ln.strip() for ln in open(paths).readlines()]
+        if max_length:
+            texts = [t for t in texts if len(t) <= max_length]
+    toks = tokenizer.tokenize(texts, truncate=True, bpe_path=bpe_path)
+    torch.save(toks, out)
+    return toks
 
 
 def build_model(config, vq_channels=None):
@@ -284,8 +304,9 @@ class TrainStep:
         ev.record(side)
         self._prefetched = ((tokens.data_ptr(), tuple(tokens.shape)), feats, ev, tokens)
 
-    def forward_loss(self, inp, out=None, facs=None, noise=None, aug_params=None):
-        """main.py:729-811 -> (loss, intermediates)."""
+    def forward_loss(self, inp, out=None, facs=None, noise=None, aug_params=None, noise_vec_in=None):
+        """main.py:729-811 -> (loss, intermediates).  facs / noise / aug_params / noise_vec_in pin the step's random
+        draws (cutout noise, augmentation parameters, the mapper's conditioning noise) for parity tests."""
         inp_feats = self.features(inp)                                          # :733
         if self.normalize_input:
             inp_feats = torch.nn.functional.normalize(inp_feats, dim=1)         # :734-735
@@ -295,8 +316,11 @@ class TrainStep:
         if self.repeat != 1:
             inp_feats = inp_feats.repeat(self.repeat, 1)                        # :739-740
             out_feats = out_feats.repeat(self.repeat, 1)
-        inp_feats_net = inp_feats
-        if self.noise_dim:                                                      # :741-751
+        inp_feats_net, noise_vec = inp_feats, None
+        if self.noise_dim and noise_vec_in is not None:
+            noise_vec = noise_vec_in
+            inp_feats_net = torch.cat((inp_feats, noise_vec), dim=1)
+        elif self.noise_dim:                                                    # :741-751
             if self.nb_noise:
                 inds = torch.randperm(len(self.NOISE))[:self.repeat]
                 noise_vec = self.NOISE[inds.to(self.NOISE.device)].repeat(bs, 1).view(bs, self.repeat, -1) \
@@ -305,27 +329,32 @@ class TrainStep:
                 noise_vec = torch.randn(len(inp_feats), self.noise_dim, device=inp_feats.device)
             inp_feats_net = torch.cat((inp_feats, noise_vec), dim=1)
         z = self.net(inp_feats_net)                                             # :754
-        l2 = (z ** 2).mean() if self.l2_coef > 0 else None                      # :758-762 (optional, plain autograd)
         z_nhwc = z.permute(0, 2, 3, 1)                                          # contiguous for NHWC-native mappers
+        l2 = ops.mean_sq(z_nhwc) if self.l2_coef > 0 else None                  # :758-762 (mean is layout-independent)
         z_nhwc = ops.clamp_with_grad(z_nhwc, self.vq.z_min, self.vq.z_max)      # :763
         xr, idx = synth_nhwc(self.vq, z_nhwc)                                   # :767
         patches = self.make_cutouts.patches(xr, self.perceptor.patch, tuple(CLIP_MEAN), tuple(CLIP_STD),
                                             self.perceptor.cdt, facs, noise, aug_params)   # :796-797 fused
         embed = self.perceptor.encode_patches(patches)                          # :799
-        loss = ops.spherical_loss(embed, out_feats, self.target_loss_coef)      # :801-811
+        dists = ops.spherical_loss(embed, out_feats, self.target_loss_coef)     # :801-811
         if self.input_loss:
-            loss = loss + ops.spherical_loss(embed, inp_feats, self.input_loss_coef)   # :812-824
+            dists = dists + ops.spherical_loss(embed, inp_feats, self.input_loss_coef)   # :812-824
+        loss = dists
+        tv = None
         if l2 is not None:
             loss = loss + self.l2_coef * l2                                     # :831
         if self.tv_coef > 0:
-            loss = loss + self.tv_coef * tv_loss(xr.permute(0, 3, 1, 2))        # :769-773,831 (optional, plain autograd)
-        return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats}
+            tv = ops.tv_loss_nhwc(xr)                                           # :769-773
+            loss = loss + self.tv_coef * tv                                     # :831
+        return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats, "dists": dists,
+                      "l2": l2, "tv": tv, "noise_vec": noise_vec}
 
-    def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None, next_inp=None):
-        loss, mid = self.forward_loss(inp, out, facs, noise, aug_params)
+    def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None, next_inp=None, noise_vec_in=None):
+        loss, mid = self.forward_loss(inp, out, facs, noise, aug_params, noise_vec_in)
         self.prefetch(next_inp)                                                 # next batch's text tower under this backward
         self.opt.zero_grad()                                                    # :825
-        loss.backward()                                                         # :832
+        ls = getattr(self.opt, "loss_scale", 1.0)
+        (loss if ls == 1.0 else loss * ls).backward()                           # :832 (f16 mode: loss-scaled gradients)
         if self.clip_grad_norm:
             self.opt.clip_grad_norm_(self.clip_grad_norm)                       # :833-834 (after the exchange in DP)
         self.opt.step()                                                         # :835
@@ -334,12 +363,45 @@ class TrainStep:
         return loss.detach(), mid
 
 
+def make_grid(images, nrow=8, padding=2):
+    """torchvision.utils.make_grid for a (N,3,H,W) float batch in [0,1] (main.py:899-901) -> uint8 HxWx3 numpy array."""
+    import numpy as np
+    x = images.detach().float().cpu().clamp(0, 1)
+    n, c, h, w = x.shape
+    xmaps = min(nrow, n)
+    ymaps = int(math.ceil(n / xmaps))
+    H, W = h + padding, w + padding
+    grid = torch.zeros(c, H * ymaps + padding, W * xmaps + padding)
+    for k in range(n):
+        yy, xx = divmod(k, xmaps)
+        grid[:, yy * H + padding:yy * H + padding + h, xx * W + padding:xx * W + padding + w] = x[k]
+    return (grid.permute(1, 2, 0) * 255).add_(0.5).clamp_(0, 255).to(torch.uint8).numpy() if c == 3 else \
+        np.repeat((grid[0] * 255).add_(0.5).clamp_(0, 255).to(torch.uint8).numpy()[:, :, None], 3, axis=2)
+
+
+def save_grid(images, path, nrow=8):
+    from PIL import Image
+    Image.fromarray(make_grid(images, nrow=nrow)).save(path)
+
+
+@torch.no_grad()
+def generate(net, vq, feats):
+    """Forward-only mapper -> clamp -> VQ -> decoder (main.py:934-942,1057-1059): (n, clip_dim[+noise]) -> (n,3,H,W)."""
+    z = net(feats)
+    z_nhwc = ops.clamp_with_grad(z.permute(0, 2, 3, 1), vq.z_min, vq.z_max)
+    xr, _ = synth_nhwc(vq, z_nhwc)
+    return xr.permute(0, 3, 1, 2)
+
+
 def train(config_file):
-    """main.py:504-974 (train loop; logging reduced to stdout + JSONL scalars, checkpoints as in the reference)."""
+    """main.py:504-974: the train loop with the reference's artefacts — `checkpoint.th` / `checkpoint_ema.th` / `opt.th`
+    (same dict layouts), `progress*.png` / `fixed_batch_progress*.png` grids, fast CLIP-score evaluation (`eval_path`),
+    scalars `loss, dists, diversity, l2, tv` (JSONL instead of tensorboard, which is not installed offline)."""
     config = Config.load(config_file)
     if "folder" not in config:
         config.folder = os.path.dirname(config_file)
     os.makedirs(config.folder, exist_ok=True)
+    use_ema = config.get("use_ema", False)
     hvd.init()
     if torch.cuda.is_available():
         torch.cuda.set_device(hvd.local_rank())
@@ -349,6 +411,7 @@ def train(config_file):
     perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt)
     vq_channels = vq.codebook.shape[1]
     checkpoint_path = os.path.join(config.folder, "checkpoint.th")
+    checkpoint_ema_path = os.path.join(config.folder, "checkpoint_ema.th")
     net = build_model(config, vq_channels)
     net.step, net.epoch = 0, 0
     if os.path.exists(checkpoint_path):
@@ -358,11 +421,18 @@ def train(config_file):
         net.epoch, net.step = ckpt["epoch"], ckpt["step"]
     net = net.cuda().prepare(cdt)
     net.config = config
-    opt = FusedAdam(net.parameters(), lr=config.lr)
+    base_lr = config.lr
+    opt = FusedAdam(net.parameters(), lr=base_lr)
+    opt.loss_scale = float(config.get("loss_scale", 4096.0 if cdt == torch.float16 else 1.0))
     opt_path = os.path.join(config.folder, "opt.th")
     if os.path.exists(opt_path):
         print(f"Resuming optimizer state from {opt_path}")
         opt.load_state_dict(torch.load(opt_path, map_location="cpu", weights_only=False))
+    if use_ema:                                                                   # main.py:598-616
+        ema_state = None
+        if os.path.exists(checkpoint_ema_path):
+            ema_state = torch.load(checkpoint_ema_path, map_location="cpu", weights_only=False)["state_dict"]
+        opt.enable_ema(config.get("ema_decay", 0.995), ema_state)
     log_interval = config.get("log_interval", 100)
     rank_zero = hvd.rank() == 0
     if hvd.size() > 1:
@@ -371,61 +441,172 @@ def train(config_file):
         hvd.broadcast_optimizer_state(opt, root_rank=0)
     scheduler = None
     if config.get("scheduler") is not None:
-        if config.scheduler == "cosine":
-            scheduler = CosineAnnealingLR(opt, T_max=config.max_steps, eta_min=0)
+        if config.scheduler == "cosine":                                          # main.py:702-709; resumes mid-schedule
+            scheduler = CosineAnnealingLR(opt, T_max=config.max_steps, eta_min=0, base_lrs=[base_lr], last_epoch=net.step)
         else:
             raise ValueError(config.scheduler)
-    if isinstance(toks, tuple):
-        data = tuple(toks)
-    else:
-        data = (toks, toks)
+    data = tuple(toks) if isinstance(toks, tuple) else (toks, toks)
+    same = data[0] is data[1]
     print(f"Number of examples:{len(data[0])}")
+    eval_data = load_dataset(config.eval_path) if config.get("eval_path") else None      # main.py:661-666
+    eval_perceptor = perceptor
+    if eval_data is not None and config.get("eval_clip_model"):
+        eval_perceptor = load_clip_model(config.eval_clip_model, path=config.get("eval_clip_model_path"), cdt=cdt)
     bs = config.batch_size
     sampler = hvd.DistributedSampler(len(data[0]), shuffle=True)
     stepper = TrainStep(config, net, vq, perceptor, opt, scheduler)
+    first_sel = torch.tensor(list(iter(sampler))[:bs])
+    first_batch = (data[0][first_sel], data[1][first_sel])                       # main.py:679
     log_f = open(os.path.join(config.folder, "scalars.jsonl"), "a") if rank_zero else None
-    avg_loss, step = 1.0, net.step
+    avg_dev = torch.ones((), dtype=torch.float32, device="cuda")                  # avg_loss = 1. (main.py:694)
+    step = net.step
     t_last = time.time()
-    for epoch in range(net.epoch, config.epochs):
-        sampler.set_epoch(epoch)
-        order = list(iter(sampler))
-        nxt = None
-        for i in range(0, len(order), bs):
-            if nxt is None:
-                sel = torch.tensor(order[i:i + bs])
-                nxt = (data[0][sel].cuda(), data[1][sel].cuda())
-            inp, out = nxt
+    zero = torch.zeros((), dtype=torch.float32, device="cuda")
+    try:
+        for epoch in range(net.epoch, config.epochs):
+            sampler.set_epoch(epoch)
+            order = list(iter(sampler))
             nxt = None
-            if i + bs < len(order):                      # one batch of look-ahead for the text-tower prefetch
-                sel = torch.tensor(order[i + bs:i + 2 * bs])
-                nxt = (data[0][sel].cuda(), data[1][sel].cuda())
-            loss, mid = stepper(inp, None if data[0] is data[1] else out,
-                                next_inp=nxt[0] if (nxt is not None and data[0] is data[1]) else None)
-            if step % log_interval == 0:                 # a collective: EVERY rank takes it at the same steps
-                (loss_r,) = hvd.allreduce_scalars(loss)
-            else:
-                loss_r = loss
-            if rank_zero and step % log_interval == 0:
-                lv = float(loss_r.item())
-                avg_loss = lv * 0.01 + avg_loss * 0.99
-                dt, t_last = time.time() - t_last, time.time()
-                print(f"epoch:{epoch:03d}, step:{step:05d}, avg_loss:{avg_loss:.3f}, loss:{lv:.3f}, dists:{lv:.3f}, "
-                      f"sec/interval:{dt:.2f}")
-                log_f.write(json.dumps({"step": step, "loss": lv, "dists": lv}) + "\n")
-                log_f.flush()
-                net.step = step
-                torch.save({"state_dict": net.state_dict(), "config": dict(config), "step": step, "epoch": epoch},
-                           checkpoint_path)
-                torch.save(opt.state_dict(), opt_path)
-            step += 1
-            if config.get("max_steps") is not None and step >= config.max_steps:
-                return
+            for i in range(0, len(order), bs):
+                if nxt is None:
+                    sel = torch.tensor(order[i:i + bs])
+                    nxt = (data[0][sel].cuda(), data[1][sel].cuda())
+                inp, out = nxt
+                nxt = None
+                if i + bs < len(order):                  # one batch of look-ahead for the text-tower prefetch
+                    sel = torch.tensor(order[i + bs:i + 2 * bs])
+                    nxt = (data[0][sel].cuda(), data[1][sel].cuda())
+                loss, mid = stepper(inp, None if same else out, next_inp=nxt[0] if (nxt is not None and same) else None)
+                avg_dev.mul_(0.99).add_(loss, alpha=0.01)        # main.py:861, every step, no host sync
+                if step % log_interval == 0:                     # a collective: EVERY rank takes it at the same steps
+                    sc = hvd.allreduce_scalars(loss, mid["dists"].detach(), zero if mid["l2"] is None else mid["l2"].detach(),
+                                               zero if mid["tv"] is None else mid["tv"].detach(), avg_dev)
+                    if rank_zero:
+                        lv, dv, l2v, tvv, avg = [float(t.item()) for t in sc]
+                        dt, t_last = time.time() - t_last, time.time()
+                        print(f"epoch:{epoch:03d}, step:{step:05d}, avg_loss:{avg:.3f}, loss:{lv:.3f}, dists:{dv:.3f}, "
+                              f"div:0.000, l2:{l2v:.3f} tv:{tvv} sec/interval:{dt:.2f}")
+                        rec = {"step": step, "loss": lv, "dists": dv, "diversity": 0.0, "l2": l2v, "tv": tvv, "avg_loss": avg,
+                               "lr": opt.param_groups[0]["lr"]}
+                        if eval_data is not None:
+                            rec.update(_fast_eval(net, vq, eval_perceptor, eval_data, bs, stepper.clip_size))
+                            print(f"Eval dists: {rec['eval_dists']:.3f}\nEval clip score: {rec['eval_clip_score']:.3f}")
+                        log_f.write(json.dumps(rec) + "\n")
+                        log_f.flush()
+                        xr = mid["xr"].detach().permute(0, 3, 1, 2)
+                        save_grid(xr, os.path.join(config.folder, "progress.png"), nrow=bs)           # main.py:899-901
+                        save_grid(xr, os.path.join(config.folder, f"progress_{step:010d}.png"), nrow=bs)
+                        net.step = step
+                        torch.save({"state_dict": net.state_dict(), "config": dict(config), "step": step, "epoch": epoch},
+                                   checkpoint_path)
+                        if use_ema:
+                            torch.save({"state_dict": opt.ema_state_dict(), "config": dict(config), "step": step,
+                                        "epoch": epoch}, checkpoint_ema_path)
+                        torch.save(opt.state_dict(), opt_path)
+                        _save_fixed_batch(stepper, first_batch, use_ema, os.path.join(config.folder, "fixed_batch_progress"),
+                                          step, bs)
+                step += 1
+                if config.get("max_steps") is not None and step >= config.max_steps:
+                    return
+    finally:
+        if log_f is not None:
+            log_f.close()
+
+
+@torch.no_grad()
+def _fast_eval(net, vq, perceptor, eval_data, bs, clip_size):
+    """main.py:868-897: CLIP distance / score of images generated for held-out prompts (bilinear resize to clip_size)."""
+    ds, cs = [], []
+    scale = perceptor.logit_scale.exp().float().cpu()
+    mean = torch.tensor(CLIP_MEAN, device="cuda").view(1, -1, 1, 1)
+    std = torch.tensor(CLIP_STD, device="cuda").view(1, -1, 1, 1)
+    for i in range(0, len(eval_data), bs):
+        chunk = eval_data[i:i + bs].cuda()
+        emb = perceptor.encode_text(chunk).float() if chunk.dtype == torch.long else chunk.float()
+        xr = generate(net, vq, emb)
+        xr = torch.nn.functional.interpolate(xr, size=(clip_size, clip_size), mode="bilinear")
+        embed = torch.nn.functional.normalize(perceptor.encode_image((xr - mean) / std).float(), dim=1)
+        H = torch.nn.functional.normalize(emb, dim=-1)
+        ds.append(H.sub(embed).norm(dim=-1).div(2).arcsin().pow(2).mul(2).cpu())
+        cs.append((scale * (H * embed).sum(dim=1).cpu()))
+    return {"eval_dists": float(torch.cat(ds).mean()), "eval_clip_score": float(torch.cat(cs).mean())}
+
+
+@torch.no_grad()
+def _save_fixed_batch(stepper, first_batch, use_ema, prefix, step, bs):
+    """main.py:920-948: images of a fixed batch, with the EMA weights when enabled."""
+    inp = first_batch[0].cuda()
+    feats = stepper.features(inp)
+    if stepper.normalize_input:
+        feats = torch.nn.functional.normalize(feats, dim=1)
+    if stepper.noise_dim:
+        nz = stepper.NOISE[:len(feats)] if stepper.NOISE is not None and len(stepper.NOISE) >= len(feats) else \
+            torch.randn(len(feats), stepper.noise_dim, device=feats.device)
+        feats = torch.cat((feats, nz.to(feats.device)), dim=1)
+    net, opt = stepper.net, getattr(stepper.opt, "opt", stepper.opt)
+    if use_ema:
+        saved = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        net.load_state_dict(opt.ema_state_dict())
+    xr = generate(net, stepper.vq, feats)
+    if use_ema:
+        net.load_state_dict(saved)
+    save_grid(xr, prefix + ".png", nrow=bs)
+    save_grid(xr, f"{prefix}_{step:010d}.png", nrow=bs)
+
+
+def test(model_path, text_or_path, *, nb_repeats=1, out_path="gen.png", images_per_row=None, seed=None,
+         cdt=torch.bfloat16, bpe_path=None):
+    """main.py:977-1061 (without the Net2Net prior): prompts -> PNG grid.  `text_or_path`: "a|b|c", a `.txt` file with
+    one prompt per line, a `.pkl` of token rows / features, or `synthetic:<n>[:seed]` token rows."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    net = load_model(model_path, cdt)
+    config = net.config
+    perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt)
+    vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt)
+    if text_or_path.startswith("synthetic:") or text_or_path.endswith(".pkl"):
+        toks = load_dataset(text_or_path)
+        toks = toks[0] if isinstance(toks, tuple) else toks
+    else:
+        from . import tokenizer
+        texts = [t.strip() for t in open(text_or_path).readlines()] if text_or_path.endswith(".txt") else \
+            text_or_path.split("|")
+        toks = tokenizer.tokenize(texts, truncate=True, bpe_path=bpe_path)
+    H = perceptor.encode_text(toks.cuda()).float() if toks.dtype == torch.long else toks.float().cuda()
+    if config.get("normalize_input", False):
+        H = torch.nn.functional.normalize(H, dim=1)
+    H = H.repeat(nb_repeats, 1)
+    if config.noise_dim:                                                          # main.py:1041-1053
+        bank = getattr(net, "NOISE", None)
+        if bank is not None:
+            bank = bank[:len(H)] if len(bank) > len(H) else bank[torch.randint(0, len(bank), (len(H),))]
+            H = torch.cat((H, bank.to(H.device)), dim=1)
+        else:
+            H = torch.cat((H, torch.randn(len(H), config.noise_dim, device=H.device)), dim=1)
+    xr = generate(net, vq, H)
+    save_grid(xr, out_path, nrow=images_per_row if images_per_row else nb_repeats)
+    return xr
 
 
 def _cli(argv):
     if len(argv) >= 2 and argv[0] == "train":
         return train(argv[1])
-    print("usage: python -m feed_forward_vqgan_clip_amd.main train <config.yaml>", file=sys.stderr)
+    if len(argv) >= 3 and argv[0] == "test":
+        import argparse
+        ap = argparse.ArgumentParser(prog="main.py test")
+        ap.add_argument("model_path")
+        ap.add_argument("text_or_path")
+        ap.add_argument("--nb-repeats", type=int, default=1)
+        ap.add_argument("--out-path", default="gen.png")
+        ap.add_argument("--images-per-row", type=int, default=None)
+        ap.add_argument("--seed", type=int, default=None)
+        ap.add_argument("--bpe-path", default=None)
+        a = ap.parse_args(argv[1:])
+        test(a.model_path, a.text_or_path, nb_repeats=a.nb_repeats, out_path=a.out_path, images_per_row=a.images_per_row,
+             seed=a.seed, bpe_path=a.bpe_path)
+        return 0
+    print("usage: python -m feed_forward_vqgan_clip_amd.main train <config.yaml> | test <model.th> <prompts> [...]",
+          file=sys.stderr)
     return 2
 
 

@@ -684,6 +684,42 @@ def spherical_loss(embed, feats, coef=1.0):
     return _SphericalLossFn.apply(embed, feats, float(coef))
 
 
+class _MeanSqFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        ctx.save_for_backward(x)
+        return K.mean_sq(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return K.mean_sq_bwd(x, _contig(g).float())
+
+
+def mean_sq(x):
+    """l2 regulariser (main.py:758-762): mean(x^2) of a contiguous fp32 tensor."""
+    return _MeanSqFn.apply(x)
+
+
+class _TVLossFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        ctx.save_for_backward(x)
+        return K.tv_loss_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return K.tv_loss_bwd(x, _contig(g).float())
+
+
+def tv_loss_nhwc(x):
+    """tv_loss (main.py:423-428) of an NHWC fp32 image batch (B, H, W, C)."""
+    return _TVLossFn.apply(x)
+
+
 def default_scale(dh):
     return 1.0 / math.sqrt(dh)
 

@@ -28,6 +28,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._v = torch.zeros_like(a.params)
         self._step = 0
         self.grad_scale = 1.0           # folded into the Adam kernel (1/world_size for summed all-reduce)
+        self.loss_scale = 1.0           # gradients in the bucket are loss_scale x the true ones (f16 backward)
+        self._ema, self._ema_decay, self._ema_updates = None, 0.0, 0
+        self._clip = None               # device [coef, total_norm] of the pending clip_grad_norm_
         for p in a.plist:
             o, n = a.param_range(p)
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[o:o + n].view(p.shape),
@@ -36,16 +39,44 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):   # grads are views of one bucket: a single memset (main.py:825)
         self.arena.zero_grad()
 
+    def _eff_scale(self):
+        return self.grad_scale / self.loss_scale
+
     def clip_grad_norm_(self, max_norm):
-        """Global-norm clipping folded into the update scale (clip_grad_norm_, main.py:833-834).
-        Runs on the gradients as they are at call time (i.e. after the all-reduce in DP runs)."""
+        """Global-norm clipping folded into the update scale (clip_grad_norm_, main.py:833-834), computed entirely on
+        the device: sum of squares of the flat gradient bucket -> coefficient -> read by the Adam kernel.  Runs on the
+        gradients as they are at call time (i.e. after the all-reduce in DP runs).  Returns a device scalar (the total
+        norm) instead of a Python float: no host synchronisation in the step."""
         ops.join_side_stream()
         ss = torch.zeros(1, dtype=torch.float32, device=self.arena.grads.device)
         K.sumsq(self.arena.grads, ss)
-        total = math.sqrt(float(ss.item())) * abs(self.grad_scale)
-        coef = min(1.0, max_norm / (total + 1e-6))
-        self._clip_coef = coef
-        return total
+        self._clip = K.clip_coef(ss, max_norm, self._eff_scale())
+        return self._clip[1]
+
+    # -- EMA of the parameters (torch_ema.ExponentialMovingAverage, main.py:520-525,598-616,843-844) ------------------
+    def enable_ema(self, decay=0.995, state=None):
+        """Keep an exponential moving average of the flat parameter bucket, updated inside the Adam kernel.
+        state: optional {name: tensor} (a `checkpoint_ema.th` state_dict) to resume from."""
+        a = self.arena
+        self._ema = a.params.clone()
+        self._ema_decay, self._ema_updates = float(decay), 0
+        if state is not None:
+            for name, p in a.module.named_parameters():
+                if name in state:
+                    o, n = a.param_range(p)
+                    self._ema[o:o + n].copy_(state[name].reshape(-1))
+
+    def ema_state_dict(self):
+        """state_dict of the mapper with the averaged parameters (what `with ema.average_parameters(): net.state_dict()`
+        yields, main.py:905-910)."""
+        if self._ema is None:
+            raise RuntimeError("EMA is not enabled")
+        a = self.arena
+        sd = {k: v.detach().clone() for k, v in a.module.state_dict().items()}
+        for name, p in a.module.named_parameters():
+            o, n = a.param_range(p)
+            sd[name] = self._ema[o:o + n].view(p.shape).detach().clone()
+        return sd
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -53,10 +84,14 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         ops.join_side_stream()          # weight gradients are produced on the side stream
         self._step += 1
-        scale = self.grad_scale * getattr(self, "_clip_coef", 1.0)
-        self._clip_coef = 1.0
+        clip, self._clip = self._clip, None
+        ema_w = 0.0
+        if self._ema is not None:       # torch_ema: decay = min(decay, (1 + n) / (10 + n)) with n counted from 1
+            self._ema_updates += 1
+            ema_w = 1.0 - min(self._ema_decay, (1 + self._ema_updates) / (10 + self._ema_updates))
         K.adam(a.params, a.grads, self._m, self._v, None if a.cdt == torch.float32 else a.shadow, g["lr"],
-               g["betas"][0], g["betas"][1], g["eps"], self._step, scale)
+               g["betas"][0], g["betas"][1], g["eps"], self._step, self._eff_scale(), ema=self._ema, ema_weight=ema_w,
+               dev_scale=None if clip is None else clip[0:1])
         a.refresh(cast=False)
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
@@ -76,12 +111,16 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 class CosineAnnealingLR:
-    """torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max, eta_min=0) closed form (main.py:705-706)."""
+    """torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max, eta_min=0) closed form (main.py:705-706).
+    base_lrs / last_epoch can be given to resume mid-schedule (the optimizer's lr is then already decayed)."""
 
-    def __init__(self, optimizer, T_max, eta_min=0.0):
+    def __init__(self, optimizer, T_max, eta_min=0.0, base_lrs=None, last_epoch=0):
         self.opt, self.T_max, self.eta_min = optimizer, T_max, eta_min
-        self.base = [g["lr"] for g in optimizer.param_groups]
-        self.last_epoch = 0
+        self.base = list(base_lrs) if base_lrs is not None else [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = int(last_epoch)
+        if self.last_epoch:
+            self.last_epoch -= 1
+            self.step()
 
     def step(self):
         self.last_epoch += 1

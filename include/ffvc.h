@@ -266,8 +266,20 @@ int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, 
                         int B, int D, float coef, void* stream);
 /* torch.optim.Adam defaults (main.py:591) over a flat fp32 bucket, step is 1-based; optionally refreshes the
  * low-precision weight shadow in the same pass; grad_scale folds 1/world_size or clip_grad_norm (main.py:833-834). */
+/* ema (may be NULL): torch_ema's ExponentialMovingAverage.update() folded into the same pass (main.py:520-525,843-844):
+ * ema -= ema_weight * (ema - p_new), ema_weight = 1 - min(decay, (1 + n_updates) / (10 + n_updates)). */
 int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr,
-              float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+              float beta1, float beta2, float eps, int step, float grad_scale, float* ema, float ema_weight,
+              const float* dev_scale, void* stream);   /* dev_scale (may be NULL): grad_scale *= dev_scale[0] */
+/* clip_grad_norm_ (main.py:833-834) without a host round trip: out[0] = min(1, max_norm / (sqrt(sumsq[0])*|grad_scale|
+ * + 1e-6)) (feed it to ffvc_adam's dev_scale), out[1] = the total norm. */
+int ffvc_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* out, void* stream);
+/* Optional regularisers of the step: l2 = mean(z^2) (main.py:758-762) and tv_loss (main.py:423-428,769-773) on the
+ * NHWC fp32 image batch; backward kernels take the upstream scalar gradient from device memory (g[0]). */
+int ffvc_mean_sq(const float* x, float* out, int64_t n, void* stream);
+int ffvc_mean_sq_bwd(const float* x, const float* g, float* dx, int64_t n, void* stream);
+int ffvc_tv_loss_fwd(const float* x, float* out, int B, int H, int W, int C, void* stream);
+int ffvc_tv_loss_bwd(const float* x, const float* g, float* dx, int B, int H, int W, int C, void* stream);
 /* out[r % period] (+)= sum_c x[r, c]: bias gradient of the token-mixing Conv1d (bias indexed by output row) */
 int ffvc_rowsum(const void* x, int dtype, float* out, int64_t rows, int cols, int period, int accumulate, void* stream);
 /* dst[r*dst_stride + c] = src[r*src_stride + c] (fp32; src_stride 0 broadcasts one row): class-token row of the

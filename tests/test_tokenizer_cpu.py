@@ -1,0 +1,65 @@
+"""CLIP BPE tokenizer front-end (tokenizer.py) on a tiny hand-made merges file: merge order, </w> handling, SOT/EOT
+framing, zero padding, truncate=True forcing EOT at the last position, int64 output (main.py:733 dispatches on it)."""
+import gzip
+
+import pytest
+import torch
+
+from feed_forward_vqgan_clip_amd import tokenizer as T
+
+
+@pytest.fixture()
+def tk(tmp_path):
+    p = tmp_path / "bpe.txt.gz"
+    merges = ["#version: test", "c a", "ca t</w>", "d o", "do g</w>", "a t</w>"]
+    with gzip.open(p, "wt", encoding="utf-8") as f:
+        f.write("\n".join(merges) + "\n")
+    return T.SimpleTokenizer(str(p))
+
+
+def test_vocab_layout(tk):
+    # 256 byte symbols, 256 word-final byte symbols, the merges, then SOT / EOT
+    assert len(tk.encoder) == 512 + 5 + 2
+    assert tk.sot == 517 and tk.eot == 518
+    assert tk.encoder["cat</w>"] == 513 and tk.encoder["dog</w>"] == 515
+
+
+def test_bpe_merges_by_rank(tk):
+    assert tk.bpe("cat") == "cat</w>"
+    assert tk.bpe("dog") == "dog</w>"
+    assert tk.bpe("at") == "at</w>"
+    assert tk.bpe("bat") == "b at</w>"              # 'a t</w>' applies, nothing merges 'b'
+    assert tk.bpe("cab") == "ca b</w>"
+
+
+def test_encode_decode_roundtrip(tk):
+    ids = tk.encode("  A  Cat &amp; a DOG's  ")
+    assert tk.decode(ids).strip() == "a cat & a dog 's"
+    assert tk.encoder["cat</w>"] in ids and tk.encoder["dog</w>"] in ids
+
+
+def test_tokenize_framing_padding_truncation(tk):
+    out = T.tokenize(["cat", "dog cat dog cat dog"], context_length=6, truncate=True, tokenizer=tk)
+    assert out.dtype == torch.long and tuple(out.shape) == (2, 6)
+    assert out[0].tolist() == [tk.sot, 513, tk.eot, 0, 0, 0]
+    assert out[1, 0] == tk.sot and out[1, -1] == tk.eot and (out[1] != 0).all()
+    with pytest.raises(RuntimeError):
+        T.tokenize(["dog cat dog cat dog"], context_length=6, truncate=False, tokenizer=tk)
+
+
+def test_missing_vocabulary_is_loud(monkeypatch):
+    monkeypatch.delenv("FFVC_BPE_VOCAB", raising=False)
+    with pytest.raises(FileNotFoundError):
+        T.tokenize(["a cat"])
+
+
+def test_load_dataset_tokenises_text_files(tk, tmp_path, monkeypatch):
+    from feed_forward_vqgan_clip_amd import main as fmain
+    p = tmp_path / "prompts.txt"
+    p.write_text("cat\ndog\n")
+    vocab = tmp_path / "bpe.txt.gz"
+    toks = fmain.load_dataset(str(p), bpe_path=str(vocab))
+    assert tuple(toks.shape) == (2, 77) and toks.dtype == torch.long and toks[1, 1] == 515
+    out = tmp_path / "tok.pkl"
+    fmain.tokenize(str(p), out=str(out), bpe_path=str(vocab))
+    assert torch.equal(fmain.load_dataset(str(out)), toks)
