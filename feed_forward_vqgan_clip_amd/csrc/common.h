@@ -50,9 +50,35 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return (uint16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
-// Storage-type traits: T = uint16_t (bf16 bits) or float.
+// ---- f16 storage (FFVC_F16): IEEE half, 11 significant bits (8x finer than bf16), same MFMA rate -------------------
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  const f32pair_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));   // v_cvt_pk_f16_f32 (round-to-nearest-even)
+}
+__device__ __forceinline__ f32pair_t unpack_f16x2(uint32_t u) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2_t, u), f32pair_t);
+}
+
+// Storage-type traits: T = uint16_t (bf16 bits), f16_t (IEEE half) or float.
 template <typename T>
 struct ElemTraits;
+template <>
+struct ElemTraits<f16_t> {
+  static constexpr int kDtype = FFVC_F16;
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float load(const f16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void store(f16_t* p, float v) { *p = (f16_t)v; }
+};
+// 16-bit formats by tag, for kernels that move raw 16-bit words (GEMM fragments, attention panels):
+//   lo_pack2<T>(a, b) -> two values rounded to T in one dword;  lo_round<T>(v) -> v rounded to T, as float
+template <typename T>
+__device__ __forceinline__ uint32_t lo_pack2(float a, float b);
+template <typename T>
+__device__ __forceinline__ float lo_unpack(uint16_t bits);
 template <>
 struct ElemTraits<uint16_t> {
   static constexpr int kDtype = FFVC_BF16;
@@ -68,7 +94,30 @@ struct ElemTraits<float> {
   __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
 };
 
-// Load / store 4 consecutive elements as floats (8 B for bf16, 16 B for f32).
+template <>
+__device__ __forceinline__ uint32_t lo_pack2<uint16_t>(float a, float b) { return pack_bf16x2(a, b); }
+template <>
+__device__ __forceinline__ uint32_t lo_pack2<f16_t>(float a, float b) { return pack_f16x2(a, b); }
+template <>
+__device__ __forceinline__ float lo_unpack<uint16_t>(uint16_t bits) { return bf16_bits_to_f32(bits); }
+template <>
+__device__ __forceinline__ float lo_unpack<f16_t>(uint16_t bits) { return (float)__builtin_bit_cast(f16_t, bits); }
+template <typename T>
+__device__ __forceinline__ float lo_round(float v) { return lo_unpack<T>((uint16_t)(lo_pack2<T>(v, 0.0f) & 0xffffu)); }
+
+// Load / store 4 consecutive elements as floats (8 B for bf16 / f16, 16 B for f32).
+__device__ __forceinline__ f32x4_t load4(const f16_t* p) {
+  const u32x2_t v = *(const u32x2_t*)p;
+  const f32pair_t a = unpack_f16x2(v[0]), b = unpack_f16x2(v[1]);
+  f32x4_t r = {a[0], a[1], b[0], b[1]};
+  return r;
+}
+__device__ __forceinline__ void store4(f16_t* p, f32x4_t v) {
+  u32x2_t o;
+  o[0] = pack_f16x2(v[0], v[1]);
+  o[1] = pack_f16x2(v[2], v[3]);
+  *(u32x2_t*)p = o;
+}
 __device__ __forceinline__ f32x4_t load4(const uint16_t* p) {
   u32x2_t v = *(const u32x2_t*)p;
   f32x4_t r;
@@ -100,6 +149,23 @@ __device__ __forceinline__ f32x8 load8(const uint16_t* p) {
     r.v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
   }
   return r;
+}
+__device__ __forceinline__ f32x8 load8(const f16_t* p) {
+  const u32x4_t u = *(const u32x4_t*)p;
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32pair_t a = unpack_f16x2(u[i]);
+    r.v[2 * i] = a[0];
+    r.v[2 * i + 1] = a[1];
+  }
+  return r;
+}
+__device__ __forceinline__ void store8(f16_t* p, const f32x8& r) {
+  u32x4_t u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = pack_f16x2(r.v[2 * i], r.v[2 * i + 1]);
+  *(u32x4_t*)p = u;
 }
 __device__ __forceinline__ f32x8 load8(const float* p) {
   f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 4);
@@ -139,6 +205,35 @@ __device__ __forceinline__ f32x4_t load4s(const uint16_t* p) {
   r[2] = __uint_as_float(v[1] << 16);
   r[3] = __uint_as_float(v[1] & 0xffff0000u);
   return r;
+}
+__device__ __forceinline__ f32x4_t load4s(const f16_t* p) {
+  const u32x2_t v = __builtin_nontemporal_load((const u32x2_t*)p);
+  const f32pair_t a = unpack_f16x2(v[0]), b = unpack_f16x2(v[1]);
+  f32x4_t r = {a[0], a[1], b[0], b[1]};
+  return r;
+}
+__device__ __forceinline__ void store4s(f16_t* p, f32x4_t v) {
+  u32x2_t o;
+  o[0] = pack_f16x2(v[0], v[1]);
+  o[1] = pack_f16x2(v[2], v[3]);
+  __builtin_nontemporal_store(o, (u32x2_t*)p);
+}
+__device__ __forceinline__ f32x8 load8s(const f16_t* p) {
+  const u32x4_t u = __builtin_nontemporal_load((const u32x4_t*)p);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32pair_t a = unpack_f16x2(u[i]);
+    r.v[2 * i] = a[0];
+    r.v[2 * i + 1] = a[1];
+  }
+  return r;
+}
+__device__ __forceinline__ void store8s(f16_t* p, const f32x8& r) {
+  u32x4_t u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = pack_f16x2(r.v[2 * i], r.v[2 * i + 1]);
+  __builtin_nontemporal_store(u, (u32x4_t*)p);
 }
 __device__ __forceinline__ f32x4_t load4s(const float* p) { return __builtin_nontemporal_load((const f32x4_t*)p); }
 __device__ __forceinline__ void store4s(uint16_t* p, f32x4_t v) {
@@ -296,5 +391,36 @@ __device__ __forceinline__ float act_swish_grad(float x) {
   const float s = sigmoidf_(x);
   return s * (1.0f + x * (1.0f - s));
 }
+
+// One 32x32x16 MFMA on two 16-byte fragments of 16-bit operands (bf16 or f16: same rate, fp32 accumulate).
+template <typename T>
+__device__ __forceinline__ void mma_lo(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b);
+template <>
+__device__ __forceinline__ void mma_lo<uint16_t>(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_lo<f16_t>(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+
+// Run a statement with `T` bound to the storage type of a dtype code.
+#define DISPATCH_DT(code, T, ...)          \
+  do {                                     \
+    if ((code) == FFVC_BF16) {             \
+      using T = uint16_t;                  \
+      __VA_ARGS__;                         \
+    } else if ((code) == FFVC_F16) {       \
+      using T = f16_t;                     \
+      __VA_ARGS__;                         \
+    } else {                               \
+      using T = float;                     \
+      __VA_ARGS__;                         \
+    }                                      \
+  } while (0)
+
+// dtype code -> element size
+static inline int ffvc_dtype_size(int code) { return code == FFVC_F32 ? 4 : 2; }
+static inline bool ffvc_dtype_ok(int code) { return code == FFVC_BF16 || code == FFVC_F32 || code == FFVC_F16; }
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

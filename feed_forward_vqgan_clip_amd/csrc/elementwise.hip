@@ -5,17 +5,6 @@
 // ~8 workgroups per CU.
 #include "common.h"
 
-#define DISPATCH_DT(code, T, ...)   \
-  do {                              \
-    if ((code) == FFVC_BF16) {      \
-      using T = uint16_t;           \
-      __VA_ARGS__;                  \
-    } else {                        \
-      using T = float;              \
-      __VA_ARGS__;                  \
-    }                               \
-  } while (0)
-
 namespace {
 
 inline int ew_grid(int64_t n, int per_block) {
@@ -750,7 +739,7 @@ extern "C" int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst
   if (batch > 65535) {   // split huge batches (gridDim.z limit)
     for (int b0 = 0; b0 < batch; b0 += 65535) {
       const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-      const size_t ss = src_dtype == FFVC_BF16 ? 2 : 4, ds = dst_dtype == FFVC_BF16 ? 2 : 4;
+      const size_t ss = ffvc_dtype_size(src_dtype), ds = ffvc_dtype_size(dst_dtype);
       int e = ffvc_transpose((const char*)src + (size_t)b0 * src_batch_stride * ss, src_dtype,
                              (char*)dst + (size_t)b0 * dst_batch_stride * ds, dst_dtype, nb, rows, cols, src_batch_stride,
                              dst_batch_stride, dst_ld, stream);
@@ -771,7 +760,7 @@ extern "C" int ffvc_transpose_multi(const ffvc_tr_item* items, const int* tile_p
                                     int dtype, void* stream) {
   FFVC_CHECK_ARG(items && tile_prefix && n_items > 0 && total_tiles > 0, "ffvc_transpose_multi: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FFVC_BF16)
+  if (dtype != FFVC_F32)     // a transpose only moves bits: both 16-bit formats share the instantiation
     hipLaunchKernelGGL((transpose_multi_kernel<uint16_t>), dim3(total_tiles), dim3(256), 0, st, items, tile_prefix, n_items);
   else
     hipLaunchKernelGGL((transpose_multi_kernel<float>), dim3(total_tiles), dim3(256), 0, st, items, tile_prefix, n_items);
@@ -790,7 +779,7 @@ extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, i
       return (int)e;
     }
   }
-  const int es = dtype == FFVC_BF16 ? 2 : 4;
+  const int es = ffvc_dtype_size(dtype);
   const int vec = (cols % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0);
   // enough row strips that column-blocks x strips fills the chip (>= ~1024 workgroups), >= 8 rows per strip
   const int colblocks = ceil_div(cols, vec ? 256 : 64);
@@ -928,6 +917,9 @@ extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* sha
   const int grid = ew_grid(n / 4 + 1, 256);
   if (shadow && shadow_dtype == FFVC_BF16)
     hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (uint16_t*)shadow, n, lr, beta1,
+                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
+  else if (shadow && shadow_dtype == FFVC_F16)
+    hipLaunchKernelGGL((adam_kernel<f16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (f16_t*)shadow, n, lr, beta1,
                        beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
   else
     hipLaunchKernelGGL((adam_kernel<float>), dim3(grid), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2,

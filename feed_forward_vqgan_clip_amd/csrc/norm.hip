@@ -11,17 +11,6 @@
 #endif
 #include "common.h"
 
-#define DISPATCH_DT(code, T, ...)   \
-  do {                              \
-    if ((code) == FFVC_BF16) {      \
-      using T = uint16_t;           \
-      __VA_ARGS__;                  \
-    } else {                        \
-      using T = float;              \
-      __VA_ARGS__;                  \
-    }                               \
-  } while (0)
-
 namespace {
 
 constexpr int LN_MAXE = 32;  // elements cached per lane -> dim <= 2048
@@ -113,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
                                                      const float* __restrict__ rstd, const XT* __restrict__ dres,
                                                      XT* __restrict__ dx, float* __restrict__ part_g,
                                                      float* __restrict__ part_b, int64_t rows, int dim,
-                                                     int rows_per_block, int acc_mode, uint16_t* __restrict__ dx_lo) {
+                                                     int rows_per_block, int acc_mode, DYT* __restrict__ dx_lo) {
   constexpr int NIT = LN_MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -785,7 +774,8 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
                          const float* rstd, const void* dres, void* dx, float* part_g, float* part_b, int64_t rows,
                          int dim, void* stream, int acc_mode, void* dx_lo) {
   FFVC_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ffvc_layernorm_bwd: null pointer");
-  FFVC_CHECK_ARG(!dx_lo || x_dtype == FFVC_F32, "ffvc_layernorm_bwd: dx_lo (bf16 copy) only next to an fp32 dx");
+  FFVC_CHECK_ARG(!dx_lo || (x_dtype == FFVC_F32 && dy_dtype != FFVC_F32),
+                 "ffvc_layernorm_bwd: dx_lo (copy in dy's 16-bit dtype) only next to an fp32 dx");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
   FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
   hipStream_t st = (hipStream_t)stream;
@@ -797,11 +787,11 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
                 if (v4)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (uint16_t*)dx_lo);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo);
                 else
                   hipLaunchKernelGGL((ln_bwd_kernel<1, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (uint16_t*)dx_lo);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo);
               }));
   FFVC_LAUNCH_CHECK();
   return 0;
@@ -826,7 +816,7 @@ extern "C" int64_t ffvc_groupnorm_ws_bytes(int B, int HW, int G) {
 }
 
 static int gn_check(int B, int HW, int C, int G, int dtype, const char* who) {
-  const int epc = dtype == FFVC_BF16 ? 8 : 4;
+  const int epc = dtype == FFVC_F32 ? 4 : 8;
   FFVC_CHECK_ARG(B > 0 && B <= 65535 && HW > 0 && C > 0 && G > 0 && G <= 64, "%s: bad dims B=%d HW=%d C=%d G=%d", who,
                  B, HW, C, G);
   FFVC_CHECK_ARG(C % G == 0 && C % epc == 0 && C <= 1024 && (C / epc) <= 256, "%s: C=%d unsupported (G=%d)", who, C, G);

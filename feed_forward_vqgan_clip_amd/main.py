@@ -489,7 +489,7 @@ def train(config_file):
                         rec = {"step": step, "loss": lv, "dists": dv, "diversity": 0.0, "l2": l2v, "tv": tvv, "avg_loss": avg,
                                "lr": opt.param_groups[0]["lr"]}
                         if eval_data is not None:
-                            rec.update(_fast_eval(net, vq, eval_perceptor, eval_data, bs, stepper.clip_size))
+                            rec.update(_fast_eval(net, vq, eval_perceptor, eval_data, bs, stepper.clip_size, stepper.noise_dim))
                             print(f"Eval dists: {rec['eval_dists']:.3f}\nEval clip score: {rec['eval_clip_score']:.3f}")
                         log_f.write(json.dumps(rec) + "\n")
                         log_f.flush()
@@ -514,8 +514,10 @@ def train(config_file):
 
 
 @torch.no_grad()
-def _fast_eval(net, vq, perceptor, eval_data, bs, clip_size):
-    """main.py:868-897: CLIP distance / score of images generated for held-out prompts (bilinear resize to clip_size)."""
+def _fast_eval(net, vq, perceptor, eval_data, bs, clip_size, noise_dim=0):
+    """main.py:868-897: CLIP distance / score of images generated for held-out prompts (bilinear resize to clip_size).
+    (With noise_dim > 0 the reference feeds the bare text features to the mapper and fails on the input width; here a
+    fresh noise vector is appended, as `test` does, main.py:1041-1053.)"""
     ds, cs = [], []
     scale = perceptor.logit_scale.exp().float().cpu()
     mean = torch.tensor(CLIP_MEAN, device="cuda").view(1, -1, 1, 1)
@@ -523,7 +525,7 @@ def _fast_eval(net, vq, perceptor, eval_data, bs, clip_size):
     for i in range(0, len(eval_data), bs):
         chunk = eval_data[i:i + bs].cuda()
         emb = perceptor.encode_text(chunk).float() if chunk.dtype == torch.long else chunk.float()
-        xr = generate(net, vq, emb)
+        xr = generate(net, vq, emb if not noise_dim else torch.cat((emb, torch.randn(len(emb), noise_dim, device=emb.device)), 1))
         xr = torch.nn.functional.interpolate(xr, size=(clip_size, clip_size), mode="bilinear")
         embed = torch.nn.functional.normalize(perceptor.encode_image((xr - mean) / std).float(), dim=1)
         H = torch.nn.functional.normalize(emb, dim=-1)

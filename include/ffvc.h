@@ -16,7 +16,9 @@
  *   - return value: 0 = ok, otherwise a hipError_t (>0) or FFVC_E_* (<0);
  *     ffvc_last_error() returns a human readable message for the calling thread.
  *   - dtype codes: FFVC_BF16 = 0 (bfloat16 storage, fp32 accumulate),
- *                  FFVC_F32  = 1 (exact fp32 "parity mode": fp32-input MFMA).
+ *                  FFVC_F32  = 1 (exact fp32 "parity mode": fp32-input MFMA),
+ *                  FFVC_F16  = 2 (IEEE half storage, fp32 accumulate; what the reference's CLIP runs in on CUDA,
+ *                                 clip.load -> fp16 weights).
  */
 #ifndef FFVC_H
 #define FFVC_H
@@ -29,6 +31,7 @@ extern "C" {
 
 #define FFVC_BF16 0
 #define FFVC_F32 1
+#define FFVC_F16 2 /* IEEE half storage, fp32 accumulate: 8x finer than bf16 at the same MFMA rate (loss-scaled backward) */
 
 #define FFVC_E_BADARG (-1)
 #define FFVC_E_UNSUPPORTED (-2)

@@ -85,3 +85,93 @@ def test_batch_rows_are_independent(full):
     assert (a["z"][:4] - b["z"]).abs().max().item() < 1e-5 * a["z"].abs().max().item() + 1e-6
     d = (a["xr"][:4] - b["xr"]).abs()                      # GroupNorm statistics are per image: only bf16 tile-order
     assert d.mean().item() < 5e-3 and d.max().item() < 0.1, (d.mean().item(), d.max().item())   # round-off (and a flipped code) remain
+
+
+# ----------------------------------------------------------------------------- cfg3 / cfg4 at full model sizes
+# BASELINE.json configs[2] (VitGAN 32x1024 + ViT-B/32, 256x256) and configs[3] (x-transformer 256x16, vq_image_size 32
+# -> 512x512 decode, 1024-token attention in the mapper and in the decoder's 4 attention blocks).  fp32 mode: the CPU
+# oracle is the checker on the mapper (z) and on the full loss at batch 2; throughput mode: properties + descent.
+def _other_cfg(kind):
+    if kind == "cfg3":
+        return dict(model_type="vitgan", dim=1024, depth=32, vq_image_size=16, num_heads=6)
+    return dict(model_type="xtransformer", dim=256, depth=16, vq_image_size=32, num_heads=6)
+
+
+def _oracle_mapper(kind, sd, x):
+    from oracle import mappers as omap
+    if kind == "cfg3":
+        return omap.vitgan_forward(sd, x, initialize_size=2, dim=1024, blocks=32, num_heads=6, out_channels=256)
+    return omap.xtransformer_forward(sd, x, image_size=32, channels=256, dim=256, depth=16, heads=6)
+
+
+@pytest.mark.parametrize("kind", ["cfg3", "cfg4"])
+def test_cfg3_cfg4_fp32_step_matches_oracle(cuda, kind):
+    from oracle import step as ostep
+    Bn, cutn = 2, 2
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dropout=0, cutn=cutn, batch_size=Bn, repeat=1, nb_noise=None,
+                       diversity_coef=0, clip_model="ViT-B/32", augs=["R"], **_other_cfg(kind))
+    torch.manual_seed(3)
+    net = fmain.build_model(cfg, 256)
+    msd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().prepare(torch.float32)
+    vq_sd, clip_sd = fvq.random_state_dict(fvq.F16_16384, seed=3), fclip.random_state_dict(fclip.VIT_B32, seed=3)
+    vq, perceptor = fvq.VQGAN(vq_sd, fvq.F16_16384, torch.float32), fclip.CLIP(clip_sd, torch.float32)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, FusedAdam(net.parameters(), lr=cfg.lr))
+    tok = fmain.synthetic_tokens(Bn, seed=5)
+    g = torch.Generator().manual_seed(9)
+    facs, noise = torch.rand(cutn * Bn, generator=g) * 0.1, torch.randn(cutn * Bn, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+        oloss, omid = ostep.train_step_loss(lambda sd, f: _oracle_mapper(kind, sd, f), msd, vq_sd, clip_sd, tok, cutn=cutn,
+                                            cut_size=224, z_min=vq.z_min, z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise)
+    S = cfg.vq_image_size
+    assert tuple(mid["z"].shape) == (Bn, 256, S, S) and tuple(mid["xr"].shape) == (Bn, 16 * S, 16 * S, 3)
+    zo = omid["z"]                                                        # oracle z is post-clamp; clamp ours the same way
+    zh = mid["z"].cpu().clamp(vq.z_min, vq.z_max)
+    zerr = ((zh - zo).pow(2).mean().sqrt() / zo.pow(2).mean().sqrt()).item()
+    agree = (mid["indices"].cpu().view(-1) == ostep.vq_indices(zo.movedim(1, 3), vq_sd["quantize.embedding.weight"]).view(-1)).float().mean().item()
+    rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    print(f"[{kind}] z rel-rms {zerr:.2e}, VQ agreement {agree:.5f}, loss hip {loss.item():.7f} oracle {oloss.item():.7f} rel {rel:.2e}")
+    assert zerr < 2e-4
+    assert agree > 0.999                                                  # fp32 accumulation-order ties only
+    xo = omid["xr"]
+    xerr = ((mid["xr"].permute(0, 3, 1, 2).cpu() - xo).pow(2).mean().sqrt() / xo.pow(2).mean().sqrt()).item()
+    if agree == 1.0:
+        assert xerr < 2e-4 and rel < 1e-4                                  # north_star tolerance
+    else:
+        assert rel < 2e-3
+
+
+@pytest.mark.parametrize("kind", ["cfg3", "cfg4"])
+def test_cfg3_cfg4_throughput_mode_properties(cuda, kind):
+    Bn, cutn = 2, 4
+    cfg = fmain.Config(lr=1e-4, epochs=1, noise_dim=0, dropout=0, cutn=cutn, batch_size=Bn, repeat=1, nb_noise=None,
+                       diversity_coef=0, clip_model="ViT-B/32", **_other_cfg(kind))
+    torch.manual_seed(3)
+    net = fmain.build_model(cfg, 256).cuda().prepare(torch.bfloat16)
+    vq = fvq.VQGAN(fvq.random_state_dict(fvq.F16_16384, seed=3), fvq.F16_16384, torch.bfloat16)
+    perceptor = fclip.CLIP(fclip.random_state_dict(fclip.VIT_B32, seed=3), torch.bfloat16)
+    opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    tok = fmain.synthetic_tokens(Bn, seed=5).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    kw = dict(facs=torch.rand(cutn * Bn, device="cuda", generator=g) * 0.1,
+              noise=torch.randn(cutn * Bn, 3, 224, 224, device="cuda", generator=g),
+              aug_params=stepper.make_cutouts.draw_aug_params(cutn * Bn, "cuda"))
+    l0, mid = stepper.forward_loss(tok, **kw)
+    S = cfg.vq_image_size
+    assert 0.0 <= l0.item() <= math.pi ** 2 / 2
+    assert tuple(mid["xr"].shape) == (Bn, 16 * S, 16 * S, 3) and mid["xr"].min().item() >= 0 and mid["xr"].max().item() <= 1
+    assert torch.isfinite(mid["embed"]).all()
+    opt.zero_grad()
+    l0.backward()
+    gr = net._ffvc_arena.grads
+    assert torch.isfinite(gr).all() and gr.abs().max().item() > 0
+    dead = [k for k, p in net.named_parameters() if p.grad.abs().max().item() == 0]
+    assert len(dead) == 0, dead[:5]
+    losses = [l0.item()]
+    for _ in range(4):
+        loss, _ = stepper(tok, **kw)
+        losses.append(loss.item())
+    final, _ = stepper.forward_loss(tok, **kw)
+    assert final.item() < losses[0], losses

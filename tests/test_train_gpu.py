@@ -1,0 +1,295 @@
+"""GPU tests of the train-step branches and host surface that round 1 left unexercised:
+l2 / tv regularisers (a13), noise conditioning with / without a bank and repeat > 1 (a17), input_loss, normalize_input,
+clip_grad_norm, cosine schedule (a14), EMA (n2), `train()` -> checkpoint -> resume -> `load_model` -> `test()` (a16, n3).
+The oracle (CPU fp32 restatement) is the checker; tolerances are the fp32-mode ones (1e-4 rel on the loss)."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from feed_forward_vqgan_clip_amd import clip as fclip  # noqa: E402
+from feed_forward_vqgan_clip_amd import kernels as K  # noqa: E402
+from feed_forward_vqgan_clip_amd import main as fmain  # noqa: E402
+from feed_forward_vqgan_clip_amd import ops  # noqa: E402
+from feed_forward_vqgan_clip_amd import vqgan as fvq  # noqa: E402
+from feed_forward_vqgan_clip_amd.optim import CosineAnnealingLR, FusedAdam  # noqa: E402
+
+F32 = torch.float32
+TINY_VQ = dict(ch=64, ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64, out_ch=3,
+               embed_dim=64, n_embed=128)
+TINY_CLIP = dict(embed_dim=32, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8,
+                 context_length=16, vocab_size=96, transformer_width=64, transformer_heads=1, transformer_layers=2)
+
+
+def _relrms(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
+def _setup(seed=11, cdt=F32, **over):
+    kw = dict(lr=1e-3, epochs=1, noise_dim=0, dim=64, depth=2, dropout=0, cutn=4, batch_size=4, repeat=1, nb_noise=None,
+              diversity_coef=0, clip_model="ViT-B/32", clip_dim=32, clip_size=32, model_type="mlp_mixer", vq_image_size=12,
+              augs=["R"])
+    kw.update(over)
+    cfg = fmain.Config(**kw)
+    clip_sd, vq_sd = fclip.random_state_dict(TINY_CLIP, seed), fvq.random_state_dict(TINY_VQ, seed + 1)
+    torch.manual_seed(seed)
+    net = fmain.build_model(cfg, 64).cuda().prepare(cdt)
+    vq, perceptor = fvq.VQGAN(vq_sd, TINY_VQ, cdt), fclip.CLIP(clip_sd, cdt)
+    opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    tok = torch.zeros(4, 16, dtype=torch.long)
+    g = torch.Generator().manual_seed(seed)
+    for i, L in enumerate([3, 6, 9, 12]):
+        tok[i, 0] = 94
+        tok[i, 1:L] = torch.randint(1, 94, (L - 1,), generator=g)
+        tok[i, L] = 95
+    n = cfg.cutn * cfg.repeat * 4
+    facs = torch.rand(n, generator=g) * 0.1
+    noise = torch.randn(n, 3, 32, 32, generator=g)
+    return cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise
+
+
+def _oracle(net_sd, vq, vq_sd, clip_sd, tok, facs, noise, cfg, noise_vec=None, text_feats=None):
+    from oracle import clip as oclip
+    from oracle import mappers as omap
+    from oracle import step as ostep
+    osd = {k: v.clone().requires_grad_(True) for k, v in net_sd.items()}
+    if text_feats is None:
+        with torch.no_grad():
+            text_feats = oclip.encode_text(clip_sd, tok, None).float()
+    feats = text_feats.repeat(cfg.repeat, 1)
+
+    def mapper(sd, f):
+        x = f if noise_vec is None else torch.cat((f, noise_vec), dim=1)
+        return omap.mixer_forward(sd, x, image_size=12, channels=64, depth=2)
+    oloss, omid = ostep.train_step_loss(mapper, osd, vq_sd, clip_sd, tok, cutn=cfg.cutn, cut_size=32, z_min=vq.z_min,
+                                        z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise, vq_cfg=TINY_VQ,
+                                        text_feats=feats)
+    return oloss, omid, osd, mapper, feats
+
+
+def _check_grads(net, osd, tol=3e-3):
+    params = dict(net.named_parameters())
+    gmax = max(v.grad.abs().max().item() for v in osd.values() if v.grad is not None)
+    for k, v in osd.items():
+        if v.grad is None:
+            continue
+        tiny = (params[k].grad.cpu() - v.grad).abs().max().item() < 1e-6 * gmax
+        assert tiny or _relrms(params[k].grad, v.grad) < tol, k
+
+
+# ----------------------------------------------------------------------------- kernels
+def test_mean_sq_and_tv_kernels(cuda):
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(3, 5, 7, 6, generator=g).cuda().requires_grad_(True)
+    zr = z.detach().double().cpu().requires_grad_(True)
+    (ops.mean_sq(z) * 1.7).backward()
+    ((zr ** 2).mean() * 1.7).backward()
+    assert abs(ops.mean_sq(z).item() - (zr ** 2).mean().item()) < 1e-6
+    assert _relrms(z.grad, zr.grad) < 1e-6
+    x = torch.rand(2, 9, 11, 3, generator=g).cuda().requires_grad_(True)           # NHWC
+    xr = x.detach().double().cpu().permute(0, 3, 1, 2).requires_grad_(True)         # NCHW reference (main.py:423-428)
+    ref = 0.5 * ((xr[:, :, 1:, :] - xr[:, :, :-1, :]).abs().mean() + (xr[:, :, :, 1:] - xr[:, :, :, :-1]).abs().mean())
+    tv = ops.tv_loss_nhwc(x)
+    assert abs(tv.item() - ref.item()) < 1e-6
+    (tv * 0.3).backward()
+    (ref * 0.3).backward()
+    assert _relrms(x.grad, xr.grad.permute(0, 2, 3, 1)) < 1e-5
+    assert abs(fmain.tv_loss(x.detach().permute(0, 3, 1, 2)).item() - ref.item()) < 1e-6     # the reference-shaped entry point
+
+
+# ----------------------------------------------------------------------------- regularisers in the step
+def test_step_with_l2_and_tv_matches_oracle(cuda):
+    from oracle import step as ostep
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _setup(l2_coef=0.05, tv_coef=0.5)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+    opt.zero_grad()
+    loss.backward()
+    oloss, omid, osd, mapper, feats = _oracle(msd, vq, vq_sd, clip_sd, tok, facs, noise, cfg)
+    z_pre = mapper(osd, feats)                                          # l2 is taken BEFORE the clamp (main.py:758-763)
+    ol2, otv = (z_pre ** 2).mean(), ostep.tv_loss(omid["xr"])
+    total = oloss + 0.05 * ol2 + 0.5 * otv                              # main.py:831
+    total.backward()
+    assert abs(mid["l2"].item() - ol2.item()) / ol2.item() < 1e-4
+    assert abs(mid["tv"].item() - otv.item()) / otv.item() < 1e-4
+    assert abs(mid["dists"].item() - oloss.item()) / oloss.item() < 1e-4
+    assert abs(loss.item() - total.item()) / total.item() < 1e-4
+    _check_grads(net, osd)
+
+
+# ----------------------------------------------------------------------------- noise conditioning / repeat
+@pytest.mark.parametrize("nb_noise,repeat", [(None, 1), (None, 2), (6, 2), (6, 1)])
+def test_noise_conditioning_and_repeat_match_oracle(cuda, nb_noise, repeat):
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _setup(noise_dim=8, nb_noise=nb_noise, repeat=repeat)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    assert net.input_dim == 32 + 8
+    msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+    opt.zero_grad()
+    loss.backward()
+    nv = mid["noise_vec"].detach().cpu()
+    assert tuple(nv.shape) == (4 * repeat, 8)
+    assert tuple(mid["z"].shape) == (4 * repeat, 64, 12, 12) and tuple(mid["embed"].shape) == (cfg.cutn * repeat * 4, 32)
+    if nb_noise:
+        bank = stepper.NOISE.cpu()
+        assert net.NOISE is stepper.NOISE and tuple(bank.shape) == (nb_noise, 8)
+        for r in range(repeat):                                          # repeat-major: rows r*bs .. r*bs+bs-1 share bank row
+            rows = nv[r * 4:(r + 1) * 4]
+            assert (rows == rows[0]).all() and any(torch.equal(rows[0], b) for b in bank)
+        if repeat == 2:
+            assert not torch.equal(nv[0], nv[4])                          # distinct bank rows per repeat (shuffle without replacement)
+    oloss, omid, osd, _, _ = _oracle(msd, vq, vq_sd, clip_sd, tok, facs, noise, cfg, noise_vec=nv)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) / oloss.item() < 1e-4
+    _check_grads(net, osd)
+    # pinned conditioning noise reproduces the step exactly
+    loss2, _ = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), noise_vec_in=nv.cuda())
+    assert abs(loss2.item() - loss.item()) < 1e-6
+
+
+# ----------------------------------------------------------------------------- (inp, out) feature pairs
+def test_input_loss_and_normalize_input_match_oracle(cuda):
+    from oracle import step as ostep
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _setup(input_loss=True, input_loss_coef=0.25,
+                                                                            target_loss_coef=0.5, normalize_input=True)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    g = torch.Generator().manual_seed(2)
+    inp, out = torch.randn(4, 32, generator=g), torch.randn(4, 32, generator=g)     # pre-computed features (main.py:733 else-branch)
+    msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss, mid = stepper.forward_loss(inp.cuda(), out.cuda(), facs=facs.cuda(), noise=noise.cuda())
+    opt.zero_grad()
+    loss.backward()
+    inp_n = torch.nn.functional.normalize(inp, dim=1)                               # main.py:734-735 (only inp is normalised)
+    oloss_t, omid, osd, _, _ = _oracle(msd, vq, vq_sd, clip_sd, tok, facs, noise, cfg, text_feats=inp_n)
+    total = 0.5 * ostep.spherical_loss(omid["embed"], out, cfg.cutn) + 0.25 * ostep.spherical_loss(omid["embed"], inp_n, cfg.cutn)
+    total.backward()
+    assert abs(loss.item() - total.item()) / total.item() < 1e-4
+    _check_grads(net, osd)
+
+
+# ----------------------------------------------------------------------------- clip_grad_norm / cosine / EMA
+def test_clip_grad_norm_matches_torch(cuda):
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _setup(clip_grad_norm=0.05)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in net.named_parameters()}
+    ropt = torch.optim.Adam(ref.values(), lr=cfg.lr)
+    for it in range(2):
+        loss, _ = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+        opt.zero_grad()
+        loss.backward()
+        for k, p in net.named_parameters():
+            ref[k].grad = p.grad.detach().clone()
+        total = opt.clip_grad_norm_(cfg.clip_grad_norm)
+        rtotal = torch.nn.utils.clip_grad_norm_(ref.values(), cfg.clip_grad_norm)
+        assert abs(total.item() - rtotal.item()) / rtotal.item() < 1e-5
+        assert rtotal.item() > cfg.clip_grad_norm                       # the clip is active in this test
+        opt.step()
+        ropt.step()
+    for k, p in net.named_parameters():
+        assert (p.detach().cpu() - ref[k].detach().cpu()).abs().max().item() < 2e-6, k
+    # TrainStep wires it in (main.py:833-834): one call with the config key set must not raise and must clip
+    stepper(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+
+
+def test_cosine_schedule_matches_torch_and_resumes(cuda):
+    cfg, net, *_ = _setup()
+    opt = FusedAdam(net.parameters(), lr=0.01)
+    p = torch.nn.Parameter(torch.zeros(1))
+    ropt = torch.optim.Adam([p], lr=0.01)
+    rs = torch.optim.lr_scheduler.CosineAnnealingLR(ropt, T_max=20, eta_min=0)
+    s = CosineAnnealingLR(opt, T_max=20, eta_min=0)
+    lrs = []
+    for _ in range(12):
+        ropt.step()
+        rs.step()
+        s.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        assert abs(opt.param_groups[0]["lr"] - ropt.param_groups[0]["lr"]) < 1e-9
+    # resume at step 7 from an optimizer whose lr is already decayed (opt.th holds it): same continuation
+    opt2 = FusedAdam(net.parameters(), lr=lrs[6])
+    s2 = CosineAnnealingLR(opt2, T_max=20, eta_min=0, base_lrs=[0.01], last_epoch=7)
+    assert abs(opt2.param_groups[0]["lr"] - lrs[6]) < 1e-12
+    for k in range(7, 12):
+        s2.step()
+        assert abs(opt2.param_groups[0]["lr"] - lrs[k]) < 1e-12
+
+
+def test_ema_matches_torch_ema_update_rule(cuda):
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _setup()
+    opt.enable_ema(0.9)
+    shadow = {k: v.detach().clone() for k, v in net.named_parameters()}           # torch_ema: shadow = copy of the params
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    for n in range(1, 4):
+        stepper(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
+        decay = min(0.9, (1 + n) / (10 + n))                                        # ExponentialMovingAverage.update()
+        for k, p in net.named_parameters():
+            shadow[k] -= (1 - decay) * (shadow[k] - p.detach())
+    esd = opt.ema_state_dict()
+    assert set(esd.keys()) == set(net.state_dict().keys())
+    for k in shadow:
+        assert (esd[k] - shadow[k]).abs().max().item() < 1e-6, k
+        assert (esd[k] - dict(net.named_parameters())[k].detach()).abs().max().item() > 0     # it really lags the weights
+
+
+# ----------------------------------------------------------------------------- train() -> resume -> load_model -> test()
+def _write_cfg(folder, **over):
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dict(lr=0.001, epochs=50, noise_dim=4, dim=64, depth=2, dropout=0, cutn=2, batch_size=2, repeat=1, nb_noise=5,
+               diversity_coef=0, vqgan_config=os.path.join(root, "configs", "vqgan_imagenet_f16_16384.yaml"),
+               vqgan_checkpoint="random:1234", clip_model="ViT-B/32", clip_model_path="random:1234", path="synthetic:16",
+               folder=str(folder), log_interval=2, model_type="mlp_mixer", vq_image_size=16, compute_dtype="bf16",
+               max_steps=3, use_ema=True, scheduler="cosine", clip_grad_norm=1.0, l2_coef=0.01, eval_path="synthetic:4:7")
+    cfg.update(over)
+    path = os.path.join(str(folder), "cfg.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return path
+
+
+def test_train_checkpoint_resume_load_model_and_test_cli(cuda, tmp_path):
+    from PIL import Image
+    path = _write_cfg(tmp_path)
+    fmain.train(path)                                                    # steps 0,1,2; logs + checkpoints at 0 and 2
+    for f in ("checkpoint.th", "checkpoint_ema.th", "opt.th", "scalars.jsonl", "progress.png", "fixed_batch_progress.png",
+              "progress_0000000002.png", "fixed_batch_progress_0000000002.png"):
+        assert os.path.exists(tmp_path / f), f
+    recs = [json.loads(ln) for ln in open(tmp_path / "scalars.jsonl")]
+    assert [r["step"] for r in recs] == [0, 2]
+    for r in recs:
+        assert set(r) >= {"loss", "dists", "diversity", "l2", "tv", "avg_loss", "lr", "eval_dists", "eval_clip_score"}
+        assert math.isfinite(r["loss"]) and r["l2"] > 0 and abs(r["loss"] - (r["dists"] + 0.01 * r["l2"])) < 1e-4
+    assert recs[1]["lr"] < recs[0]["lr"]                                  # cosine schedule is live
+    assert abs(recs[0]["avg_loss"] - (0.99 + 0.01 * recs[0]["loss"])) < 1e-5      # EMA from 1.0, every step (main.py:861)
+    ck = torch.load(tmp_path / "checkpoint.th", weights_only=False)
+    assert set(ck) == {"state_dict", "config", "step", "epoch"} and ck["step"] == 2
+    assert Image.open(tmp_path / "progress.png").size == (2 * 258 + 2, 258 + 2)   # make_grid(nrow=bs, padding=2) of 256x256
+    # resume: picks up at the checkpointed step with the optimizer state and runs on to max_steps
+    path2 = _write_cfg(tmp_path, max_steps=6)
+    fmain.train(path2)
+    recs = [json.loads(ln) for ln in open(tmp_path / "scalars.jsonl")]
+    assert [r["step"] for r in recs] == [0, 2, 2, 4]
+    ck2 = torch.load(tmp_path / "checkpoint.th", weights_only=False)
+    assert ck2["step"] == 4
+    opt_sd = torch.load(tmp_path / "opt.th", weights_only=False)
+    assert int(float(opt_sd["state"][0]["step"])) == 3 + 3               # 3 steps of the first run + steps 2,3,4 of the second
+    # cosine resumed mid-schedule (T_max 6, base 1e-3; the record holds the lr AFTER step 4's scheduler.step(), i.e.
+    # schedule position 5) — not a restart from the decayed lr stored in opt.th
+    assert abs(recs[-1]["lr"] - 0.001 * (1 + math.cos(math.pi * 5 / 6)) / 2) < 1e-9
+    # load_model round trip + forward-only generation (main.py:977-1061)
+    net = fmain.load_model(str(tmp_path / "checkpoint.th"))
+    assert net.config.dim == 64
+    for k, v in ck2["state_dict"].items():
+        assert torch.equal(net.state_dict()[k].cpu(), v.cpu()), k
+    out = tmp_path / "gen.png"
+    xr = fmain.test(str(tmp_path / "checkpoint_ema.th"), "synthetic:3:1", nb_repeats=2, out_path=str(out), seed=0)
+    assert tuple(xr.shape) == (6, 3, 256, 256) and float(xr.min()) >= 0 and float(xr.max()) <= 1
+    assert Image.open(out).size == (2 * 258 + 2, 3 * 258 + 2)
+    assert fmain._cli(["test", str(tmp_path / "checkpoint.th"), "synthetic:2", "--out-path", str(tmp_path / "g2.png")]) == 0
+    assert os.path.exists(tmp_path / "g2.png")
