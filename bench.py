@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 # Algorithmic forward GMAC per unit (SURVEY.md §8d / BASELINE.md §2)
 GMAC = dict(mixer=86.07, vq=2.147, dec=126.37, img=4.409, txt=2.980)
-PEAK_BF16_TFLOPS = 2516.6      # 256 CU x 4096 FLOP/clk x 2.4 GHz dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2516.6      # 256 CU x 4096 FLOP/clk x 2.4 GHz dense bf16 / f16 MFMA (MI355X_MICROARCH.md)
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
 
 
 def step_tflop(B, cutn):
@@ -40,7 +41,7 @@ def build(args, device):
     from feed_forward_vqgan_clip_amd import vqgan as fvq
     from feed_forward_vqgan_clip_amd.optim import FusedAdam
 
-    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cdt = DTYPES[args.dtype]
     cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
                        batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
                        model_type=args.model_type, vq_image_size=args.vq_image_size,
@@ -54,6 +55,7 @@ def build(args, device):
     vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
     perceptor = fclip.CLIP(clip_sd, cdt)
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    opt.loss_scale = args.loss_scale if cdt == torch.float16 else 1.0
     if hvd.is_distributed():
         opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
         hvd.broadcast_parameters(net, root_rank=0)
@@ -131,31 +133,105 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     return out, {"loss": loss0, "tok": tok, "facs": facs.view(-1), "noise": noise, "aug_params": prm}
 
 
+def _relrms(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
 def full_size_parity(args, sds, ref):
-    """The oracle's first-step loss (computed by the cpu_baseline leg above) against the HIP path on the SAME full-size
-    weights and inputs, in both compute modes: the north-star parity figure at the benchmark's own model sizes."""
+    """Parity of the timed mode at the benchmark's own model sizes, as a per-stage error budget.
+
+    (1) the oracle (CPU fp32 restatement, pinned to the reference by tests/golden) vs the HIP fp32-MFMA mode at batch
+        `pb` (default 4) -> `rel_fp32`: pins the HIP path's algorithm at full size;
+    (2) the timed 16-bit mode vs that fp32 run, stage by stage at batch `pb`: mapper (z rel-rms, VQ code agreement),
+        decoder (xr with the SAME codes), image tower (embed), loss with the reference's codes handed to the decoder
+        (`rel_same_codes`: the VQ argmin is a discontinuity of the reference itself) and free-running (`rel_free`);
+    (3) free-running at the benchmark's batch (HIP fp32 vs timed mode on the same weights / inputs) -> `rel_free_bench_batch`.
+    """
+    from feed_forward_vqgan_clip_amd import augment as faug
     from feed_forward_vqgan_clip_amd import clip as fclip
     from feed_forward_vqgan_clip_amd import main as fmain
     from feed_forward_vqgan_clip_amd import vqgan as fvq
     from feed_forward_vqgan_clip_amd.optim import FusedAdam
+    from oracle import mappers as omap
+    from oracle import step as ostep
     mixer_sd, vq_sd, clip_sd = sds
-    res = {"loss_oracle_fp32": ref["loss"]}
-    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
-                       batch_size=1, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
-                       model_type="mlp_mixer", vq_image_size=16, augs=None if args.augs == "default" else args.augs.split(","))
-    prm = ref["aug_params"]
-    for name, cdt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+    pb, cutn = args.parity_batch, args.cutn
+    augs = None if args.augs == "default" else args.augs.split(",")
+
+    def inputs(B, seed):
+        g = torch.Generator().manual_seed(seed)
+        tok = fmain.synthetic_tokens(B, seed=seed)
+        facs = torch.rand(cutn * B, generator=g) * 0.1
+        noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
+        names = faug.SUPPORTED if augs is None else tuple(a for a in augs if a != "R")
+        prm = faug.draw_params(cutn * B, 224, names, generator=g) if names else None
+        return tok, facs, noise, prm
+
+    def make(cdt, B):
+        cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=cutn,
+                           batch_size=B, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
+                           model_type="mlp_mixer", vq_image_size=16, augs=augs)
         net = fmain.build_model(cfg, 256)
         net.load_state_dict(mixer_sd)
         net = net.cuda().prepare(cdt)
-        stepper = fmain.TrainStep(cfg, net, fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt),
-                                  FusedAdam(net.parameters(), lr=1e-3))
+        return fmain.TrainStep(cfg, net, fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt),
+                               FusedAdam(net.parameters(), lr=1e-3))
+
+    def run(st, tok, facs, noise, prm, force_idx=None):
         with torch.no_grad():
-            loss, _ = stepper.forward_loss(ref["tok"].cuda(), facs=ref["facs"].cuda(), noise=ref["noise"].cuda(),
-                                           aug_params=None if prm is None else {k: v.cuda() for k, v in prm.items()})
-        res[f"loss_hip_{name}"] = float(loss)
-        res[f"rel_{name}"] = abs(float(loss) - ref["loss"]) / abs(ref["loss"])
-        del stepper, net
+            loss, mid = st.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(),
+                                        aug_params=None if prm is None else {k: v.cuda() for k, v in prm.items()},
+                                        force_idx=force_idx)
+        return float(loss), mid
+
+    res = {"batch": pb, "timed_dtype": args.dtype}
+    tok, facs, noise, prm = inputs(pb, 99)
+    cb = vq_sd["quantize.embedding.weight"]
+    torch.set_num_threads(effective_cores())
+    with torch.no_grad():                       # (1) the oracle, forward only
+        oloss, omid = ostep.train_step_loss(
+            lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=args.depth), mixer_sd, vq_sd, clip_sd,
+            tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(), facs=facs.view(-1, 1, 1, 1),
+            noise=noise, aug_params=prm)
+    res["loss_oracle_fp32"] = float(oloss)
+    st32 = make(torch.float32, pb)
+    l32, m32 = run(st32, tok, facs, noise, prm)
+    res["loss_hip_fp32"] = l32
+    res["rel_fp32"] = abs(l32 - float(oloss)) / abs(float(oloss))
+    oidx = ostep.vq_indices(omid["z"].movedim(1, 3), cb).view(-1)
+    res["vq_agree_fp32"] = float((m32["indices"].cpu().view(-1) == oidx).float().mean())
+    lo = DTYPES[args.dtype]
+    if lo != torch.float32:                     # (2) stage budget of the timed mode against the fp32 run
+        stl = make(lo, pb)
+        ll, ml = run(stl, tok, facs, noise, prm)
+        lsc, msc = run(stl, tok, facs, noise, prm, force_idx=m32["indices"])
+        res.update({
+            "loss_hip_" + args.dtype: ll,
+            "z_relrms": _relrms(ml["z"], m32["z"]),
+            "vq_agree": float((ml["indices"] == m32["indices"]).float().mean()),
+            "vq_flips": int((ml["indices"] != m32["indices"]).sum()), "vq_positions": int(m32["indices"].numel()),
+            "xr_relrms_same_codes": _relrms(msc["xr"], m32["xr"]),
+            "embed_relrms_same_codes": _relrms(msc["embed"], m32["embed"]),
+            "rel_same_codes": abs(lsc - l32) / abs(l32),
+            "rel_free": abs(ll - l32) / abs(l32),
+            "rel_" + args.dtype: abs(ll - float(oloss)) / abs(float(oloss)),
+        })
+        del stl
+    del st32
+    torch.cuda.empty_cache()
+    if lo != torch.float32 and args.batch > pb:  # (3) the benchmark's own batch, free-running
+        tok, facs, noise, prm = inputs(args.batch, 123)
+        st32 = make(torch.float32, args.batch)
+        l32, m32 = run(st32, tok, facs, noise, prm)
+        del st32
+        torch.cuda.empty_cache()
+        stl = make(lo, args.batch)
+        ll, ml = run(stl, tok, facs, noise, prm)
+        res.update({"bench_batch": args.batch, "loss_hip_fp32_bench_batch": l32, "loss_timed_bench_batch": ll,
+                    "rel_free_bench_batch": abs(ll - l32) / abs(l32),
+                    "vq_agree_bench_batch": float((ml["indices"] == m32["indices"]).float().mean())})
+        del stl
         torch.cuda.empty_cache()
     return res
 
@@ -174,7 +250,11 @@ def main():
     ap.add_argument("--vq-image-size", type=int, default=16, help="latent grid S (image = 16*S)")
     ap.add_argument("--augs", default="default", help="'default' = the reference's Af,Pe,Ji,Er (main.py:164-165), or a "
                     "comma list, e.g. 'R'")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp32"],
+                    help="compute dtype of the timed step: 16-bit storage (bf16 | f16: same MFMA rate, f16 = 8x finer "
+                         "mantissa + loss-scaled backward) with fp32 accumulation, or exact fp32 MFMA")
+    ap.add_argument("--loss-scale", type=float, default=4096.0, help="static loss scale of the f16 backward pass")
+    ap.add_argument("--parity-batch", type=int, default=4, help="batch of the oracle-vs-HIP parity leg")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-prefetch-text", dest="prefetch_text", action="store_false",
                     help="encode each step's prompts inside the step instead of one step ahead on a side stream")
@@ -235,6 +315,11 @@ def main():
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic seeded token batches, random-init weights (no network)",
+        "precision_recipe": {"bf16": "bf16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
+                                     "fp32 text tower, VQ distances and loss",
+                             "f16": "IEEE f16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
+                                    f"fp32 text tower, VQ distances and loss, backward loss-scaled x{args.loss_scale:g}",
+                             "fp32": "exact fp32 MFMA everywhere"}[args.dtype],
         "config": {"workload": (f"cfg2: MLP-Mixer {args.depth}x{args.dim}" if args.model_type == "mlp_mixer" else
                                 f"{args.model_type} {args.depth}x{args.dim}") +
                                f" mapper + VQGAN f16-16384 decoder {16 * args.vq_image_size}x{16 * args.vq_image_size} + CLIP "
@@ -276,7 +361,7 @@ def main():
                       f"{v[2]/(v[1]/v[0]*1e-3)/1e12:7.1f}", file=sys.stderr)
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         name, (n, flops, secs) = dom
-        peak = PEAK_BF16_TFLOPS if name.endswith("bf16") else 157.3
+        peak = 157.3 if name.endswith("f32") else PEAK_BF16_TFLOPS
         traffic, traffic_src = None, None
         try:     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
@@ -299,6 +384,7 @@ def main():
         torch.cuda.empty_cache()
         out["cpu_baseline"], ref = cpu_baseline(sds, args.cutn, augs=args.augs)
         out["parity_full_size"] = full_size_parity(args, sds, ref)
+        out["parity_full_size"]["loss_oracle_fp32_batch1"] = ref["loss"]
     if rank == 0:
         print(json.dumps(out))
     if hvd.is_distributed():

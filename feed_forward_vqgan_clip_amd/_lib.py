@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FFVC_LIB") or os.path.join(_HERE, "lib", "libffvc_hip.so")   # FFVC_LIB: A/B builds of the same ABI
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 OP_KMAJOR, OP_TRANS, OP_CONV3X3 = 0, 1, 2
 F_BIAS_ALONG_M = 1
@@ -90,8 +90,8 @@ _SIGNATURES = {
     "ffvc_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ffvc_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                    c_int, c_float, c_void_p]),
-    "ffvc_attn_small_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ffvc_attn_small_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_transpose_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ffvc_layernorm_bwd_blocks": (c_int, [c_int64]),
     "ffvc_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -20,15 +20,8 @@ constexpr int TS = 68;            // LDS row stride (bf16) of a transposed 64 x 
 constexpr int PANEL = 64 * TS;
 constexpr float LOG2E = 1.44269504088896341f;
 
-__device__ __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
-  union {
-    u32x4_t u;
-    bf16x8_t h;
-  } ua, ub;
-  ua.u = a;
-  ub.u = b;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
-}
+// L = 16-bit storage format tag (uint16_t = bf16, f16_t = IEEE half); data moves as raw 16-bit words
+#define mma mma_lo<L>
 
 // 8 consecutive features (k = 16 s + 8 h ...) of token `row` straight from global memory; rows >= T read as zero.
 __device__ __forceinline__ u32x4_t rowfrag(const uint16_t* base, int64_t ld, int row, int T, int s, int h) {
@@ -37,7 +30,7 @@ __device__ __forceinline__ u32x4_t rowfrag(const uint16_t* base, int64_t ld, int
 }
 
 // acc[a][b][r] += sum_d A[rowA0 + 32 a + i(r)][d] * B[rowB0 + 32 b + lane%32][d],  i(r) = 8 (r/4) + 4 (lane/32) + r%4
-template <int NA, int NB>
+template <typename L, int NA, int NB>
 __device__ __forceinline__ void rows_product(f32x16_t (&acc)[NA][NB], const uint16_t* A, int rowA0, const uint16_t* B,
                                              int rowB0, int64_t ld, int T, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
@@ -71,16 +64,17 @@ __device__ __forceinline__ void stage_transposed(uint16_t* Xt, const uint16_t* X
   }
 }
 
+template <typename L>
 __device__ __forceinline__ u32x4_t pack8(const f32x16_t& t, int first) {
   u32x4_t r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = pack_bf16x2(t[first + 2 * e], t[first + 2 * e + 1]);
+  for (int e = 0; e < 4; ++e) r[e] = lo_pack2<L>(t[first + 2 * e], t[first + 2 * e + 1]);
   return r;
 }
 
 // acc[dt][bt][r] += sum_c Xt[32 dt + i(r)][c] * src[c / 32][bt]{c % 32, lane},  c over 64 (contraction index of the
 // source tiles' REGISTER dimension); NC = number of 32-wide contraction tiles present in src (1 or 2).
-template <int NC, int NB>
+template <typename L, int NC, int NB>
 __device__ __forceinline__ void lds_product(f32x16_t (&acc)[2][NB], const uint16_t* Xt, const f32x16_t (&src)[NC][NB],
                                             int c0, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
@@ -96,7 +90,7 @@ __device__ __forceinline__ void lds_product(f32x16_t (&acc)[2][NB], const uint16
       fa[dt] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) fb[b] = pack8(src[ct][b], 8 * sg);
+    for (int b = 0; b < NB; ++b) fb[b] = pack8<L>(src[ct][b], 8 * sg);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -118,6 +112,7 @@ __device__ __forceinline__ int reg_index(int r, int h) { return 8 * (r >> 2) + 4
 
 // Softmax over the keys of transposed score tiles ST[kt][qt] (lane = query, registers = keys), in place, probabilities
 // rounded to bf16 precision (kept as float).  Returns per (lane, qt) the row maximum and 1 / row sum.
+template <typename L>
 __device__ __forceinline__ void softmax_transposed(f32x16_t (&ST)[2][2], int T, float scale, int lane, float (&mx)[2],
                                                    float (&linv)[2]) {
   const int h = lane >> 5;
@@ -145,14 +140,14 @@ __device__ __forceinline__ void softmax_transposed(f32x16_t (&ST)[2][2], int T, 
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ST[kt][qt][r] = bf16_bits_to_f32(f32_to_bf16_bits(ST[kt][qt][r] * inv));
+      for (int r = 0; r < 16; ++r) ST[kt][qt][r] = lo_round<L>(ST[kt][qt][r] * inv);
     mx[qt] = m;
     linv[qt] = inv;
   }
 }
 
 // out[(row0 + 32 bt + lane%32) * ld + 32 dt + i(r)] = acc[dt][bt][r]  (4 consecutive features per store), rows < T
-template <int NB>
+template <typename L, int NB>
 __device__ __forceinline__ void store_transposed(uint16_t* out, int64_t ld, const f32x16_t (&acc)[2][NB], int row0, int T,
                                                  int lane) {
   const int l31 = lane & 31, h = lane >> 5;
@@ -167,11 +162,12 @@ __device__ __forceinline__ void store_transposed(uint16_t* out, int64_t ld, cons
         f32x4_t v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[dt][b][4 * g + j];
-        store4(out + (int64_t)row * ld + 32 * dt + 8 * g + 4 * h, v);
+        store4((L*)out + (int64_t)row * ld + 32 * dt + 8 * g + 4 * h, v);
       }
   }
 }
 
+template <typename L>
 __global__ __launch_bounds__(64) void attn_small_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
                                                            int T, int heads, float scale) {
   __shared__ __attribute__((aligned(16))) uint16_t Vt[PANEL];
@@ -185,18 +181,19 @@ __global__ __launch_bounds__(64) void attn_small_fwd_kernel(const uint16_t* __re
   stage_transposed(Vt, V, ld, T, lane);
   f32x16_t ST[2][2];
   zero_tiles(ST);
-  rows_product<2, 2>(ST, Kp, 0, Q, 0, ld, T, lane);
+  rows_product<L, 2, 2>(ST, Kp, 0, Q, 0, ld, T, lane);
   float mx[2], linv[2];
-  softmax_transposed(ST, T, scale, lane, mx, linv);
+  softmax_transposed<L>(ST, T, scale, lane, mx, linv);
   __syncthreads();
   f32x16_t OT[2][2];
   zero_tiles(OT);
-  lds_product<2, 2>(OT, Vt, ST, 0, lane);
-  store_transposed<2>(o + (int64_t)b * T * D + hd * 64, D, OT, 0, T, lane);
+  lds_product<L, 2, 2>(OT, Vt, ST, 0, lane);
+  store_transposed<L, 2>(o + (int64_t)b * T * D + hd * 64, D, OT, 0, T, lane);
 }
 
 // Backward.  Phase A works on transposed tiles (lane = query): dQ.  Phase B walks the two query tiles in the other
 // orientation (lane = key, registers = queries), re-deriving P from the row statistics kept in LDS: dV and dK.
+template <typename L>
 __global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* __restrict__ qkv,
                                                            const uint16_t* __restrict__ dout,
                                                            uint16_t* __restrict__ dqkv, int T, int heads, float scale) {
@@ -221,9 +218,9 @@ __global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* _
   {
     f32x16_t PT[2][2], dPT[2][2];
     zero_tiles(PT);
-    rows_product<2, 2>(PT, Kp, 0, Q, 0, ld, T, lane);
+    rows_product<L, 2, 2>(PT, Kp, 0, Q, 0, ld, T, lane);
     float mx[2], linv[2];
-    softmax_transposed(PT, T, scale, lane, mx, linv);
+    softmax_transposed<L>(PT, T, scale, lane, mx, linv);
     // dP^T[key][query] = sum_d V[key][d] dO[query][d]   (dO rows have their own stride D)
     zero_tiles(dPT);
     {
@@ -262,8 +259,8 @@ __global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* _
     // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
     f32x16_t dQT[2][2];
     zero_tiles(dQT);
-    lds_product<2, 2>(dQT, bufA, dPT, 0, lane);
-    store_transposed<2>(dQ, ld, dQT, 0, T, lane);
+    lds_product<L, 2, 2>(dQT, bufA, dPT, 0, lane);
+    store_transposed<L, 2>(dQ, ld, dQT, 0, T, lane);
   }
   __syncthreads();
   stage_transposed(bufA, dO, D, T, lane);      // dO^T[d][query]
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* _
     f32x16_t S[1][2], dP[1][2];                // [.][key tile], registers = queries of tile qt
     zero_tiles(S);
     zero_tiles(dP);
-    rows_product<1, 2>(S, Q, 32 * qt, Kp, 0, ld, T, lane);
+    rows_product<L, 1, 2>(S, Q, 32 * qt, Kp, 0, ld, T, lane);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const u32x4_t fa = rowfrag(dO, D, 32 * qt + l31, T, s, h);
@@ -298,43 +295,55 @@ __global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* _
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           float p = kok ? __builtin_amdgcn_exp2f((S[0][kt][r] - m4[j]) * c) * i4[j] : 0.0f;
-          p = bf16_bits_to_f32(f32_to_bf16_bits(p));
+          p = lo_round<L>(p);
           S[0][kt][r] = p;                                           // P[query][key]
           dP[0][kt][r] = p * (dP[0][kt][r] - d4[j]) * scale;         // dS[query][key]
         }
       }
     }
     // dV^T[d][key] += sum_query dO^T[d][query] P[query][key];  dK^T[d][key] += sum_query Q^T[d][query] dS[query][key]
-    lds_product<1, 2>(dVT, bufA, S, 32 * qt, lane);
-    lds_product<1, 2>(dKT, bufB, dP, 32 * qt, lane);
+    lds_product<L, 1, 2>(dVT, bufA, S, 32 * qt, lane);
+    lds_product<L, 1, 2>(dKT, bufB, dP, 32 * qt, lane);
   }
-  store_transposed<2>(dV, ld, dVT, 0, T, lane);
-  store_transposed<2>(dK, ld, dKT, 0, T, lane);
+  store_transposed<L, 2>(dV, ld, dVT, 0, T, lane);
+  store_transposed<L, 2>(dK, ld, dKT, 0, T, lane);
 }
+
+#undef mma
 
 }  // namespace
 
-extern "C" int ffvc_attn_small_fwd(const void* qkv, void* out, int B, int T, int heads, int head_dim, float scale,
-                                   void* stream) {
+extern "C" int ffvc_attn_small_fwd(const void* qkv, void* out, int dtype, int B, int T, int heads, int head_dim,
+                                   float scale, void* stream) {
+  FFVC_CHECK_ARG(dtype == FFVC_BF16 || dtype == FFVC_F16, "ffvc_attn_small_fwd: 16-bit storage only (dtype %d)", dtype);
   FFVC_CHECK_ARG(qkv && out && B > 0 && heads > 0, "ffvc_attn_small_fwd: bad args");
   FFVC_CHECK_ARG(T >= 1 && T <= 64 && head_dim == 64, "ffvc_attn_small_fwd: needs T <= 64 and head_dim == 64 (T=%d, dh=%d)",
                  T, head_dim);
   FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ffvc_attn_small_fwd: misaligned pointers");
-  hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv,
-                     (uint16_t*)out, T, heads, scale);
+  if (dtype == FFVC_F16)
+    hipLaunchKernelGGL(attn_small_fwd_kernel<f16_t>, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       (uint16_t*)out, T, heads, scale);
+  else
+    hipLaunchKernelGGL(attn_small_fwd_kernel<uint16_t>, dim3(B * heads), dim3(64), 0, (hipStream_t)stream,
+                       (const uint16_t*)qkv, (uint16_t*)out, T, heads, scale);
   FFVC_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int B, int T, int heads, int head_dim,
-                                   float scale, void* stream) {
+extern "C" int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int B, int T, int heads,
+                                   int head_dim, float scale, void* stream) {
+  FFVC_CHECK_ARG(dtype == FFVC_BF16 || dtype == FFVC_F16, "ffvc_attn_small_bwd: 16-bit storage only (dtype %d)", dtype);
   FFVC_CHECK_ARG(qkv && dout && dqkv && B > 0 && heads > 0, "ffvc_attn_small_bwd: bad args");
   FFVC_CHECK_ARG(T >= 1 && T <= 64 && head_dim == 64, "ffvc_attn_small_bwd: needs T <= 64 and head_dim == 64 (T=%d, dh=%d)",
                  T, head_dim);
   FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)dqkv % 8) == 0,
                  "ffvc_attn_small_bwd: misaligned pointers");
-  hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv,
-                     (const uint16_t*)dout, (uint16_t*)dqkv, T, heads, scale);
+  if (dtype == FFVC_F16)
+    hipLaunchKernelGGL(attn_small_bwd_kernel<f16_t>, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv,
+                       (const uint16_t*)dout, (uint16_t*)dqkv, T, heads, scale);
+  else
+    hipLaunchKernelGGL(attn_small_bwd_kernel<uint16_t>, dim3(B * heads), dim3(64), 0, (hipStream_t)stream,
+                       (const uint16_t*)qkv, (const uint16_t*)dout, (uint16_t*)dqkv, T, heads, scale);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -48,6 +48,8 @@ struct GemmTraits<uint16_t> {
   static constexpr int TR_CHUNKS_PER_ROW = 16;
 };
 template <>
+struct GemmTraits<f16_t> : GemmTraits<uint16_t> {};   // same 16-bit tile geometry, only the MFMA opcode differs
+template <>
 struct GemmTraits<float> {
   static constexpr int BK = 32;
   static constexpr int EPC = 4;
@@ -232,8 +234,7 @@ struct FragReader<T, FFVC_OP_KMAJOR, TRSAFE> {
 template <typename T, bool TRSAFE>
 struct FragReader<T, FFVC_OP_CONV3X3, TRSAFE> : FragReader<T, FFVC_OP_KMAJOR, TRSAFE> {};
 
-template <>
-struct FragReader<uint16_t, FFVC_OP_TRANS, false> {
+struct FragReaderTr16 {
   // ds_read_b64_tr_b16: within a 16-lane group, lane 4j+q supplies 4 consecutive bf16 of k-row j
   // (columns 4q..4q+3); lane c receives column c of that 4x16 block (rows j = 0..3).
   static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
@@ -256,7 +257,10 @@ struct FragReader<uint16_t, FFVC_OP_TRANS, false> {
   }
 };
 template <>
-struct FragReader<uint16_t, FFVC_OP_TRANS, true> {
+struct FragReader<uint16_t, FFVC_OP_TRANS, false> : FragReaderTr16 {};
+template <>
+struct FragReader<f16_t, FFVC_OP_TRANS, false> : FragReaderTr16 {};
+struct FragReaderTr16Safe {
   static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
     constexpr int RS = GemmTraits<uint16_t>::RS_TRANS;
     union {
@@ -269,6 +273,10 @@ struct FragReader<uint16_t, FFVC_OP_TRANS, true> {
     return u.v;
   }
 };
+template <>
+struct FragReader<uint16_t, FFVC_OP_TRANS, true> : FragReaderTr16Safe {};
+template <>
+struct FragReader<f16_t, FFVC_OP_TRANS, true> : FragReaderTr16Safe {};
 template <bool TRSAFE>
 struct FragReader<float, FFVC_OP_TRANS, TRSAFE> {
   static __device__ __forceinline__ u32x4_t read(const unsigned char* s, int row, int sub, int lane) {
@@ -284,15 +292,12 @@ struct FragReader<float, FFVC_OP_TRANS, TRSAFE> {
 template <typename T>
 __device__ __forceinline__ void mma_chunk(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b);
 template <>
-__device__ __forceinline__ void mma_chunk<uint16_t>(f32x16_t& acc, const u32x4_t& a,
-                                                    const u32x4_t& b) {
-  union {
-    u32x4_t u;
-    bf16x8_t h;
-  } ua, ub;
-  ua.u = a;
-  ub.u = b;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+__device__ __forceinline__ void mma_chunk<uint16_t>(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  mma_lo<uint16_t>(acc, a, b);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<f16_t>(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  mma_lo<f16_t>(acc, a, b);
 }
 template <>
 __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
@@ -460,8 +465,7 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   ffvc_gemm_desc d = *dp;
   FFVC_CHECK_ARG(d.x && d.w && d.y, "ffvc_gemm: null operand pointer");
   FFVC_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ffvc_gemm: bad dims M=%d N=%d K=%d", d.M, d.N, d.K);
-  FFVC_CHECK_ARG(d.in_dtype == FFVC_BF16 || d.in_dtype == FFVC_F32, "ffvc_gemm: bad dtype %d",
-                 d.in_dtype);
+  FFVC_CHECK_ARG(ffvc_dtype_ok(d.in_dtype), "ffvc_gemm: bad dtype %d", d.in_dtype);
   if (d.batch < 1) d.batch = 1;
   if (d.batch_inner < 1) d.batch_inner = 1;
   FFVC_CHECK_ARG(d.batch <= 65535, "ffvc_gemm: batch %d > 65535", d.batch);
@@ -476,7 +480,7 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_ACCUM_OUT) || d.split_k == 1, "ffvc_gemm: FFVC_F_ACCUM_OUT needs split_k == 1");
   FFVC_CHECK_ARG(!((d.flags & (FFVC_F_WRITE_PREACT | FFVC_F_MUL_ACT_GRAD)) && !d.aux),
                  "ffvc_gemm: aux pointer required by flags");
-  const int es = d.in_dtype == FFVC_BF16 ? 2 : 4;
+  const int es = ffvc_dtype_size(d.in_dtype);
   // global_load_dwordx4 needs DWORD alignment only: leading dims / strides must keep 4-byte alignment
   // (16-byte aligned rows are merely the fast case)
   const int epc = 4 / es;
@@ -528,5 +532,6 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_GN_SUMS), "ffvc_gemm: FFVC_F_GN_SUMS is only available on the bf16 LDS-DMA path");
   if (d.in_dtype == FFVC_BF16) return dispatch<uint16_t>(d, st, vec_ok);
+  if (d.in_dtype == FFVC_F16) return dispatch<f16_t>(d, st, vec_ok);
   return dispatch<float>(d, st, vec_ok);
 }

@@ -36,6 +36,7 @@ namespace {
 // 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
 // (X 33 KiB + W 16 KiB) so that two workgroups share a CU and alternate DMA / MFMA phases.
 // K order: kh (3) x 64-channel block (Cin/64) x kw (3); the X tile is (re)loaded only when (kh, block) changes.
+template <typename L>
 __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
                                                           const uint16_t* zero) {
   constexpr int MT = 4, BM = 256, BN = 128;
@@ -95,16 +96,16 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[a], fb[b]);
+            for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[a], fb[b]);
         }
         __syncthreads();
       }
     }
   }
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
   else
-    ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+    ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
 }
 
 uint16_t* g_zero_page[16] = {nullptr};
@@ -139,7 +140,7 @@ inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 // 1 = enqueued here, 0 = shape not eligible (caller falls back to gemm.hip), < 0 = launch error.
 int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
-  if (d.in_dtype != FFVC_BF16 || (d.flags & FFVC_F_TR_SAFE)) return 0;
+  if ((d.in_dtype != FFVC_BF16 && d.in_dtype != FFVC_F16) || (d.flags & FFVC_F_TR_SAFE)) return 0;
   if (!vec_ok || (d.N % 4) != 0) return 0;     // this path carries the vectorised epilogue only
   // the DMA moves whole 16-byte chunks from 16-byte aligned addresses
   if (((uintptr_t)d.x % 16) || ((uintptr_t)d.w % 16)) return 0;
@@ -217,10 +218,14 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       constexpr int lds = 264 * 128 + 128 * 128 + 4 * 4096;
       static bool attr = false;
       if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_row_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
       }
-      hipLaunchKernelGGL(conv_row_kernel, dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+      if (d.in_dtype == FFVC_F16)
+        hipLaunchKernelGGL(conv_row_kernel<f16_t>, dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+      else
+        hipLaunchKernelGGL(conv_row_kernel<uint16_t>, dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) {
         ffvc_set_error("conv_row launch failed: %s", hipGetErrorString(e));

@@ -232,15 +232,8 @@ __device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row
   return u.v;
 }
 
-__device__ __forceinline__ void mma_bf16(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
-  union {
-    u32x4_t u;
-    bf16x8_t h;
-  } ua, ub;
-  ua.u = a;
-  ub.u = b;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
-}
+// L = 16-bit storage format of the operands (uint16_t = bf16, f16_t = IEEE half): tiles move as raw 16-bit words, only
+// the MFMA opcode and the epilogue conversions depend on it.
 
 // Tile configurations (BM x BN, waves as 2(M) x BN/64(N), wave tile (BM/2) x 64):
 //   128x128: 4 waves x 64x64,  2-stage ring (64 KiB),  2 workgroups / CU            -- small / ragged grids
@@ -265,7 +258,7 @@ constexpr bool EXP_SKIP = true;    // timing experiment only (wrong results): em
 #else
 constexpr bool EXP_SKIP = false;
 #endif
-template <int XMODE, int WMODE, int BM, int BN>
+template <typename L, int XMODE, int WMODE, int BM, int BN>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2_kernel(
     const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero, int gm) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
@@ -355,7 +348,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[a], fb[b]);
+          for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[a], fb[b]);
         between(sub);
       }
     } else {
@@ -380,7 +373,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+          for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
         between(sub);
       }
     }
@@ -423,10 +416,10 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     }
   }
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, m0, n0, wm, wn, lane, zo, zi,
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, m0, n0, wm, wn, lane, zo, zi,
                                                        smem + (RING ? 2 : 1) * STAGE + wid * 4096);
   else
-    ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
+    ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
 
 #ifdef FFVC_BUILD_PERSIST   // opt-in build (adds ~2 min of compile time): make CXXEXTRA=-DFFVC_BUILD_PERSIST
@@ -473,7 +466,7 @@ __device__ __forceinline__ WorkItem decode_work(const ffvc_gemm_desc& p, int w, 
   return it;
 }
 
-template <int XMODE, int WMODE, int BM, int BN>
+template <typename L, int XMODE, int WMODE, int BM, int BN>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2p_kernel(
     const ffvc_gemm_desc p, int tiles_n, int n_tiles, int nbatch, int total, int ksplit_len, int vec_ok,
     const uint16_t* zero, int gm, int exact) {
@@ -530,7 +523,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < MT; ++b) mma_bf16(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
+        for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[sub & 1][a], fb[sub & 1][b]);
       between(sub);
     }
   };
@@ -585,10 +578,10 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       });
     }
     if (vec_ok == 2)
-      ffvc_gemm_detail::gemm_epilogue_rows<uint16_t, MT>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi,
+      ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi,
                                                          smem + 2 * STAGE + wid * 4096, cur.zs);
     else
-      ffvc_gemm_detail::gemm_epilogue<uint16_t, MT, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi, 1, cur.zs);
+      ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, cur.zo, cur.zi, 1, cur.zs);
     if (!has_next) break;
     cur = nxt;
     w = wnext;
@@ -597,7 +590,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 
 #endif  // FFVC_BUILD_PERSIST
 
-template <int XMODE, int WMODE, int BM, int BN>
+template <typename L, int XMODE, int WMODE, int BM, int BN>
 int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
   const int n_tiles = tiles_m * tiles_n;
@@ -616,7 +609,7 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128) + 2 * (BN / 64) * 4096;
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<L, XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   static int persist = -1, n_cu = 0;
@@ -647,11 +640,11 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
       int pgrid = total < slots ? (int)total : slots;
       static bool pattr_set = false;
       if (!pattr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm2p_kernel<XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm2p_kernel<L, XMODE, WMODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         pattr_set = true;
       }
       if (total < (1ll << 31)) {
-        hipLaunchKernelGGL((gemm2p_kernel<XMODE, WMODE, BM, BN>), dim3(pgrid), dim3(nthreads), lds, st, d, tiles_n, n_tiles,
+        hipLaunchKernelGGL((gemm2p_kernel<L, XMODE, WMODE, BM, BN>), dim3(pgrid), dim3(nthreads), lds, st, d, tiles_n, n_tiles,
                            d.batch, (int)total, ksplit_len, vec_ok, zero, gm, interior ? 1 : 0);
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) {
@@ -665,7 +658,7 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
 #else
   (void)persist;
 #endif
-  hipLaunchKernelGGL((gemm2_kernel<XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
+  hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
                      vec_ok, zero, gm);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -676,11 +669,16 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
 }
 
 // cfg: 128 -> 128x128, 256 -> 256x128, 512 -> 256x256
+template <typename L, int XMODE, int WMODE>
+int launch2_cfg_t(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg) {
+  if (cfg == 512) return launch2<L, XMODE, WMODE, 256, 256>(d, st, vec_ok, zero);
+  if (cfg == 256) return launch2<L, XMODE, WMODE, 256, 128>(d, st, vec_ok, zero);
+  return launch2<L, XMODE, WMODE, 128, 128>(d, st, vec_ok, zero);
+}
 template <int XMODE, int WMODE>
 int launch2_cfg(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg) {
-  if (cfg == 512) return launch2<XMODE, WMODE, 256, 256>(d, st, vec_ok, zero);
-  if (cfg == 256) return launch2<XMODE, WMODE, 256, 128>(d, st, vec_ok, zero);
-  return launch2<XMODE, WMODE, 128, 128>(d, st, vec_ok, zero);
+  if (d.in_dtype == FFVC_F16) return launch2_cfg_t<f16_t, XMODE, WMODE>(d, st, vec_ok, zero, cfg);
+  return launch2_cfg_t<uint16_t, XMODE, WMODE>(d, st, vec_ok, zero, cfg);
 }
 
 

@@ -12,9 +12,12 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, BF16, F32, F_ACCUM_OUT, F_ATOMIC_OUT, F_BIAS_ALONG_M,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, BF16, F16, F32, F_ACCUM_OUT, F_ATOMIC_OUT, F_BIAS_ALONG_M,  # noqa: F401
                    F_MUL_ACT_GRAD, F_OUT_F32, F_RES_F32, F_TR_SAFE, F_UPSAMPLE2X, F_WRITE_PREACT,
                    OP_CONV3X3, OP_KMAJOR, OP_TRANS, GemmDesc)
+
+
+LOWP = (torch.bfloat16, torch.float16)      # 16-bit storage formats (fp32 accumulate); same kernels, same MFMA rate
 
 
 def stream_ptr():
@@ -33,6 +36,8 @@ def dtype_code(dt):
         return BF16
     if dt == torch.float32:
         return F32
+    if dt == torch.float16:
+        return F16
     raise TypeError(f"unsupported compute dtype {dt}")
 
 
@@ -126,7 +131,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
         e0.record()
         _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
         e1.record()
-        PROFILE.append((_GEMM_CLASS[(x_mode, w_mode)] + ("_f32" if x.dtype == torch.float32 else "_bf16"),
+        PROFILE.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
                         2.0 * M * N * K * max(1, batch), e0, e1, (M, N, K, max(1, batch), split_k)))
         return y
     _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
@@ -169,8 +174,8 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def _dx_lo(x, want_lo):
-    return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want_lo and x.dtype == torch.float32) else None
+def _dx_lo(x, want_lo, lo_dtype=torch.bfloat16):
+    return torch.empty(x.shape, dtype=lo_dtype, device=x.device) if (want_lo and x.dtype == torch.float32) else None
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, want_lo=False):
@@ -183,7 +188,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, w
     if dres is not None and dres.dtype != x.dtype:
         raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
     pg = pb = None
-    lo = _dx_lo(x, want_lo)
+    lo = _dx_lo(x, want_lo, dy.dtype)
     if want_param_grads:
         nb = _lib.load().ffvc_layernorm_bwd_blocks(rows)
         pg = torch.empty(nb, dim, dtype=torch.float32, device=x.device)
@@ -213,7 +218,7 @@ def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_l
         raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
     if dgamma.dtype != torch.float32 or dbeta.dtype != torch.float32 or not dgamma.is_contiguous() or not dbeta.is_contiguous():
         raise TypeError("layernorm_bwd_acc: gradients must be contiguous fp32")
-    lo = _dx_lo(x, want_lo)
+    lo = _dx_lo(x, want_lo, dy.dtype)
     _call("ffvc_layernorm_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
           gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
           dbeta.data_ptr(), _ptr(lo), rows, dim, stream_ptr())
@@ -229,7 +234,7 @@ def _gn_ws(B, HW, G, dev):
 
 def gn_sums_ok(M, N, HW, dtype, G=32):
     """Can the GEMM that produces an (M = images*HW, N = C) NHWC tensor also accumulate its GroupNorm moments?"""
-    return (dtype == torch.bfloat16 and HW % 256 == 0 and M % HW == 0 and N % G == 0 and (N // G) % 4 == 0 and
+    return (dtype in LOWP and HW % 256 == 0 and M % HW == 0 and N % G == 0 and (N // G) % 4 == 0 and
             os.environ.get("FFVC_GN_FUSE", "1") != "0")
 
 
@@ -616,25 +621,27 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
 def attn_small_ok(qkv, heads, causal):
     """Shapes the fused short-sequence attention kernel covers."""
     B, T, D3 = qkv.shape
-    return (qkv.dtype == torch.bfloat16 and not causal and T <= 64 and D3 == 3 * heads * 64 and
+    return (qkv.dtype in LOWP and not causal and T <= 64 and D3 == 3 * heads * 64 and
             os.environ.get("FFVC_ATTN_SMALL", "1") != "0")
 
 
 def attn_small_fwd(qkv, heads, scale):
-    _req(torch.bfloat16, qkv)
+    _req(qkv.dtype if qkv.dtype in LOWP else torch.bfloat16, qkv)
     B, T, D3 = qkv.shape
     o = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
-    _call("ffvc_attn_small_fwd", qkv.data_ptr(), o.data_ptr(), B, T, heads, 64, float(scale), stream_ptr())
+    _call("ffvc_attn_small_fwd", qkv.data_ptr(), o.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64, float(scale),
+          stream_ptr())
     return o
 
 
 def attn_small_bwd(qkv, do, heads, scale):
-    _req(torch.bfloat16, qkv, do)
+    _req(qkv.dtype if qkv.dtype in LOWP else torch.bfloat16, qkv, do)
     if do.shape[:2] != qkv.shape[:2] or do.shape[2] * 3 != qkv.shape[2]:
         raise ValueError('attn_small_bwd: dout shape does not match qkv')
     B, T, D3 = qkv.shape
     dqkv = torch.empty_like(qkv)
-    _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, T, heads, 64, float(scale),
+    _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
+          float(scale),
           stream_ptr())
     return dqkv
 

@@ -147,7 +147,7 @@ def tv_loss(Y_hat):
 
 def _cdt(config):
     name = str(config.get("compute_dtype", "bf16"))
-    return {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[name]
+    return {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "fp32": torch.float32, "f32": torch.float32}[name]
 
 
 def load_clip_model(model_type, path=None, cdt=torch.bfloat16):
@@ -304,7 +304,7 @@ class TrainStep:
         ev.record(side)
         self._prefetched = ((tokens.data_ptr(), tuple(tokens.shape)), feats, ev, tokens)
 
-    def forward_loss(self, inp, out=None, facs=None, noise=None, aug_params=None, noise_vec_in=None):
+    def forward_loss(self, inp, out=None, facs=None, noise=None, aug_params=None, noise_vec_in=None, force_idx=None):
         """main.py:729-811 -> (loss, intermediates).  facs / noise / aug_params / noise_vec_in pin the step's random
         draws (cutout noise, augmentation parameters, the mapper's conditioning noise) for parity tests."""
         inp_feats = self.features(inp)                                          # :733
@@ -332,7 +332,7 @@ class TrainStep:
         z_nhwc = z.permute(0, 2, 3, 1)                                          # contiguous for NHWC-native mappers
         l2 = ops.mean_sq(z_nhwc) if self.l2_coef > 0 else None                  # :758-762 (mean is layout-independent)
         z_nhwc = ops.clamp_with_grad(z_nhwc, self.vq.z_min, self.vq.z_max)      # :763
-        xr, idx = synth_nhwc(self.vq, z_nhwc)                                   # :767
+        xr, idx = synth_nhwc(self.vq, z_nhwc, force_idx)                        # :767 (force_idx: parity instrumentation)
         patches = self.make_cutouts.patches(xr, self.perceptor.patch, tuple(CLIP_MEAN), tuple(CLIP_STD),
                                             self.perceptor.cdt, facs, noise, aug_params)   # :796-797 fused
         embed = self.perceptor.encode_patches(patches)                          # :799

@@ -170,7 +170,7 @@ class _VitGANBase(_MapperBase):
         """GTransformerEncoder (vitgan.py:120-164): hl, x fp32 (B, T, dim)."""
         cdt, f32 = self.cdt, torch.float32
         B, T, dim = x.shape
-        align = 2 if cdt == torch.bfloat16 else 1          # GEMM operands need 4-byte aligned head blocks
+        align = 2 if cdt != torch.float32 else 1          # GEMM operands need 4-byte aligned head blocks
         for (n1, Wqkv, Wout, n2, W1, W2, att) in self._bp:
             H, dh = att.num_heads, att.dim_head
             dhp = (dh + align - 1) // align * align

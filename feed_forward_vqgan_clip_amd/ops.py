@@ -2,7 +2,7 @@
 backward only enqueue ffvc_* kernels (feed_forward_vqgan_clip_amd/kernels.py).
 
 Conventions
-  * activations are contiguous; `cdt` (compute dtype) is torch.bfloat16 (throughput mode, fp32
+  * activations are contiguous; `cdt` (compute dtype) is torch.bfloat16 / torch.float16 (throughput modes, fp32
     accumulate) or torch.float32 (parity mode: exact fp32 MFMA).  Residual streams of the mapper
     and of CLIP are fp32; the decoder is `cdt` end to end.
   * weights are `Weights` packs: fp32 master (`weight`, `bias`, reference layout/names) plus the
@@ -131,7 +131,7 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None):
     """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N)."""
     wg = _grad_buf(W.weight)
     bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad) else None
-    bk = 64 if dy2d.dtype == torch.bfloat16 else 32
+    bk = 64 if dy2d.dtype in K.LOWP else 32
     sk = _split_k(W.N, W.K, rows, bk)
     with _on_side(dy2d, x2d):
         K.gemm_splitk_accumulate(dy2d, x2d, wg, W.N, W.K, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
@@ -147,7 +147,7 @@ _LN_LO = os.environ.get("FFVC_LN_LO", "1") != "0"      # A/B switch for the fuse
 
 def _gn_request(gn, y, images, hw, C):
     """Moments buffer for a producer whose NHWC output `y` goes into GroupNorm(32) next (None if not fusable)."""
-    if not gn or y.dtype != torch.bfloat16 or not K.gn_sums_ok(images * hw, C, hw, y.dtype):
+    if not gn or y.dtype not in K.LOWP or not K.gn_sums_ok(images * hw, C, hw, y.dtype):
         return None
     sums = K.gn_sums_buffer(images, 32, y.device)
     y._ffvc_gn = sums
@@ -301,7 +301,7 @@ class _TokenMLPFn(Function):
         K.gemm(W2.sht, dyt, dh, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, aux=h_pre, ldaux=D, act=ACT_GELU,
                flags=K.F_MUL_ACT_GRAD, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
         if ctx.train:
-            bk = 64 if cdt == torch.bfloat16 else 32
+            bk = 64 if cdt in K.LOWP else 32
             seg_ok = D % bk == 0
             for (g, a, W, n_out, k_out) in ((dyt, h, W2, T, O), (dh, xn, W1, O, T)):
                 wg = _grad_buf(W.weight)
@@ -356,7 +356,7 @@ class _LNForkFn(Function):
         if dres is not None:
             dres = _as(_contig(dres), x.dtype)
         # fp32 residual stream under bf16 compute: the gradient leaving here feeds a bf16 GEMM next -> emit its copy now
-        lo = _LN_LO and x.dtype == torch.float32 and dy.dtype == torch.bfloat16
+        lo = _LN_LO and x.dtype == torch.float32 and dy.dtype in K.LOWP
         if ctx.params is not None:
             gamma, beta = ctx.params
             dx = K.layernorm_bwd_acc(dy, x, g, mean, rstd, _grad_buf(gamma), _grad_buf(beta), dres=dres, want_lo=lo)
@@ -422,7 +422,7 @@ class ConvWeights:
         wd_k = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()             # [Cin, kh', kw', Cout]
         self.w = _as(w_k.view(self.Cout, 9 * self.Cin), cdt)
         self.bias = None if bias is None else bias.detach().float().cuda().contiguous()
-        bk = 64 if cdt == torch.bfloat16 else 32
+        bk = 64 if cdt in K.LOWP else 32
         self.wd = self.wd_small = None
         if self.Cout % bk == 0:
             self.wd = _as(wd_k.view(self.Cin, 9 * self.Cout), cdt)
@@ -574,26 +574,31 @@ def clamp_with_grad(x, lo, hi, mul=1.0, add=0.0, out_dtype=None):
 
 class _VQFn(Function):
     @staticmethod
-    def forward(ctx, z, codebook, cnorm, out_dtype):
+    def forward(ctx, z, codebook, cnorm, out_dtype, force_idx):
         z = _contig(z)
         C = z.shape[-1]
         rows = z.numel() // C
         n = codebook.shape[0]
-        dot = torch.empty(rows, n, dtype=torch.float32, device=z.device)
-        K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
-        idx = K.vq_argmin(dot, K.rownorm_sq(z), cnorm)
+        if force_idx is None:
+            dot = torch.empty(rows, n, dtype=torch.float32, device=z.device)
+            K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
+            idx = K.vq_argmin(dot, K.rownorm_sq(z), cnorm)
+        else:
+            idx = force_idx.reshape(rows).to(torch.int64).contiguous()
         ctx.zdtype = z.dtype
         ctx.mark_non_differentiable(idx)
         return K.gather_rows(codebook, idx.view(z.shape[:-1]), out_dtype), idx
 
     @staticmethod
     def backward(ctx, g, _):
-        return _as(_contig(g), ctx.zdtype), None, None, None      # straight-through (main.py:105-116,138)
+        return _as(_contig(g), ctx.zdtype), None, None, None, None      # straight-through (main.py:105-116,138)
 
 
-def vector_quantize(z, codebook, cnorm, out_dtype):
-    """z: (..., C) fp32 -> (z_q in out_dtype, indices). Nearest code, STE gradient (main.py:134-138)."""
-    return _VQFn.apply(z, codebook, cnorm, out_dtype)
+def vector_quantize(z, codebook, cnorm, out_dtype, force_idx=None):
+    """z: (..., C) fp32 -> (z_q in out_dtype, indices). Nearest code, STE gradient (main.py:134-138).
+    force_idx: take these codes instead of the argmin (parity instrumentation: the argmin is a discontinuity, so
+    stage-wise precision checks hand the reference's codes to the low-precision decoder)."""
+    return _VQFn.apply(z, codebook, cnorm, out_dtype, force_idx)
 
 
 class _CutoutsFn(Function):

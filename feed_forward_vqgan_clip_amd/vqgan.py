@@ -163,9 +163,9 @@ class VQGAN:
         hn, _ = ops.groupnorm_fork(h, *self.norm_out, True)
         return ops.conv3x3(hn, self.conv_out, out_dtype=torch.float32)
 
-    def quantize_nhwc(self, z_nhwc):
+    def quantize_nhwc(self, z_nhwc, force_idx=None):
         """(B,S,S,C) fp32 -> (z_q compute dtype with straight-through grad, indices)."""
-        return ops.vector_quantize(z_nhwc, self.codebook, self.cnorm, self.cdt)
+        return ops.vector_quantize(z_nhwc, self.codebook, self.cnorm, self.cdt, force_idx)
 
     # -- reference-shaped API ---------------------------------------------------
     def decode(self, z_q):
@@ -181,9 +181,9 @@ def vector_quantize(x, codebook, vq=None):
     return ops.vector_quantize(x.float(), cb, cn, torch.float32)[0]
 
 
-def synth_nhwc(model, z_nhwc):
+def synth_nhwc(model, z_nhwc, force_idx=None):
     """NHWC core of synth(): (B,S,S,C) fp32 -> (xr NHWC fp32 in [0,1], indices)."""
-    z_q, idx = model.quantize_nhwc(z_nhwc)
+    z_q, idx = model.quantize_nhwc(z_nhwc, force_idx)
     dec = model.decode_nhwc(z_q)
     return ops.clamp_with_grad(dec, 0.0, 1.0, mul=0.5, add=0.5), idx
 

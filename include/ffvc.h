@@ -193,8 +193,9 @@ int ffvc_softmax_bwd(const void* p, const float* dp, void* ds, int p_dtype, int6
  * softmax / both products in registers.  qkv: [B, T, 3*heads*64] (q | k | v sections, head-major inside each, the
  * packed in_proj output of nn.MultiheadAttention, cloob.py:199-200), out / dout: [B, T, heads*64], dqkv like qkv.
  * Non-causal.  The backward recomputes the probabilities from qkv (nothing but qkv is kept from the forward). */
-int ffvc_attn_small_fwd(const void* qkv, void* out, int B, int T, int heads, int head_dim, float scale, void* stream);
-int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int B, int T, int heads, int head_dim,
+int ffvc_attn_small_fwd(const void* qkv, void* out, int dtype, int B, int T, int heads, int head_dim, float scale,
+                        void* stream);   /* dtype: FFVC_BF16 | FFVC_F16 */
+int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int B, int T, int heads, int head_dim,
                         float scale, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -15,7 +15,7 @@ from feed_forward_vqgan_clip_amd import ops, vqgan as fvq  # noqa: E402
 from feed_forward_vqgan_clip_amd.mappers import Mixer  # noqa: E402
 from feed_forward_vqgan_clip_amd.optim import FusedAdam  # noqa: E402
 
-F32, BF16 = torch.float32, torch.bfloat16
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
 TINY_VQ = dict(ch=64, ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64,
                out_ch=3, embed_dim=64, n_embed=128)      # 3 levels -> image = 4 * S, attention at the first level
 
@@ -43,13 +43,24 @@ def test_mixer_fp32_matches_reference_golden(cuda):
         assert_close(sd[k].grad.cpu(), g, 3e-4, 3e-5, f"mixer grad {k}")
 
 
-def test_mixer_bf16_close_to_reference_golden(cuda):
+@pytest.mark.parametrize("cdt,tol", [(BF16, 2e-2), (F16, 3e-3)])
+def test_mixer_16bit_close_to_reference_golden(cuda, cdt, tol):
     z = load("mixer.npz")
     net = Mixer(input_dim=24, image_size=4, channels=8, patch_size=1, dim=16, depth=2)
     net.load_state_dict(unpack_sd(z, "sd"))
-    net = net.cuda().prepare(BF16)
-    y = net(t(z["x"]).cuda())
-    assert _relrms(y, t(z["y"])) < 2e-2            # bf16 operands, fp32 accumulate / residual / LN
+    net = net.cuda().prepare(cdt)
+    x = t(z["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert _relrms(y, t(z["y"])) < tol             # 16-bit operands, fp32 accumulate / residual / LN
+    net._ffvc_arena.zero_grad()
+    (y * t(z["gw"]).cuda()).sum().backward()
+    assert _relrms(x.grad, t(z["dx"])) < 3 * tol
+    sd = dict(net.named_parameters())
+    gs = grads(z, "grad")
+    gmax = max(g.abs().max().item() for g in gs.values())
+    for k, g in gs.items():
+        if g.abs().max().item() > 1e-4 * gmax:
+            assert _relrms(sd[k].grad, g) < 5 * tol, k
 
 
 def test_mixer_state_dict_layout():
@@ -59,7 +70,7 @@ def test_mixer_state_dict_layout():
 
 
 # ----------------------------------------------------------------------------- CLIP vs reference golden
-@pytest.mark.parametrize("cdt,tol", [(F32, 2e-4), (BF16, 3e-2)])
+@pytest.mark.parametrize("cdt,tol", [(F32, 2e-4), (BF16, 3e-2), (F16, 4e-3)])
 def test_clip_matches_reference_golden(cuda, cdt, tol):
     z = load("clip.npz")
     sd = unpack_sd(z, "sd")
@@ -74,13 +85,13 @@ def test_clip_matches_reference_golden(cuda, cdt, tol):
     if cdt == F32:
         assert_close(img.grad.cpu(), z["dimg"], 5e-4, 2e-5, "dimg")
     else:
-        assert _relrms(img.grad, t(z["dimg"])) < 5e-2
+        assert _relrms(img.grad, t(z["dimg"])) < 2 * tol
     et = model.encode_text(t(z["tok"]).cuda())          # text tower is always exact fp32
     assert_close(et.cpu(), z["text_embed"], 2e-4, 1e-5, "text_embed")
 
 
 # ----------------------------------------------------------------------------- VQGAN decoder vs oracle
-@pytest.mark.parametrize("cdt,tol", [(F32, 1e-4), (BF16, 3e-2)])
+@pytest.mark.parametrize("cdt,tol", [(F32, 1e-4), (BF16, 3e-2), (F16, 4e-3)])
 def test_vqgan_decoder_matches_oracle(cuda, cdt, tol):
     from oracle import step as ostep
     sd = fvq.random_state_dict(TINY_VQ, seed=7)
@@ -100,7 +111,7 @@ def test_vqgan_decoder_matches_oracle(cuda, cdt, tol):
         assert_close(z.grad.cpu(), zo.grad, 1e-3, 1e-5, "dz")
     else:
         assert _relrms(xr, xo.detach()) < tol
-        assert _relrms(z.grad, zo.grad) < 8e-2
+        assert _relrms(z.grad, zo.grad) < 3 * tol
 
 
 def test_vq_and_glue_match_reference_golden(cuda):
@@ -153,7 +164,15 @@ def _tiny_step(cdt, seed=11):
     return cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise
 
 
-@pytest.mark.parametrize("cdt", [F32, BF16])
+# 16-bit throughput modes: stage tolerances, asserted UNCONDITIONALLY.  The VQ argmin is a discontinuity of the reference
+# itself (a code flips when the two nearest codes are closer than the mapper's rounding error), so the end-to-end
+# comparison is made twice: free-running (codes may differ: loose bound, agreement rate asserted) and with the
+# reference's codes handed to the decoder (`force_idx`), where the north-star tolerance on the loss applies.
+LOWP_TOL = {BF16: dict(z=3e-2, agree=0.97, xr=3e-2, loss_same_codes=2e-3, loss_free=2e-2, grad=1.5e-1),
+            F16: dict(z=4e-3, agree=0.99, xr=4e-3, loss_same_codes=1e-4, loss_free=5e-3, grad=5e-2)}
+
+
+@pytest.mark.parametrize("cdt", [F32, BF16, F16])
 def test_train_step_matches_oracle(cuda, cdt):
     from oracle import mappers as omap
     from oracle import step as ostep
@@ -161,37 +180,53 @@ def test_train_step_matches_oracle(cuda, cdt):
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
     msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda())
-    opt.zero_grad()
-    loss.backward()
     # oracle on identical weights / inputs
     osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
     oloss, omid = ostep.train_step_loss(
         lambda sd, f: omap.mixer_forward(sd, f, image_size=12, channels=64, depth=2), osd, vq_sd, clip_sd, tok,
         cutn=4, cut_size=32, z_min=vq.z_min, z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise, vq_cfg=TINY_VQ)
     oloss.backward()
+    oidx = ostep.vq_indices(omid["z"].detach().movedim(1, 3), vq_sd["quantize.embedding.weight"])
     rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
-    agree = (mid["indices"].cpu().view(-1) == ostep.vq_indices(omid["z"].detach().movedim(1, 3), vq_sd["quantize.embedding.weight"]).view(-1)).float().mean().item()
+    agree = (mid["indices"].cpu().view(-1) == oidx.view(-1)).float().mean().item()
     print(f"[{cdt}] loss hip={loss.item():.7f} oracle={oloss.item():.7f} rel={rel:.2e} vq index agreement={agree:.4f}")
+    params = dict(net.named_parameters())
+    gmax = max(v.grad.abs().max().item() for v in osd.values())
     if cdt == F32:
+        opt.zero_grad()
+        loss.backward()
         assert_close(mid["z"].cpu(), omid["z"].detach(), 2e-4, 2e-5, "z")
         assert agree == 1.0
         assert_close(mid["xr"].permute(0, 3, 1, 2).cpu(), omid["xr"].detach(), 2e-4, 2e-5, "xr")
         assert_close(mid["embed"].cpu(), omid["embed"].detach(), 5e-4, 5e-5, "embed")
         assert rel < 1e-4                                   # north_star: CLIP loss within 1e-4 rel of the CPU reference
-        params = dict(net.named_parameters())
-        gmax = max(v.grad.abs().max().item() for v in osd.values())
         for k, v in osd.items():
             # parameters whose exact gradient is 0 (token-mix bias in front of a LayerNorm) hold round-off only
             tiny = (params[k].grad.cpu() - v.grad).abs().max().item() < 1e-6 * gmax
             assert tiny or _relrms(params[k].grad, v.grad) < 2e-3, k
-    else:
-        assert _relrms(mid["z"], omid["z"].detach()) < 3e-2
-        if agree == 1.0:                                    # identical codes -> the remaining stages are comparable
-            assert _relrms(mid["xr"].permute(0, 3, 1, 2), omid["xr"].detach()) < 3e-2
-            assert rel < 2e-2
+        return
+    tol = LOWP_TOL[cdt]
+    zc = mid["z"].detach().clamp(vq.z_min, vq.z_max)
+    assert _relrms(zc, omid["z"].detach()) < tol["z"]
+    assert agree >= tol["agree"]
+    assert rel < tol["loss_free"]
+    # same codes -> the remaining stages are comparable at the stated tolerance
+    loss_sc, mid_sc = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), force_idx=oidx.cuda())
+    rel_sc = abs(loss_sc.item() - oloss.item()) / abs(oloss.item())
+    xerr = _relrms(mid_sc["xr"].permute(0, 3, 1, 2), omid["xr"].detach())
+    print(f"[{cdt}] same codes: loss rel={rel_sc:.2e} xr rel-rms={xerr:.2e}")
+    assert xerr < tol["xr"]
+    assert rel_sc < tol["loss_same_codes"]
+    ls = 8192.0 if cdt == F16 else 1.0                      # loss-scaled backward in f16 (gradients below 6e-5 would go subnormal)
+    opt.zero_grad()
+    (loss_sc * ls).backward()
+    errs = sorted(((_relrms(params[k].grad / ls, v.grad), k) for k, v in osd.items() if v.grad.abs().max().item() > 1e-4 * gmax),
+                  reverse=True)
+    print(f"[{cdt}] worst param-grad rel-rms (same codes): {errs[:3]}")
+    assert errs[0][0] < tol["grad"]
 
 
-@pytest.mark.parametrize("cdt", [F32, BF16])
+@pytest.mark.parametrize("cdt", [F32, BF16, F16])
 def test_train_step_default_augs_matches_oracle(cuda, cdt):
     """Same step with the reference's DEFAULT augmentation set (Af, Pe, Ji, Er; main.py:164-165), the random
     parameters drawn once and fed to both sides."""
@@ -224,7 +259,7 @@ def test_train_step_default_augs_matches_oracle(cuda, cdt):
             tiny = (params[k].grad.cpu() - v.grad).abs().max().item() < 1e-6 * gmax
             assert tiny or _relrms(params[k].grad, v.grad) < 5e-3, k
     else:
-        assert rel < 3e-2
+        assert rel < LOWP_TOL[cdt]["loss_free"]
     # a step without explicit parameters draws its own
     loss2, _ = stepper.forward_loss(tok.cuda())
     assert torch.isfinite(loss2)
@@ -281,7 +316,7 @@ def test_simple_vitgan_fp32_matches_reference_golden(cuda):
 
 
 @pytest.mark.parametrize("kind", ["vitgan", "simple_vitgan", "xtransformer"])
-@pytest.mark.parametrize("cdt", [F32, BF16])
+@pytest.mark.parametrize("cdt", [F32, BF16, F16])
 def test_other_mappers_match_oracle(cuda, kind, cdt):
     """Realistic head geometry (dim 120 / 6 heads -> dim_head 20; x-transformer 3 heads x 64) vs the oracle."""
     from oracle import mappers as omap
@@ -305,11 +340,11 @@ def test_other_mappers_match_oracle(cuda, kind, cdt):
     net._ffvc_arena.zero_grad()
     (y * gw.cuda()).sum().backward()
     (yo * gw).sum().backward()
-    tol = 2e-4 if cdt == F32 else 4e-2
+    tol = {F32: 2e-4, BF16: 4e-2, F16: 5e-3}[cdt]
     assert _relrms(y, yo.detach()) < tol, "forward"
     params = dict(net.named_parameters())
     worst = max(_relrms(params[k].grad, v.grad) for k, v in sd.items() if v.grad.abs().max() > 1e-6)
-    assert worst < (2e-3 if cdt == F32 else 1.5e-1), f"worst param-grad rel-rms {worst}"   # bf16 operands at dim_head 20
+    assert worst < {F32: 2e-3, BF16: 1.5e-1, F16: 2e-2}[cdt], f"worst param-grad rel-rms {worst}"   # 16-bit operands at dim_head 20
 
 
 def test_text_prefetch_matches_inline(cuda):
