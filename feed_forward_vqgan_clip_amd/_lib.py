@@ -146,6 +146,9 @@ _SIGNATURES = {
     "ffvc_slab_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ffvc_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ffvc_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ffvc_tokmix_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "ffvc_tokmix_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_tokmix_bwd_hidden": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_set_option": (c_int, [c_char_p, c_int]),
     "ffvc_last_error": (c_char_p, []),
     "ffvc_version": (c_int, []),

@@ -238,8 +238,13 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) {
     // measured: wgrad (both operands through ds_read_b64_tr_b16) runs 745 TFLOP/s on the register-staged kernel
     // (3 workgroups/CU) vs 551 on the 128x128 DMA tile -> keep it on gemm.hip unless forced
-    if (env_bm != 128 && env_bm != 256 && env_bm != 512) return 0;
-    return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, cfg);
+    // round 2 (profiles/r02_wgrad_ab.txt): with 256x256 tiles and a 4-way slab split-K the DMA path passes it on the big
+    // square-ish weight gradients (4096x1024x16384: 856 vs 640 TFLOP/s); narrow outputs / short reductions stay on v1.
+    if (env_bm == 128 || env_bm == 256 || env_bm == 512) return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, cfg);
+    if (env_bm == 1 && d.M >= 1024 && d.N >= 1024 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.K >= 8192 && d.batch == 1 &&
+        (int64_t)(d.M / 256) * (d.N / 256) * (d.split_k < 1 ? 1 : d.split_k) >= 192)
+      return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
+    return 0;
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return ffvc_gemm2_launch_nn(d, st, vec_ok, zero, cfg);
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_KMAJOR) return ffvc_gemm2_launch_tn(d, st, vec_ok, zero, cfg);

@@ -95,21 +95,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma.
 // Each workgroup owns a strip of rows and emits one partial row of dgamma / dbeta
 // (part_g/part_b: [gridDim.x, dim], reduced afterwards by ffvc_colsum); NULL skips them.
-template <int VEC, typename DYT, typename XT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, const XT* __restrict__ x,
+// MAXE = elements cached per lane (16: dim <= 1024, 32: dim <= 2048): the kernel is latency-bound on its row loads, so
+// register count (= waves in flight per SIMD) is what sets its bandwidth.
+template <int VEC, typename DYT, typename XT, int MAXE = LN_MAXE>
+__global__ __launch_bounds__(256, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(const DYT* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const XT* __restrict__ dres,
                                                      XT* __restrict__ dx, float* __restrict__ part_g,
                                                      float* __restrict__ part_b, int64_t rows, int dim,
                                                      int rows_per_block, int acc_mode, DYT* __restrict__ dx_lo) {
-  constexpr int NIT = LN_MAXE / VEC;
+  constexpr int NIT = MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool want_p = part_g != nullptr;
-  float ag[LN_MAXE], ab[LN_MAXE];
+  float ag[MAXE], ab[MAXE];
 #pragma unroll
-  for (int i = 0; i < LN_MAXE; ++i) ag[i] = ab[i] = 0.f;
+  for (int i = 0; i < MAXE; ++i) ag[i] = ab[i] = 0.f;
   if (want_p) {
     for (int i = threadIdx.x; i < 2 * dim; i += 256) ln_smem[i] = 0.f;
     __syncthreads();
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
   const int64_t r1 = min(rows, r0 + rows_per_block);
   for (int64_t row = r0 + wave; row < r1; row += 4) {
     const float mu = mean[row], rs = rstd[row];
-    float g[LN_MAXE], xh[LN_MAXE];
+    float g[MAXE], xh[MAXE], rsd[MAXE];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
         ld_vec<VEC>(dy + row * dim + idx, d);
         ld_vec<VEC>(x + row * dim + idx, xv);
         ld_vec<VEC>(gamma + idx, gm);
+        if (dres) ld_vec<VEC>(dres + row * dim + idx, &rsd[k * VEC]);   // issued with the other row loads, used after the reductions
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float h = (xv[j] - mu) * rs;
@@ -150,10 +153,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = rs * (g[k * VEC + j] - s1 - xh[k * VEC + j] * s2);
         if (dres) {
-          float r[VEC];
-          ld_vec<VEC>(dres + row * dim + idx, r);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) o[j] += r[j];
+          for (int j = 0; j < VEC; ++j) o[j] += rsd[k * VEC + j];
         }
         st_vec<VEC>(dx + row * dim + idx, o);
         if (dx_lo) st_vec<VEC>(dx_lo + row * dim + idx, o);   // bf16 copy for the GEMM that consumes this gradient
@@ -784,7 +785,11 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
   const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
   const bool v4 = (dim % 4) == 0;
   DISPATCH_DT(dy_dtype, DYT, DISPATCH_DT(x_dtype, XT, {
-                if (v4)
+                if (v4 && dim <= 1024)
+                  hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
+                                     (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
+                                     dim, rpb, acc_mode, (DYT*)dx_lo);
+                else if (v4)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
                                      dim, rpb, acc_mode, (DYT*)dx_lo);

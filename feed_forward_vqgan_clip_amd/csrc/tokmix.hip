@@ -1,0 +1,422 @@
+// tokmix.hip — fused token-mixing MLP of the MLP-Mixer mapper (mlp_mixer_pytorch.py:28,34: Conv1d(k=1) over the token
+// axis -> GELU -> Conv1d(k=1), inside PreNormResidual :7-14):
+//
+//     y[b] = W2 @ gelu(W1 @ xn[b] + b1) + b2 + res[b]          xn[b]: [T, D]   W1: [O, T]   W2: [T, O]   (O = 4T)
+//
+// As two batched GEMMs this is the worst-shaped work of the step: K = T = 256 is only 4 K-steps, so the first GEMM is all
+// prologue + epilogue (142 TFLOP/s, round 1) and the hidden activation [B, O, D] (2 x 134 MB per layer with its
+// pre-activation) crosses HBM four times per step.  Here ONE workgroup owns (sample b, 256 columns of D):
+//
+//   * the 256 x 256 slice of xn[b] is staged once (LDS-DMA, transposed reads) into MFMA B fragments that stay in
+//     registers for the whole kernel (T/16 fragments = 64 VGPRs at T = 256): every wave owns 32 columns;
+//   * the hidden dimension is walked in chunks of 32 rows: W1[32, T] and W2[T, 32] chunks stream through a 4-deep LDS ring
+//     (counted vmcnt, one barrier per chunk); GEMM-1 gives the 32 x 32 hidden block in accumulators, bias + erf-GELU are
+//     applied in registers, and — since MFMA sums over k in any order as long as both operands agree — the accumulator
+//     registers ARE the B fragment of GEMM-2 after four v_permlane32_swap (which make each lane's 8 hidden rows
+//     consecutive, so the W2 fragment is a plain 16-byte K-major read).  The hidden activation never leaves the CU;
+//   * the output tile goes through LDS once so that residual reads / y stores are full 1 KiB rows (16 B per lane).
+//
+// Backward recomputes the hidden block instead of reading it back (`tokmix_bwd_hidden_kernel`): h = gelu(W1 xn + b1) and
+// dh = (W2^T dy) * gelu'(W1 xn + b1) are produced chunk by chunk and written once (16-bit) for the weight-gradient GEMMs;
+// dx = W1^T dh stays a plain batched GEMM (K = O is long).  Nothing of the forward is saved besides xn.
+//
+// LDS images (16-byte slots, source-side XOR swizzle as in gemm2.hip; verified conflict-free for T in {128, 256}):
+//   W1 / W2^T chunk [32 rows][T]:  slot' = slot ^ (row & 15)
+//   W2 chunk        [T rows][32]:  4 slots per row, 4 rows per 256-B line:  q' = q ^ (line & 15)
+#include "gemm2_kernels.h"
+
+namespace {
+
+constexpr int TM_DT = 256;   // D columns per workgroup (8 waves x 32)
+constexpr int TM_OC = 32;    // hidden rows per chunk
+constexpr int TM_NST = 4;    // ring depth
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 12 && (N % 2) == 0, "add the vmcnt literal");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+typedef const __attribute__((address_space(4))) float* const_f32p;   // constant address space: uniform loads become s_load
+
+// per-thread DMA sources of one [32 rows][T] K-major chunk (row stride `ld` elements) and of one [T rows][32] chunk
+template <int T_>
+struct ChunkDma {
+  static constexpr int NP = T_ / 128;          // 1-KiB pieces per thread per chunk half (512 threads x 16 B = 8 KiB)
+  int offA[NP];                                // [32][T] image: element offset of this thread's 16 bytes (+ chunk base)
+  int offB[NP];                                // [T][32] image
+  __device__ __forceinline__ void init(int tid, int ldA, int ldB) {
+    const int lane = tid & 63, w = tid >> 6;
+    constexpr int SPR = T_ / 8;                // 16-byte slots per [32][T] row
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = (8 * j + w) * 64 + lane;
+      const int row = p / SPR, slot = (p % SPR) ^ (row & 15);
+      offA[j] = row * ldA + slot * 8;
+      const int e = (p & ~15) | ((p & 15) ^ ((p >> 4) & 15));
+      offB[j] = (e >> 2) * ldB + (e & 3) * 8;
+    }
+  }
+  // chunk of rows [r0, r0+32) of a K-major [rows][T] matrix
+  __device__ __forceinline__ void issueA(unsigned char* dst, const uint16_t* base, int tid) const {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dma16(base + offA[j], dst + (8 * j + w) * 1024);
+  }
+  // columns [c0, c0+32) of a K-major [T][cols] matrix (base already offset by c0)
+  __device__ __forceinline__ void issueB(unsigned char* dst, const uint16_t* base, int tid) const {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dma16(base + offB[j], dst + (8 * j + w) * 1024);
+  }
+};
+
+template <int T_>
+__device__ __forceinline__ u32x4_t fragA(const unsigned char* s, int row, int kstep, int hh) {   // [32][T] image
+  // slot (2 kstep + hh) ^ (row & 15) == (2 kstep) ^ (hh ^ (row & 15)): one xor per fragment on a per-lane constant
+  return *(const u32x4_t*)(s + row * (2 * T_) + (((2 * kstep) ^ (hh ^ (row & 15))) << 4));
+}
+__device__ __forceinline__ u32x4_t fragB(const unsigned char* s, int row, int u, int hh) {       // [T][32] image
+  const int e = row * 4 + 2 * u + hh;
+  const int p = (e & ~15) | ((e & 15) ^ ((e >> 4) & 15));
+  return *(const u32x4_t*)(s + p * 16);
+}
+
+// stage the [T][256] slice of an activation (rows t, columns d0..d0+255 of a [T][D] matrix) and return this wave's B
+// fragments (column 32*wid + lane%32, k = t)
+template <typename L, int T_>
+__device__ __forceinline__ void load_bfrags(u32x4_t (&f)[T_ / 16], unsigned char* smem, const uint16_t* act, int D, int d0,
+                                            const uint16_t* zero, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+  TransDma<256, 8> sx;
+  sx.init(act, D, d0, D, tid);
+#pragma unroll
+  for (int kt = 0; kt < T_ / 64; ++kt) sx.issue(smem + kt * 32768, kt * 64, T_, zero, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < T_ / 64; ++kt)
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) f[kt * 4 + sub] = frag_trans<256>(smem + kt * 32768, 32 * wid + (lane & 31), sub, lane);
+  __syncthreads();
+}
+
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+  // a[lanes 32..63] <-> b[lanes 0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+
+template <typename L, int T_>
+__global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ w1,
+                                                            const float* __restrict__ b1, const uint16_t* __restrict__ w2,
+                                                            const float* __restrict__ b2, const float* __restrict__ res,
+                                                            float* __restrict__ y, int D, int O, const uint16_t* zero) {
+  constexpr int NK1 = T_ / 16;                 // k-steps of GEMM-1
+  constexpr int NTB = T_ / 32;                 // 32-row output blocks of GEMM-2
+  constexpr int HALF = 64 * T_;                // bytes of one [32][T] / [T][32] chunk image
+  constexpr int STAGE = 2 * HALF;
+  constexpr int PPC = 2 * ChunkDma<T_>::NP;    // DMA pieces per thread per chunk
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // ring (>= xn staging) | b1 (O floats)
+  constexpr int RING = (TM_NST * STAGE > (T_ / 64) * 32768) ? TM_NST * STAGE : (T_ / 64) * 32768;
+  float* b1s = (float*)(smem + RING);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, d0 = blockIdx.x * TM_DT;
+  const int64_t act0 = (int64_t)b * T_ * D;
+
+  for (int i = tid; i < O; i += 512) b1s[i] = b1[i];
+  u32x4_t xf[NK1];
+  load_bfrags<L, T_>(xf, smem, xn + act0, D, d0, zero, tid);
+
+  ChunkDma<T_> dm;
+  dm.init(tid, T_, O);
+  const int NC = O / TM_OC;
+  auto issue = [&](int c) {
+    unsigned char* st = smem + (c % TM_NST) * STAGE;
+    dm.issueA(st, w1 + (int64_t)c * TM_OC * T_, tid);
+    dm.issueB(st + HALF, w2 + c * TM_OC, tid);
+  };
+#pragma unroll
+  for (int c = 0; c < TM_NST - 1; ++c)
+    if (c < NC) issue(c);
+
+  f32x16_t acc2[NTB];
+#pragma unroll
+  for (int t = 0; t < NTB; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[t][i] = 0.0f;
+
+  for (int c = 0; c < NC; ++c) {
+    // chunk c has landed when at most the pieces of the (up to two) later chunks are still in flight
+    if (c + 2 < NC)
+      wait_vm<2 * PPC>();
+    else if (c + 1 < NC)
+      wait_vm<PPC>();
+    else
+      wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (c + TM_NST - 1 < NC) issue(c + TM_NST - 1);      // into the stage everyone finished reading before this barrier
+    const unsigned char* s1 = smem + (c % TM_NST) * STAGE;
+    const unsigned char* s2 = s1 + HALF;
+    f32x16_t a1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a1[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NK1; ++s) mma_lo<L>(a1, fragA<T_>(s1, l31, s, hh), xf[s]);
+    // bias + exact-erf GELU in registers; register r of the block is hidden row 8 (r / 4) + 4 hh + r % 4
+    uint32_t P[4][2];
+    const float* bc = b1s + c * TM_OC + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4_t bb = *(const f32x4_t*)(bc + 8 * m);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x2_t g = act_gelu_fast2(f32x2_t{a1[4 * m + 2 * q] + bb[2 * q], a1[4 * m + 2 * q + 1] + bb[2 * q + 1]});
+        P[m][q] = lo_pack2<L>(g[0], g[1]);
+      }
+    }
+    // make each lane's 8 rows per k-step consecutive: half 0 keeps rows 0-3 and receives 4-7, half 1 gets 8-11 and keeps 12-15
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      swap_halves(P[0][q], P[1][q]);
+      swap_halves(P[2][q], P[3][q]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const u32x4_t hb = {P[2 * u][0], P[2 * u][1], P[2 * u + 1][0], P[2 * u + 1][1]};
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) mma_lo<L>(acc2[t], fragB(s2, 32 * t + l31, u, hh), hb);
+    }
+  }
+
+  // epilogue: [T/2 rows][256 cols] fp32 through LDS per half, then whole 1 KiB rows: y = acc + b2[t] + res
+  constexpr int RH = T_ / 2;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    __syncthreads();
+#pragma unroll
+    for (int tb = 0; tb < NTB / 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tl = 32 * tb + 8 * (r >> 2) + 4 * hh + (r & 3);
+        *(float*)(smem + tl * 1024 + (32 * wid + l31) * 4) = acc2[hf * (NTB / 2) + tb][r];
+      }
+    __syncthreads();
+    const int d = d0 + 4 * lane;
+    if (d < D) {
+#pragma unroll 4
+      for (int i = 0; i < RH / 8; ++i) {
+        const int tl = wid + 8 * i, t = hf * RH + tl;
+        f32x4_t v = *(const f32x4_t*)(smem + tl * 1024 + lane * 16);
+        const int64_t off = act0 + (int64_t)t * D + d;
+        const f32x4_t r = *(const f32x4_t*)(res + off);
+        const float bt = b2[t];
+        v += r + bt;
+        *(f32x4_t*)(y + off) = v;
+      }
+    }
+  }
+}
+
+// Backward, hidden part: recompute pre = W1 xn + b1 and g = W2^T dy chunk by chunk; write h = gelu(pre) and
+// dh = g * gelu'(pre) as [B][O][D] (16-bit) for the weight-gradient GEMMs and the dx GEMM.
+template <typename L, int T_>
+__global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ dy,
+                                                                   const uint16_t* __restrict__ w1, const float* __restrict__ b1,
+                                                                   const uint16_t* __restrict__ w2t, uint16_t* __restrict__ hout,
+                                                                   uint16_t* __restrict__ dhout, int D, int O,
+                                                                   const uint16_t* zero) {
+  constexpr int NK1 = T_ / 16;
+  constexpr int HALF = 64 * T_;
+  constexpr int STAGE = 2 * HALF;
+  constexpr int NST = 3;                       // ring depth here: 3 stages + 2 output staging buffers fill the LDS
+  constexpr int PPC = 2 * ChunkDma<T_>::NP;
+  constexpr int OUTB = 2 * TM_OC * TM_DT * 2;  // h and dh tiles of one chunk: 2 x [32][256] 16-bit = 32 KiB
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int RING = NST * STAGE;            // the fragment staging of the prologue ((T/64) x 32 KiB) may run into outb[0]
+  unsigned char* outb = smem + RING;           // [2][OUTB]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, d0 = blockIdx.x * TM_DT;
+  const int64_t act0 = (int64_t)b * T_ * D;
+
+  u32x4_t xf[NK1], yf[NK1];
+  load_bfrags<L, T_>(xf, smem, xn + act0, D, d0, zero, tid);
+  load_bfrags<L, T_>(yf, smem, dy + act0, D, d0, zero, tid);
+
+  ChunkDma<T_> dm;
+  dm.init(tid, T_, T_);
+  const int NC = O / TM_OC;
+  auto issue = [&](int c) {
+    unsigned char* st = smem + (c % NST) * STAGE;
+    dm.issueA(st, w1 + (int64_t)c * TM_OC * T_, tid);
+    dm.issueA(st + HALF, w2t + (int64_t)c * TM_OC * T_, tid);
+  };
+#pragma unroll
+  for (int c = 0; c < NST - 1; ++c)
+    if (c < NC) issue(c);
+
+  const int64_t out0 = (int64_t)b * O * D;
+  auto flush = [&](int c) {        // coalesced store of chunk c's staged tiles: 64 rows of 512 B, 16 B per lane
+    const unsigned char* ob = outb + (c & 1) * OUTB;
+    const int d = d0 + 8 * (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + 2 * wid + (lane >> 5);            // 0..31: h rows, 32..63: dh rows
+      const u32x4_t v = *(const u32x4_t*)(ob + row * 512 + (lane & 31) * 16);
+      if (d < D) {
+        uint16_t* dst = (row < 32 ? hout : dhout) + out0 + (int64_t)(c * TM_OC + (row & 31)) * D + d;
+        *(u32x4_t*)dst = v;
+      }
+    }
+  };
+
+  for (int c = 0; c < NC; ++c) {
+    // vmcnt retires in issue order and counts the flush stores too.  Issued after chunk c's pieces: the flush of iteration
+    // c-2 (4 stores, c >= 3), chunk c+1 (PPC pieces), the flush of iteration c-1 (4 stores, c >= 2).
+    const bool more = c + 1 < NC;
+    if (c >= 3) {
+      if (more) wait_vm<PPC + 8>(); else wait_vm<8>();
+    } else if (c == 2) {
+      if (more) wait_vm<PPC + 4>(); else wait_vm<4>();
+    } else {
+      if (more) wait_vm<PPC>(); else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (c + NST - 1 < NC) issue(c + NST - 1);
+    if (c > 0) flush(c - 1);                   // staged by everyone before this barrier
+    const unsigned char* s1 = smem + (c % NST) * STAGE;
+    const unsigned char* s2 = s1 + HALF;
+    f32x16_t a1, a2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a1[i] = a2[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NK1; ++s) {
+      mma_lo<L>(a1, fragA<T_>(s1, l31, s, hh), xf[s]);
+      mma_lo<L>(a2, fragA<T_>(s2, l31, s, hh), yf[s]);
+    }
+    unsigned char* ob = outb + (c & 1) * OUTB;
+    // the chunk's 32 biases come through SCALAR loads (wave-uniform addresses): an ordinary vector load here would make
+    // hipcc drain the LDS-DMA ring with vmcnt(0) at its first use
+    const const_f32p bc = (const_f32p)(b1 + __builtin_amdgcn_readfirstlane(c) * TM_OC);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ol = 8 * (r >> 2) + 4 * hh + (r & 3);
+      const float blo = bc[8 * (r >> 2) + (r & 3)], bhi = bc[8 * (r >> 2) + 4 + (r & 3)];
+      const float pre = a1[r] + (hh ? bhi : blo);
+      float cdf, e;
+      gelu_parts_fast(pre, cdf, e);
+      const float hv = pre * cdf;
+      const float dv = a2[r] * (cdf + pre * 0.39894228040143267794f * e);
+      const uint32_t pk = lo_pack2<L>(hv, dv);
+      *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk & 0xffffu);
+      *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk >> 16);
+    }
+  }
+  __syncthreads();
+  flush(NC - 1);
+}
+
+const uint16_t* tm_zero_page() {
+  static uint16_t* page[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!page[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    page[dev] = (uint16_t*)p;
+  }
+  return page[dev];
+}
+
+template <typename L, int T_>
+int launch_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* res, float* y,
+               int B, int D, int O, hipStream_t st, const uint16_t* zero) {
+  constexpr int STAGE = 128 * T_;
+  constexpr int RING = (TM_NST * STAGE > (T_ / 64) * 32768) ? TM_NST * STAGE : (T_ / 64) * 32768;
+  const int lds = RING + O * (int)sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)tokmix_fwd_kernel<L, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    attr = true;
+  }
+  hipLaunchKernelGGL((tokmix_fwd_kernel<L, T_>), dim3(ceil_div(D, TM_DT), B), dim3(512), lds, st, (const uint16_t*)xn,
+                     (const uint16_t*)w1, b1, (const uint16_t*)w2, b2, res, y, D, O, zero);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename L, int T_>
+int launch_bwd(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t, void* h, void* dh, int B,
+               int D, int O, hipStream_t st, const uint16_t* zero) {
+  constexpr int lds_main = 3 * 128 * T_ + 2 * (2 * TM_OC * TM_DT * 2);
+  constexpr int lds_stage = (T_ / 64) * 32768;
+  constexpr int lds = lds_main > lds_stage ? lds_main : lds_stage;
+  static_assert(lds <= 163840, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)tokmix_bwd_hidden_kernel<L, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    attr = true;
+  }
+  hipLaunchKernelGGL((tokmix_bwd_hidden_kernel<L, T_>), dim3(ceil_div(D, TM_DT), B), dim3(512), lds, st, (const uint16_t*)xn,
+                     (const uint16_t*)dy, (const uint16_t*)w1, b1, (const uint16_t*)w2t, (uint16_t*)h, (uint16_t*)dh, D, O, zero);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+int tm_check(const char* who, int dtype, int B, int T, int D, int O) {
+  FFVC_CHECK_ARG(dtype == FFVC_BF16 || dtype == FFVC_F16, "%s: 16-bit storage only (dtype %d)", who, dtype);
+  FFVC_CHECK_ARG(T == 128 || T == 256, "%s: T=%d unsupported (128 | 256; use the unfused GEMM path)", who, T);
+  FFVC_CHECK_ARG(B > 0 && B <= 65535 && D > 0 && D % 32 == 0 && O > 0 && O % TM_OC == 0 && O * 4 <= 16384,
+                 "%s: bad dims B=%d D=%d O=%d (D %% 32, O %% 32, O <= 4096)", who, B, D, O);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ffvc_tokmix_supported(int dtype, int T, int D, int O) {
+  return (dtype == FFVC_BF16 || dtype == FFVC_F16) && (T == 128 || T == 256) && D > 0 && D % 32 == 0 && O > 0 &&
+         O % TM_OC == 0 && O <= 4096;
+}
+
+extern "C" int ffvc_tokmix_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2,
+                               const float* residual, float* y, int dtype, int B, int T, int D, int O, void* stream) {
+  FFVC_CHECK_ARG(xn && w1 && b1 && w2 && b2 && residual && y, "ffvc_tokmix_fwd: null pointer");
+  if (int e = tm_check("ffvc_tokmix_fwd", dtype, B, T, D, O)) return e;
+  FFVC_CHECK_ARG(((uintptr_t)xn % 16) == 0 && ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)w2 % 16) == 0 &&
+                     ((uintptr_t)residual % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)b1 % 16) == 0,
+                 "ffvc_tokmix_fwd: pointers must be 16-byte aligned");
+  const uint16_t* zero = tm_zero_page();
+  FFVC_CHECK_ARG(zero != nullptr, "ffvc_tokmix_fwd: zero page allocation failed");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FFVC_F16)
+    return T == 256 ? launch_fwd<f16_t, 256>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero)
+                    : launch_fwd<f16_t, 128>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero);
+  return T == 256 ? launch_fwd<uint16_t, 256>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero)
+                  : launch_fwd<uint16_t, 128>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero);
+}
+
+extern "C" int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t,
+                                      void* h, void* dh, int dtype, int B, int T, int D, int O, void* stream) {
+  FFVC_CHECK_ARG(xn && dy && w1 && b1 && w2t && h && dh, "ffvc_tokmix_bwd_hidden: null pointer");
+  if (int e = tm_check("ffvc_tokmix_bwd_hidden", dtype, B, T, D, O)) return e;
+  FFVC_CHECK_ARG(((uintptr_t)xn % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)w1 % 16) == 0 &&
+                     ((uintptr_t)w2t % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)dh % 16) == 0,
+                 "ffvc_tokmix_bwd_hidden: pointers must be 16-byte aligned");
+  const uint16_t* zero = tm_zero_page();
+  FFVC_CHECK_ARG(zero != nullptr, "ffvc_tokmix_bwd_hidden: zero page allocation failed");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FFVC_F16)
+    return T == 256 ? launch_bwd<f16_t, 256>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero)
+                    : launch_bwd<f16_t, 128>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero);
+  return T == 256 ? launch_bwd<uint16_t, 256>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero)
+                  : launch_bwd<uint16_t, 128>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero);
+}

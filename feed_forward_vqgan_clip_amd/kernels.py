@@ -646,6 +646,42 @@ def attn_small_bwd(qkv, do, heads, scale):
     return dqkv
 
 
+def tokmix_supported(dtype, T, D, O):
+    """Shapes / dtypes the fused token-mixing kernels cover (FFVC_TOKMIX=0 switches them off for A/B runs)."""
+    if dtype not in LOWP or os.environ.get("FFVC_TOKMIX", "1") == "0":
+        return False
+    return bool(_lib.load().ffvc_tokmix_supported(dtype_code(dtype), T, D, O))
+
+
+def tokmix_fwd(xn, w1, b1, w2, b2, residual):
+    """y[b] = W2 @ gelu(W1 @ xn[b] + b1) + b2 + residual[b]; xn (B,T,D) 16-bit, residual / y fp32."""
+    _req(xn.dtype, xn, w1, w2)
+    _req_f32(b1, b2, residual)
+    B, T, D = xn.shape
+    O = w1.shape[0]
+    if tuple(w1.shape) != (O, T) or tuple(w2.shape) != (T, O) or tuple(residual.shape) != (B, T, D):
+        raise ValueError("tokmix_fwd: shape mismatch")
+    y = torch.empty(B, T, D, dtype=torch.float32, device=xn.device)
+    _call("ffvc_tokmix_fwd", xn.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), residual.data_ptr(),
+          y.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
+    return y
+
+
+def tokmix_bwd_hidden(xn, dy, w1, b1, w2t):
+    """-> (h, dh) as (B,O,D) in xn's dtype: h = gelu(W1 xn + b1), dh = (W2^T dy) * gelu'(W1 xn + b1); w2t = W2^T (O,T)."""
+    _req(xn.dtype, xn, dy, w1, w2t)
+    _req_f32(b1)
+    B, T, D = xn.shape
+    O = w1.shape[0]
+    if tuple(w1.shape) != (O, T) or tuple(w2t.shape) != (O, T) or tuple(dy.shape) != (B, T, D):
+        raise ValueError("tokmix_bwd_hidden: shape mismatch")
+    h = torch.empty(B, O, D, dtype=xn.dtype, device=xn.device)
+    dh = torch.empty_like(h)
+    _call("ffvc_tokmix_bwd_hidden", xn.data_ptr(), dy.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), h.data_ptr(),
+          dh.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
+    return h, dh
+
+
 def set_option(name, value):
     """Kernel-selection override (tests / A-B runs): see ffvc_set_option in include/ffvc.h."""
     _call("ffvc_set_option", name.encode(), int(value))

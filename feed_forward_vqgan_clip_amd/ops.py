@@ -120,7 +120,11 @@ def _grad_buf(p):
     return p.grad
 
 
-def _split_k(n_out, k_out, red, bk):
+def _split_k(n_out, k_out, red, bk, big_tiles=False):
+    if big_tiles and n_out >= 1024 and k_out >= 1024 and n_out % 256 == 0 and k_out % 256 == 0 and red >= 8192:
+        t256 = (n_out // 256) * (k_out // 256)          # 256x256 LDS-DMA tiles: one workgroup per CU (gemm2.hip, TT mode)
+        if t256 < 256:
+            return max(1, min(256 // t256, red // (32 * bk)))
     tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
     if tiles >= 512:
         return 1
@@ -132,7 +136,7 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None):
     wg = _grad_buf(W.weight)
     bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad) else None
     bk = 64 if dy2d.dtype in K.LOWP else 32
-    sk = _split_k(W.N, W.K, rows, bk)
+    sk = _split_k(W.N, W.K, rows, bk, big_tiles=dy2d.dtype in K.LOWP and (ldy or W.N) == W.N)
     with _on_side(dy2d, x2d):
         K.gemm_splitk_accumulate(dy2d, x2d, wg, W.N, W.K, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
                                  w_mode=K.OP_TRANS)
@@ -274,6 +278,16 @@ class _TokenMLPFn(Function):
         xn = _contig(xn)
         B, T, D = xn.shape
         O = W1.N
+        ctx.W1, ctx.W2 = W1, W2
+        ctx.train = w1 is not None and w1.requires_grad
+        ctx.has_res = residual is not None
+        ctx.dims = (B, T, D, O)
+        ctx.fused = (residual is not None and residual.dtype == torch.float32 and (out_dtype or cdt) == torch.float32 and
+                     W1.bias is not None and W2.bias is not None and K.tokmix_supported(cdt, T, D, O))
+        if ctx.fused:
+            # one launch, the hidden activation stays on chip; backward recomputes it (nothing saved but xn)
+            ctx.save_for_backward(xn, None, None)
+            return K.tokmix_fwd(xn, W1.sh, W1.bias, W2.sh, W2.bias, _contig(residual))
         h_pre = torch.empty(B, O, D, dtype=cdt, device=xn.device)
         h = torch.empty_like(h_pre)
         K.gemm(W1.sh, xn, h, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, bias=W1.bias, act=ACT_GELU, aux=h_pre, ldaux=D,
@@ -281,11 +295,7 @@ class _TokenMLPFn(Function):
         y = torch.empty(B, T, D, dtype=out_dtype or cdt, device=xn.device)
         K.gemm(W2.sh, h, y, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, bias=W2.bias, residual=residual,
                flags=K.F_BIAS_ALONG_M, batch=B, wb=(O * D, 0), yb=(T * D, 0), rb=(T * D, 0))
-        ctx.W1, ctx.W2 = W1, W2
-        ctx.train = w1 is not None and w1.requires_grad
-        ctx.has_res = residual is not None
         ctx.save_for_backward(xn if ctx.train else None, h_pre, h if ctx.train else None)
-        ctx.dims = (B, T, D, O)
         return y
 
     @staticmethod
@@ -296,10 +306,13 @@ class _TokenMLPFn(Function):
         xn, h_pre, h = ctx.saved_tensors
         dy = _contig(dy)
         dyt = _as(dy, cdt)
-        # dh_pre[b] = (W2^T @ dy[b]) * gelu'(h_pre[b])
-        dh = torch.empty_like(h_pre)
-        K.gemm(W2.sht, dyt, dh, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, aux=h_pre, ldaux=D, act=ACT_GELU,
-               flags=K.F_MUL_ACT_GRAD, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
+        if ctx.fused:
+            h, dh = K.tokmix_bwd_hidden(xn, dyt, W1.sh, W1.bias, W2.sht)
+        else:
+            # dh_pre[b] = (W2^T @ dy[b]) * gelu'(h_pre[b])
+            dh = torch.empty_like(h_pre)
+            K.gemm(W2.sht, dyt, dh, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, aux=h_pre, ldaux=D, act=ACT_GELU,
+                   flags=K.F_MUL_ACT_GRAD, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
         if ctx.train:
             bk = 64 if cdt in K.LOWP else 32
             seg_ok = D % bk == 0

@@ -299,6 +299,18 @@ int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nslab, int acc
 int ffvc_sumsq(const float* x, float* out, int64_t n, void* stream);            /* out[0] += sum x^2 */
 int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream); /* y = a*x + b*y */
 
+/* Fused token-mixing MLP of the MLP-Mixer (mlp_mixer_pytorch.py:28,34 inside PreNormResidual :7-14), one launch:
+ *   y[b] = W2 @ gelu(W1 @ xn[b] + b1) + b2 + residual[b]     xn: [B,T,D] 16-bit, W1: [O,T], W2: [T,O] (K-major 16-bit
+ *   shadows), b1: [O], b2: [T] fp32, residual / y: [B,T,D] fp32.  The hidden activation never leaves the CU.
+ * ffvc_tokmix_bwd_hidden recomputes it for the backward pass: h = gelu(W1 xn + b1), dh = (W2^T dy) * gelu'(W1 xn + b1),
+ *   written once as [B,O,D] 16-bit (w2t = W2^T as [O,T]); dx = W1^T dh and the weight gradients stay ffvc_gemm calls.
+ * Supported: dtype FFVC_BF16 | FFVC_F16, T in {128, 256}, D % 32 == 0, O % 32 == 0, O <= 4096 (ffvc_tokmix_supported). */
+int ffvc_tokmix_supported(int dtype, int T, int D, int O);
+int ffvc_tokmix_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* residual,
+                    float* y, int dtype, int B, int T, int D, int O, void* stream);
+int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t, void* h,
+                           void* dh, int dtype, int B, int T, int D, int O, void* stream);
+
 /* Kernel-selection overrides for tests / A-B measurements (defaults come from FFVC_GEMM2_BM / FFVC_CONV_ROW):
  *   "gemm2_tile": 0 = register-staged kernel only, 1 = heuristic, 128 | 256 | 512 = force the LDS-DMA tile
  *                 (128x128 | 256x128 | 256x256);   "conv_row": 0 off, 1 heuristic, 2 force the haloed row-tile conv. */

@@ -346,3 +346,66 @@ def test_transpose_multi(cuda, dt):
     plan.run()
     for src, dst in pairs:
         assert torch.equal(dst, src.t().contiguous())
+
+
+# ----------------------------------------------------------------------------- fused token-mixing MLP
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,D,O", [(3, 256, 320, 1024), (2, 128, 64, 512), (2, 256, 1024, 1024), (1, 128, 288, 160)])
+def test_tokmix_fused_kernels_vs_fp64(cuda, dt, B, T, D, O):
+    """ffvc_tokmix_fwd / ffvc_tokmix_bwd_hidden (mlp_mixer_pytorch.py:28,34) vs fp64 math on the same 16-bit operands,
+    incl. a D that is not a multiple of the 256-column workgroup tile and a hidden size that is not a multiple of 64."""
+    import torch.nn.functional as F
+    tol = 1e-2 if dt == torch.bfloat16 else 1.3e-3
+    xn = _mk((B, T, D), dt, cuda, 1)
+    w1, w2 = _mk((O, T), dt, cuda, 2, T ** -0.5), _mk((T, O), dt, cuda, 3, O ** -0.5)
+    b1, b2 = _mk((O,), torch.float32, cuda, 4, 0.3), _mk((T,), torch.float32, cuda, 5, 0.3)
+    res = _mk((B, T, D), torch.float32, cuda, 6)
+    assert K.tokmix_supported(dt, T, D, O)
+    y = K.tokmix_fwd(xn, w1, b1, w2, b2, res)
+    pre = w1.double() @ xn.double() + b1.double()[None, :, None]
+    h = F.gelu(pre)
+    hr = h.to(dt).double()                                   # the kernel rounds the hidden activation to the storage dtype
+    ref = w2.double() @ hr + b2.double()[None, :, None] + res.double()
+    assert _rel(y, ref) < tol / 8                             # fp32 output: only the boundary flips of the h rounding remain
+    dy = _mk((B, T, D), dt, cuda, 7)
+    hk, dhk = K.tokmix_bwd_hidden(xn, dy, w1, b1, w2.t().contiguous())
+    p = pre.clone().requires_grad_(True)
+    F.gelu(p).sum().backward()
+    dref = (w2.double().t() @ dy.double()) * p.grad
+    assert _rel(hk, h) < tol and _rel(dhk, dref) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_tokmix_fused_autograd_matches_unfused(cuda, dt):
+    """ops.token_mlp with the fused kernels (forward recompute in backward) vs the two-GEMM path: output, dx and every
+    parameter gradient."""
+    import os
+    from feed_forward_vqgan_clip_amd import ops
+    from feed_forward_vqgan_clip_amd.mappers import Mixer
+    torch.manual_seed(3)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["FFVC_TOKMIX"] = mode
+        try:
+            torch.manual_seed(3)
+            net = Mixer(input_dim=32, image_size=16, channels=16, patch_size=1, dim=64, depth=1).cuda().prepare(dt)
+            (n1, t1, t2, n2, c1, c2) = net._blocks[0]
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn(3, 256, 64, generator=g).cuda().requires_grad_(True)
+            hn, hid = ops.layernorm_fork(x, n1.weight, n1.bias, dt)
+            y = ops.token_mlp(hn, t1, t2, residual=hid, out_dtype=torch.float32)
+            gw = torch.randn(3, 256, 64, generator=g).cuda()
+            net._ffvc_arena.zero_grad()
+            (y * gw).sum().backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            outs[mode] = (y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()
+                                                               if "mixer.2.0" in k})
+        finally:
+            os.environ.pop("FFVC_TOKMIX")
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    (y1, dx1, g1), (y0, dx0, g0) = outs["1"], outs["0"]
+    assert _rel(y1, y0) < tol / 4 and _rel(dx1, dx0) < tol
+    assert len(g1) == 6
+    for k in g1:
+        assert _rel(g1[k], g0[k]) < tol, k

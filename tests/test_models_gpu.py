@@ -169,7 +169,7 @@ def _tiny_step(cdt, seed=11):
 # comparison is made twice: free-running (codes may differ: loose bound, agreement rate asserted) and with the
 # reference's codes handed to the decoder (`force_idx`), where the north-star tolerance on the loss applies.
 LOWP_TOL = {BF16: dict(z=3e-2, agree=0.97, xr=3e-2, loss_same_codes=2e-3, loss_free=2e-2, grad=1.5e-1),
-            F16: dict(z=4e-3, agree=0.99, xr=4e-3, loss_same_codes=1e-4, loss_free=5e-3, grad=5e-2)}
+            F16: dict(z=4e-3, agree=0.99, xr=4e-3, loss_same_codes=1e-4, loss_free=5e-3, grad=8e-2)}   # worst: bias gradients of the tiny model
 
 
 @pytest.mark.parametrize("cdt", [F32, BF16, F16])
