@@ -256,6 +256,9 @@ def main():
     ap.add_argument("--loss-scale", type=float, default=4096.0, help="static loss scale of the f16 backward pass")
     ap.add_argument("--parity-batch", type=int, default=4, help="batch of the oracle-vs-HIP parity leg")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch prompts PER GPU (the reference's batch_size semantics, main.py:647,678); strong: "
+                         "--batch is the GLOBAL batch, split evenly over the ranks")
     ap.add_argument("--no-prefetch-text", dest="prefetch_text", action="store_false",
                     help="encode each step's prompts inside the step instead of one step ahead on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -281,6 +284,10 @@ def main():
     args.keep_cpu_weights = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     cfg, stepper, sds = build(args, device)
 
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: global batch {args.batch} is not divisible by {world} ranks")
+        args.batch //= world
     B = args.batch
     toks = fmain.synthetic_tokens(B * (args.steps + args.warmup + 1), seed=1234 + rank).to(device)
 
@@ -313,7 +320,7 @@ def main():
     out = {
         "metric": "train-step images/sec (whole node), ViT-B/32 + VQGAN-f16 256x256, bs=64, 1/2/4/8 GPU",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic seeded token batches, random-init weights (no network)",
         "precision_recipe": {"bf16": "bf16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
                                      "fp32 text tower, VQ distances and loss",
@@ -325,7 +332,8 @@ def main():
                                f" mapper + VQGAN f16-16384 decoder {16 * args.vq_image_size}x{16 * args.vq_image_size} + CLIP "
                                f"ViT-B/32, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire},
+                   "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire,
+                   "dp": hvd.describe()},
         "final_loss": float(loss.item()),
     }
     tf_step = step_tflop(B, args.cutn) if (args.model_type, args.depth, args.dim, args.vq_image_size) == \

@@ -402,10 +402,20 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       const bool more = (kt + 1 < nk) && FFVC_EXP_MODE != 1;
       const int kn = k_begin + (kt + 1) * BK;
       if (DMA_SPREAD) {
+#ifdef FFVC_DMA_STAGGER
+        // experiment: the two waves that share a SIMD (w and w + NW/2) issue their pieces in different sub-steps, so one
+        // of them always has MFMAs queued while the other is stuck in LDS-DMA issue
+        const int s0 = (NW == 8 && wid >= 4) ? 2 : 0;
+        compute(cur, cur + XTILE, [&](int sub) {
+          if (more && sub == s0) sx.issue(nxt, kn, k_end, zero, tid);
+          if (more && sub == s0 + 1) sw.issue(nxt + XTILE, kn, k_end, zero, tid);
+        });
+#else
         compute(cur, cur + XTILE, [&](int sub) {
           if (more && sub == 0) sx.issue(nxt, kn, k_end, zero, tid);
           if (more && sub == 1) sw.issue(nxt + XTILE, kn, k_end, zero, tid);
         });
+#endif
       } else {
         if (more) {
           sx.issue(nxt, kn, k_end, zero, tid);

@@ -48,6 +48,15 @@ def init(backend=None):
     _STATE["init"] = True
 
 
+def describe():
+    """What the data-parallel layer actually runs on (goes into the bench line): backend, ranks the process group
+    sees, and every NCCL_* / RCCL_* / HSA_* knob of the environment (channel / link configuration of RCCL over xGMI)."""
+    env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "FFVC_DP", "FFVC_SHARE"))}
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "ranks": 1, "env": env}
+    return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env}
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _STATE.get("force", False))
 
@@ -187,7 +196,15 @@ class DistributedOptimizer:
 
     # -- gradient-ready plumbing ------------------------------------------------
     def _param_ready(self, p):
-        if not is_distributed() or id(p) in self._seen:
+        if not is_distributed():
+            return
+        if id(p) in self._seen:
+            # The fused wgrad / LayerNorm paths report a parameter once per USE.  A second report after the bucket went
+            # out means a weight shared between two layers: its later contribution would be written into a slice that is
+            # already being all-reduced (replicas stay identical, the gradient is silently wrong) -> refuse.
+            if any(b in self._handles for b in self._bucket_of[id(p)]):
+                raise RuntimeError("DistributedOptimizer: a parameter received a second gradient contribution after its "
+                                   "bucket was launched (weight sharing is not supported by the fused gradient path)")
             return
         self._seen.add(id(p))
         for b in self._bucket_of[id(p)]:

@@ -300,18 +300,18 @@ class _XWrapper(nn.Module):
 class XTransformer(_MapperBase):
     def __init__(self, input_dim, image_size, channels, dim, depth, heads, initial_proj=True, add_input=True):
         super().__init__()
-        if not initial_proj:
-            raise NotImplementedError("XTransformer: only initial_proj=True (the configured default, main.py:497)")
         self.input_dim, self.image_size, self.channels, self.dim, self.depth, self.heads = \
             input_dim, image_size, channels, dim, depth, heads
-        self.add_input = add_input
-        self.transformer = _XWrapper(dim, channels, image_size * image_size + (0 if add_input else 1), dim, depth, heads)
-        self.proj = nn.Linear(input_dim, image_size * image_size * dim)
+        self.add_input, self.initial_proj = add_input, initial_proj
+        self.transformer = _XWrapper(dim if initial_proj else input_dim, channels,
+                                     image_size * image_size + (0 if add_input else 1), dim, depth, heads)   # transformer.py:11-20
+        if initial_proj:
+            self.proj = nn.Linear(input_dim, image_size * image_size * dim)                                   # :22-23
 
     def _build_packs(self, arena):
         mk = arena.make_weights
         t = self.transformer
-        self._w_proj = mk(self.proj.weight, self.proj.bias)
+        self._w_proj = mk(self.proj.weight, self.proj.bias) if self.initial_proj else None
         self._w_in = mk(t.project_in.weight, t.project_in.bias)
         self._w_outp = mk(t.project_out.weight, t.project_out.bias)
         self._xl = []
@@ -328,9 +328,22 @@ class XTransformer(_MapperBase):
         B, S, dim = x.shape[0], self.image_size, self.dim
         n = S * S
         t = self.transformer
-        h = ops.linear(ops.cast(x.float(), cdt), self._w_proj).view(B, n, dim)              # transformer.py:30-31
-        h = ops.linear(h, self._w_in, out_dtype=f32)                                        # project_in
-        h = h + t.pos_emb.emb.weight[:n] * (dim ** -0.5)                                    # scaled abs. pos. emb.
+        xc = ops.cast(x.float(), cdt)
+        if self.initial_proj:
+            h = ops.linear(xc, self._w_proj).view(B, n, dim)                                # transformer.py:30-31
+            h = ops.linear(h, self._w_in, out_dtype=f32)                                    # project_in
+            L = n
+        elif self.add_input:
+            # every position carries the same input row (:34-36): project it once, broadcast over the n positions
+            h = ops.linear(xc, self._w_in, out_dtype=f32).unsqueeze(1).expand(B, n, dim)
+            L = n
+        else:
+            # token 0 = the input, n zero tokens behind it (:38-40); the zero rows go through project_in like any other
+            # row (one use of the weight pack per step keeps the fused wgrad / all-reduce bookkeeping simple)
+            xin = torch.cat((xc.view(B, 1, -1), torch.zeros(B, n, xc.shape[1], dtype=cdt, device=xc.device)), dim=1)
+            h = ops.linear(xin, self._w_in, out_dtype=f32)
+            L = n + 1
+        h = (h + t.pos_emb.emb.weight[:L] * (dim ** -0.5)).contiguous()                     # scaled abs. pos. emb.
         for (n1, Wq, Wk, Wv, Wo, n2, W1, W2) in self._xl:
             hn, hid = ops.layernorm_fork(h, n1.weight, n1.bias, cdt)                        # pre-norm
             o = ops.attention(ops.qkv3(hn, Wq, Wk, Wv), self.heads, 64 ** -0.5, True)       # causal, dim_head 64
@@ -339,6 +352,8 @@ class XTransformer(_MapperBase):
             h = ops.mlp(hn, W1, W2, ACT_GELU, residual=hid, out_dtype=f32)
         hn = ops.layernorm(h, t.norm.weight, t.norm.bias, cdt)
         z = ops.linear(hn, self._w_outp, out_dtype=f32)
+        if L != n:
+            z = z[:, 1:].contiguous()                                                       # drop the input token (:42-43)
         return z.view(B, S, S, self.channels).permute(0, 3, 1, 2)                           # transformer.py:44-45
 
 

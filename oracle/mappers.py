@@ -99,14 +99,21 @@ def simple_vitgan_forward(sd, noise, *, size, dim, blocks, num_heads, out_channe
 # x-transformer mapper — transformer.py:5-46 over x-transformers==0.19.1
 # ContinuousTransformerWrapper(Decoder).  PARITY UNPINNED: x_transformers is not in
 # /root/reference nor installed; restated from the published 0.19.1 source
-# (SURVEY.md App. A.3).  Supports initial_proj=True (the configured default, main.py:497).
+# (SURVEY.md App. A.3).  All three input modes of transformer.py:29-40 (initial_proj / add_input).
 # ---------------------------------------------------------------------------
 def xtransformer_forward(sd, x, *, image_size, channels, dim, depth, heads, dim_head=64,
-                         pos_scale=True):
+                         pos_scale=True, initial_proj=True, add_input=True):
     B, S = x.shape[0], image_size
     n = S * S
-    h = _lin(x, sd, "proj").view(B, n, dim)                   # transformer.py:30-31
+    nout = n
     t = "transformer"
+    if initial_proj:
+        h = _lin(x, sd, "proj").view(B, n, dim)               # transformer.py:30-31
+    elif add_input:
+        h = x.view(B, 1, -1).repeat(1, n, 1)                  # :34-36
+    else:
+        h = torch.cat((x.view(B, 1, -1), torch.zeros(B, n, x.shape[1], dtype=x.dtype)), dim=1)   # :38-40
+        n = n + 1
     h = _lin(h, sd, t + ".project_in")                        # wrapper: Linear(dim_in, dim) (dim_in given)
     pos = sd[t + ".pos_emb.emb.weight"][:n]
     h = h + (pos * (dim ** -0.5) if pos_scale else pos)       # AbsolutePositionalEmbedding (scaled)
@@ -130,4 +137,6 @@ def xtransformer_forward(sd, x, *, image_size, channels, dim, depth, heads, dim_
         h = _lin(y, sd, f + ".1.net.2") + r
     h = _ln(h, sd, t + ".norm")
     h = _lin(h, sd, t + ".project_out")
-    return h.view(B, S, S, channels).permute(0, 3, 1, 2)      # transformer.py:44-45
+    if n != nout:
+        h = h[:, 1:]                                          # :42-43
+    return h.reshape(B, S, S, channels).permute(0, 3, 1, 2)   # transformer.py:44-45

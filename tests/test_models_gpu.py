@@ -347,6 +347,34 @@ def test_other_mappers_match_oracle(cuda, kind, cdt):
     assert worst < {F32: 2e-3, BF16: 1.5e-1, F16: 2e-2}[cdt], f"worst param-grad rel-rms {worst}"   # 16-bit operands at dim_head 20
 
 
+@pytest.mark.parametrize("add_input", [True, False])
+def test_xtransformer_without_initial_proj_matches_oracle(cuda, add_input):
+    """transformer.py:33-43: initial_proj=False feeds the raw input row to every position (add_input) or as an extra
+    leading token that is dropped afterwards."""
+    from oracle import mappers as omap
+    torch.manual_seed(9)
+    net = XTransformer(input_dim=32, image_size=4, channels=16, dim=64, depth=2, heads=3, initial_proj=False,
+                       add_input=add_input)
+    assert not hasattr(net, "proj") and net.transformer.project_in.weight.shape == (64, 32)
+    assert net.transformer.pos_emb.emb.weight.shape[0] == 16 + (0 if add_input else 1)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda().prepare(F32)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(5, 32, generator=g)
+    y = net(x.cuda())
+    yo = omap.xtransformer_forward(sd, x, image_size=4, channels=16, dim=64, depth=2, heads=3, initial_proj=False,
+                                   add_input=add_input)
+    assert tuple(y.shape) == (5, 16, 4, 4)
+    gw = torch.randn(*yo.shape, generator=g)
+    net._ffvc_arena.zero_grad()
+    (y * gw.cuda()).sum().backward()
+    (yo * gw).sum().backward()
+    assert _relrms(y, yo.detach()) < 2e-4
+    params = dict(net.named_parameters())
+    worst = max(_relrms(params[k].grad, v.grad) for k, v in sd.items() if v.grad is not None and v.grad.abs().max() > 1e-6)
+    assert worst < 2e-3, worst
+
+
 def test_text_prefetch_matches_inline(cuda):
     """The side-stream text-tower prefetch hands the same features to the step as the inline encode."""
     cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(F32)
