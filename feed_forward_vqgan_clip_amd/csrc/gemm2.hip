@@ -251,8 +251,21 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   return 0;
 }
 
+#ifdef FFVC_G8_TIMING
+extern "C" int ffvc_debug_g8_stamps(unsigned long long* host_out) {   // debug builds only (tools/g8_timing.py)
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g8_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
+
+int g_force_gemm8 = 0;
+
 extern "C" int ffvc_set_option(const char* name, int value) {
   if (!name) return FFVC_E_BADARG;
+  if (!strcmp(name, "gemm8")) {
+    g_force_gemm8 = value;
+    return 0;
+  }
   if (!strcmp(name, "gemm2_tile")) {
     g_opt_gemm2_tile = value;
     return 0;

@@ -9,6 +9,8 @@
 
 #include "gemm_common.h"
 
+extern int g_force_gemm8;   // gemm2.hip; ffvc_set_option("gemm8", 1): every eligible launch takes the 8-phase kernel (tests)
+
 namespace {
 
 constexpr int BK = 64;
@@ -72,6 +74,20 @@ struct KMajorDma {
       dma16(ok ? (const void*)src : (const void*)zero, tile + (NW * j + w) * 1024);
     }
   }
+  // pieces J0 and J1 only (rows 8*NW*J .. of the tile): the half-tile granularity of the 8-phase kernel.  Plain operands
+  // only (no K segments, no split row map: the launcher checks), so the source is one add away from the row pointer.
+  template <int J0, int J1>
+  __device__ __forceinline__ void issue2(unsigned char* tile, int k0, int kend, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+    const bool kok = k0 + kc + EPC <= kend;
+    const uint16_t* p0 = row0p + k0 + kc;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jj ? J1 : J0;
+      const bool ok = kok && (r0 + (8 * NW) * j) < rows;
+      dma16(ok ? (const void*)(p0 + j * step) : (const void*)zero, tile + (NW * j + w) * 1024);
+    }
+  }
 };
 
 // ---- implicit im2col (3x3, pad 1, optional fused nearest 2x upsample) ------------------------------------
@@ -114,6 +130,21 @@ struct ConvDma {
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
+      const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
+      const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
+      dma16(ok ? (const void*)(base + off) : (const void*)zero, tile + (NW * j + w) * 1024);
+    }
+  }
+  template <int J0, int J1>
+  __device__ __forceinline__ void issue2(unsigned char* tile, int k0, int /*kend*/, const uint16_t* zero, int tid) {
+    const int w = tid >> 6;
+    const int tap = k0 / Cin;
+    const int ci0 = k0 - tap * Cin;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jj ? J1 : J0;
       const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
       const bool ok = rvalid[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const int64_t off = ((int64_t)(pix[j] + (iy >> ups) * Win + (ix >> ups))) * Cin + ci0 + kc[j];
@@ -205,6 +236,121 @@ struct TransDma {
       const bool ok = cvalid[j] && k < kend;
       dma16(ok ? (const void*)(colp[j] + (int64_t)k * ld) : (const void*)zero, tile + (NW * j + w) * 1024);
     }
+  }
+};
+
+// ---- buffer-resource variants (buffer_load_dwordx4 ... lds): 32-bit byte offsets against a wave-uniform descriptor instead of
+// 64-bit per-lane addresses — half the address VALU per piece — and out-of-range rows / K tails / conv halo are simply an
+// offset beyond num_records (the hardware writes zeros), so no zero page and no select on pointers.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t DMA_OOB = 0xFFFFFFF0u;
+constexpr int DMA_NUMREC = 0x7FFFFF00;            // every valid offset must stay below 2 GiB (launcher-checked)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, DMA_NUMREC, 0x00020000);
+}
+__device__ __forceinline__ void dma16b(rsrc_t rs, uint32_t voff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dma16bs(rsrc_t rs, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int ROWS, int NW>
+struct KMajorDmaB {
+  static constexpr int NP = ROWS / (8 * NW);
+  rsrc_t rs;
+  uint32_t voff[NP];        // byte offset of this thread's chunk in piece j at k = 0; DMA_OOB for rows beyond the operand
+  int kc, w;
+  // base = pointer to (first row of the tile, k = 0); rows_ = rows of the operand left from there
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int rows_, int tid) {
+    const int lane = tid & 63;
+    w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int line = 4 * w + (lane >> 4);
+    const int cp = (lane & 15) ^ (line & 15);
+    const int r0 = 2 * line + (cp >> 3);
+    kc = (cp & 7) * EPC;
+    rs = make_rsrc(base);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int r = r0 + (8 * NW) * j;
+      voff[j] = r < rows_ ? (uint32_t)(((int64_t)r * ld + kc) * 2) : DMA_OOB;
+    }
+  }
+  // k0 is wave-uniform: it travels in the instruction's scalar offset, so an interior K tile costs no VALU at all
+  __device__ __forceinline__ void issue1(unsigned char* tile, int j, int k0, int kend) {
+    if (k0 + BK <= kend) {
+      dma16bs(rs, voff[j], (uint32_t)k0 * 2u, tile + (NW * j + w) * 1024);
+    } else {                 // K tail: chunks beyond kend read as zero
+      const bool ok = k0 + kc + EPC <= kend;
+      dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? (uint32_t)k0 * 2u : 0u, tile + (NW * j + w) * 1024);
+    }
+  }
+  template <int J0, int J1>
+  __device__ __forceinline__ void issue2(unsigned char* tile, int k0, int kend) {
+    issue1(tile, J0, k0, kend);
+    issue1(tile, J1, k0, kend);
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue1(tile, j, k0, kend);
+  }
+};
+
+template <int ROWS, int NW>
+struct ConvDmaB {
+  static constexpr int NP = ROWS / (8 * NW);
+  rsrc_t rs;
+  int pixo[NP], oy[NP], ox[NP];   // (image base + channel chunk) in elements, output coordinates (-4 marks a row beyond M)
+  int H, W, Win, Cin, ups, w;
+  int tap_k0, kh, kw, ci0;        // tap decomposition of the K tile last seen (wave-uniform, recomputed when k0 changes)
+  __device__ __forceinline__ void init(const uint16_t* base, int row0, int rows, int H_, int W_, int Cin_, int ups_, int tid) {
+    const int lane = tid & 63;
+    w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    rs = make_rsrc(base);
+    H = H_;
+    W = W_;
+    Cin = Cin_;
+    ups = ups_;
+    Win = W_ >> ups_;
+    const int Hin = H_ >> ups_;
+    tap_k0 = -1;
+    kh = kw = ci0 = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = (NW * j + w) * 64 + lane;
+      const int line = p >> 4, cp = (p & 15) ^ (line & 15);
+      const int r = row0 + 2 * line + (cp >> 3);
+      const bool valid = r < rows;
+      const int rr = valid ? r : 0;
+      const int b = rr / (H * W);
+      const int rem = rr - b * (H * W);
+      oy[j] = valid ? rem / W : -4;
+      ox[j] = rem - (rem / W) * W;
+      pixo[j] = b * Hin * Win * Cin + (cp & 7) * EPC;
+    }
+  }
+  __device__ __forceinline__ void issue1(unsigned char* tile, int j, int k0, int /*kend*/) {
+    if (k0 != tap_k0) {           // scalar: once per K tile, not once per piece
+      tap_k0 = k0;
+      const int tap = k0 / Cin;
+      ci0 = k0 - tap * Cin;
+      kh = tap / 3;
+      kw = tap - 3 * kh;
+    }
+    const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const uint32_t off = (uint32_t)(pixo[j] + ((iy >> ups) * Win + (ix >> ups)) * Cin) * 2u;
+    dma16bs(rs, ok ? off : DMA_OOB, ok ? (uint32_t)ci0 * 2u : 0u, tile + (NW * j + w) * 1024);
+  }
+  template <int J0, int J1>
+  __device__ __forceinline__ void issue2(unsigned char* tile, int k0, int kend) {
+    issue1(tile, J0, k0, kend);
+    issue1(tile, J1, k0, kend);
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue1(tile, j, k0, kend);
   }
 };
 
@@ -432,6 +578,203 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
 
+// ---- 8-phase 256x256 kernel (K-major W; K-major or implicit-im2col X) --------------------------------------------------
+// The ring kernel above spends ~25 % of its time with both waves of a SIMD stuck in LDS-DMA issue / fragment reads at the
+// same moment (they run the same schedule in lock step after every barrier), so the matrix pipe idles.  Here a K tile is
+// four phases, each a LOAD segment (fragment reads of ONE 64x32 quadrant of the wave tile + two DMA pieces) and an MFMA
+// segment (8 MFMAs), separated by workgroup barriers, and the two wave groups (waves 0-3 / 4-7 = the two waves of every
+// SIMD) run ONE SEGMENT APART: while one wave of a SIMD loads, the other multiplies.
+//
+//   quadrants of the 128(M) x 64(N) wave tile per K tile:  Q1 = XA x WA, Q2 = XA x WB, Q3 = XB x WB, Q4 = XB x WA
+//     XA / XB = first / second 64 rows of the wave's X rows (DMA pieces {0,2} / {1,3} of the 256-row X tile),
+//     WA / WB = first / second 32 of its W rows; the W rows of a wave are 32*wn.. and 128+32*wn.., so WA of all waves is
+//     W pieces {0,1} and WB is {2,3} (epilogue column map NSPLIT).
+//   L1 reads XA, WA (12 x b128) | L2 reads WB (4) | L3 reads XB (8) | L4 reads nothing (WA fragments are kept).
+//   Half-tile slots die early: XA, WA after L1, WB after L2, XB after L3 (of BOTH groups, i.e. one segment later), which
+//   is what lets the loader run a full K tile ahead inside a 2-tile ring.  The DMA pieces are issued INSIDE the MFMA
+//   segments (two per segment, between the MFMAs: measured with s_memtime, a load segment that also issued them was
+//   twice as long as an MFMA segment and set the pace):
+//     M1(t) stages (t+1).XB -> other buffer     M2(t) stages (t+2).XA -> this buffer
+//     M3(t) stages (t+2).WA -> this buffer      M4(t) stages (t+2).WB -> this buffer
+//   One counted wait per K tile, right before the barrier that ends group 0's M4 / group 1's L4 (the same barrier):
+//   group 0 leaves its three youngest issues in flight (vmcnt(6)), group 1 its two (vmcnt(4)): (t+1).XB and everything
+//   older is then complete, which covers every read up to the next wait.  Fragment reads are retired (lgkmcnt(0)) BEFORE
+//   the barrier that ends their load segment, so a slot may be restaged one segment after its last read.
+#ifndef FFVC_NO_GEMM8
+#ifdef FFVC_G8_TIMING
+__device__ unsigned long long g8_stamps[2][64];     // [group][event]: s_memtime at segment boundaries of K tiles 4..5, block 0
+#define G8_STAMP(idx)                                                                              \
+  do {                                                                                             \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (tid & 255) == 0 && t >= 4 && t < 6) \
+      g8_stamps[grp][(t - 4) * 16 + (idx)] = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+#else
+#define G8_STAMP(idx)
+#endif
+template <typename L, int XMODE>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len,
+                                                       int vec_ok, const uint16_t* zero, int gm) {
+  constexpr int BM = 256, BN = 256, MT = 4, NW = 8;
+  constexpr int XTILE = BM * 128, STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // the ONLY LDS object: 2 stages | 8 x 4 KiB pads
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1, grp = wid >> 2;
+  const int l31 = lane & 31;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  if (gm > 1) {
+    const int width = gm * tiles_n;
+    const int g = tile / width, rem = tile - g * width;
+    const int first = g * gm;
+    const int gsz = min(n_tiles / tiles_n - first, gm);
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+  const int k_begin = blockIdx.z * ksplit_len;
+  const int k_end = min(p.K, k_begin + ksplit_len);
+  const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
+  const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
+  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDmaB<BM, NW>, KMajorDmaB<BM, NW>>::type;
+  XDma sx;
+  KMajorDmaB<BN, NW> sw;
+  if constexpr (XMODE == FFVC_OP_CONV3X3)
+    sx.init(xb, m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  else
+    sx.init(xb + (int64_t)m0 * p.ldx, p.ldx, p.M - m0, tid);
+  sw.init(wb + (int64_t)n0 * p.ldw, p.ldw, p.N - n0, tid);
+  (void)zero;
+
+  f32x16_t acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  auto kof = [&](int t) { return k_begin + t * BK; };
+  // prologue: tile 0 completely, tile 1 without XB (L1(0) stages it)
+  if (nk > 0) {
+    sx.issue(smem, kof(0), k_end);
+    sw.issue(smem + XTILE, kof(0), k_end);
+  }
+  if (nk > 1) {
+    sx.template issue2<0, 2>(smem + STAGE, kof(1), k_end);
+    sw.issue(smem + STAGE + XTILE, kof(1), k_end);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();          // group 1 runs one segment behind group 0
+
+  const int xrow = wm * 128 + l31;                 // + 32 b
+  const int wrowA = wn * 32 + l31, wrowB = 128 + wn * 32 + l31;
+  u32x4_t fx[2][4], fwA[4], fwB[4];
+  auto end_load = [&]() {                          // fragment reads retired, then the segment's barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end_mma = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one MFMA segment: quadrant (a; b0, b0+1) += fw x fx, with the segment's two DMA pieces issued between the MFMAs (the
+  // matrix pipe keeps draining its queue while the wave is busy in LDS-DMA issue)
+  auto mma_seg = [&](int a, int b0, const u32x4_t (&fw)[4], auto&& stage) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) mma_lo<L>(acc[a][b0 + b], fw[s], fx[b][s]);
+      if (s == 0) stage(0);
+      if (s == 2) stage(1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  for (int t = 0; t < nk; ++t) {
+    unsigned char* cur = smem + (t & 1) * STAGE;
+    unsigned char* oth = smem + ((t + 1) & 1) * STAGE;
+    const unsigned char* sX = cur;
+    const unsigned char* sW = cur + XTILE;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    const int k1 = kof(t + 1), k2 = kof(t + 2);
+    // ---- L1: XA, WA fragments
+    G8_STAMP(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fwA[s] = frag_kmajor(sW, wrowA, s, lane);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fx[b][s] = frag_kmajor(sX, xrow + 32 * b, s, lane);
+    G8_STAMP(1);
+    end_load();
+    G8_STAMP(3);
+    // ---- M1: Q1 = XA x WA; stage (t+1).XB -> other buffer
+    mma_seg(0, 0, fwA, [&](int i) { if (n1) sx.issue1(oth, i ? 3 : 1, k1, k_end); });
+    G8_STAMP(4);
+    end_mma();
+    G8_STAMP(5);
+    // ---- L2: WB fragments
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fwB[s] = frag_kmajor(sW, wrowB, s, lane);
+    G8_STAMP(6);
+    end_load();
+    G8_STAMP(8);
+    // ---- M2: Q2 = XA x WB; stage (t+2).XA -> this buffer (XA was last read in L1, two segments ago for either group)
+    mma_seg(1, 0, fwB, [&](int i) { if (n2) sx.issue1(cur, i ? 2 : 0, k2, k_end); });
+    G8_STAMP(9);
+    end_mma();
+    G8_STAMP(10);
+    // ---- L3: XB fragments
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fx[b][s] = frag_kmajor(sX, xrow + 64 + 32 * b, s, lane);
+    G8_STAMP(11);
+    end_load();
+    G8_STAMP(13);
+    // ---- M3: Q3 = XB x WB; stage (t+2).WA
+    mma_seg(1, 2, fwB, [&](int i) { if (n2) sw.issue1(cur + XTILE, i, k2, k_end); });
+    G8_STAMP(14);
+    end_mma();
+    G8_STAMP(15);
+    // ---- L4: nothing to read (WA fragments are kept); group 1's counted wait: its M1..M3 issues of this tile are behind
+    // it, (t+1).XB (M1) has to be complete, the two younger ones may stay in flight
+    if (grp) {
+      if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    end_load();
+    // ---- M4: Q4 = XB x WA; stage (t+2).WB; group 0's counted wait (M2..M4 issues may stay in flight)
+    mma_seg(0, 2, fwA, [&](int i) { if (n2) sw.issue1(cur + XTILE, 2 + i, k2, k_end); });
+    if (!grp) {
+      if (n2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    end_mma();
+  }
+  if (!grp) __builtin_amdgcn_s_barrier();         // balance group 1's extra barrier
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, smem + 2 * STAGE + wid * 4096);
+  else
+    ffvc_gemm_detail::gemm_epilogue<L, MT, true, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
+}
+#endif  // FFVC_NO_GEMM8
+
 #ifdef FFVC_BUILD_PERSIST   // opt-in build (adds ~2 min of compile time): make CXXEXTRA=-DFFVC_BUILD_PERSIST
 // ---- persistent variant of the ring kernel ------------------------------------------------------------------------------
 // One workgroup per CU slot walks work items w = blockIdx.x, + gridDim.x, ... (tile x batch x K-split).  The K loop is
@@ -600,6 +943,19 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 
 #endif  // FFVC_BUILD_PERSIST
 
+// the buffer-descriptor DMA addresses a tile with 32-bit byte offsets below 2 GiB
+template <int XMODE>
+inline bool g8_offsets_ok(const ffvc_gemm_desc& d) {
+  const int64_t lim = 0x7FFFFF00ll;
+  if (256 * d.ldw * 2 + (int64_t)d.K * 2 >= lim) return false;
+  if (XMODE == FFVC_OP_CONV3X3) {
+    const int ups = (d.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0;
+    const int64_t images = d.M / ((int64_t)d.conv_H * d.conv_W);
+    return images * (d.conv_H >> ups) * (d.conv_W >> ups) * d.conv_Cin * 2 < lim;
+  }
+  return 256 * d.ldx * 2 + (int64_t)d.K * 2 < lim;
+}
+
 template <typename L, int XMODE, int WMODE, int BM, int BN>
 int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
@@ -667,6 +1023,34 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   }
 #else
   (void)persist;
+#endif
+#ifndef FFVC_NO_GEMM8
+  if constexpr (BM == 256 && BN == 256 && WMODE == FFVC_OP_KMAJOR && (XMODE == FFVC_OP_KMAJOR || XMODE == FFVC_OP_CONV3X3)) {
+    // FFVC_GEMM8: 0 = ring kernel only | 1 (default) = 8-phase kernel where it measured faster (plain K-major x K-major,
+    // K >= 2048: +4..8 %, profiles/r02_gemm8_ab.txt; shorter reductions and the implicit-GEMM conv stay on the ring) |
+    // 2 = every eligible launch (tests)
+    static int use8 = -1;
+    if (use8 < 0) {
+      const char* e = getenv("FFVC_GEMM8");
+      use8 = e ? atoi(e) : 1;
+    }
+    const bool pays = XMODE == FFVC_OP_KMAJOR && d.K >= 2048;
+    if ((use8 == 2 || (use8 == 1 && pays) || g_force_gemm8) && d.kseg == 0 && d.x_mi == 0 && g8_offsets_ok<XMODE>(d)) {
+      static bool attr8 = false;
+      if (!attr8) {
+        (void)hipFuncSetAttribute((const void*)gemm8_kernel<L, XMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr8 = true;
+      }
+      hipLaunchKernelGGL((gemm8_kernel<L, XMODE>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len, vec_ok,
+                         zero, gm);
+      hipError_t e8 = hipGetLastError();
+      if (e8 != hipSuccess) {
+        ffvc_set_error("gemm8 launch failed: %s", hipGetErrorString(e8));
+        return -(int)e8 - 1000;
+      }
+      return 1;
+    }
+  }
 #endif
   hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
                      vec_ok, zero, gm);

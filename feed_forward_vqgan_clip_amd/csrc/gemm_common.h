@@ -81,7 +81,9 @@ __device__ __forceinline__ void epilogue_quad(const ffvc_gemm_desc& p, f32x4_t v
   }
 }
 
-template <typename T, int MT = 2, bool VEC_ONLY = false>
+// NSPLIT: the wave's two 32-column blocks sit 128 columns apart (n0 + nt*128 + wn*32: gemm8_kernel) instead of side by
+// side (n0 + wn*64 + nt*32).
+template <typename T, int MT = 2, bool VEC_ONLY = false, bool NSPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0, int wm,
                                               int wn, int lane, int zo, int zi, int vec_ok, int zs = -1) {
   const int l31 = lane & 31, h = lane >> 5;
@@ -105,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t 
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + nt * 32 + 8 * q + 4 * h;
+        const int n = n0 + (NSPLIT ? nt * 128 + wn * 32 : wn * 64 + nt * 32) + 8 * q + 4 * h;
         f32x4_t v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
@@ -202,7 +204,7 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
 }
 
 // pad: this wave's 4 KiB of LDS.  Requires N % 8 == 0 and 16-byte aligned rows of y / aux / residual (host-checked).
-template <typename T, int MT>
+template <typename T, int MT, bool NSPLIT = false>
 __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0,
                                                    int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
                                                    int zs = -1) {
@@ -245,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int n = n0 + wn * 64 + nt * 32 + 8 * cc;
+      const int n = n0 + (NSPLIT ? nt * 128 + wn * 32 : wn * 64 + nt * 32) + 8 * cc;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = rr + 16 * i;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
           a += __shfl_xor(a, o, 64);
           b += __shfl_xor(b, o, 64);
         }
-        const int n = n0 + wn * 64 + nt * 32 + 8 * cc + 4 * hf;
+        const int n = n0 + (NSPLIT ? nt * 128 + wn * 32 : wn * 64 + nt * 32) + 8 * cc + 4 * hf;
         if (rr == 0 && n < p.N) {
           double* o2 = p.gn_sums + (img + n / p.gn_cpg) * 2;
           atomicAdd(o2, (double)a);

@@ -187,7 +187,7 @@ class DistributedOptimizer:
         a.add_grad_callback(self._param_ready)
         for p in a.plist:
             if p.requires_grad:
-                p.register_post_accumulate_grad_hook(self._param_ready)
+                p.register_post_accumulate_grad_hook(self._param_ready_hook)
         self.param_groups = opt.param_groups
 
     def _aligned_end(self, i):
@@ -195,6 +195,12 @@ class DistributedOptimizer:
         return a.offsets[i + 1] if i + 1 < len(a.plist) else a.total
 
     # -- gradient-ready plumbing ------------------------------------------------
+    def _param_ready_hook(self, p):
+        # autograd's own notification.  The engine also runs the AccumulateGrad node (and this hook) of a parameter whose
+        # gradient a fused kernel already wrote (its Function returned None for it): that repeat is not a second use.
+        if id(p) not in self._seen:
+            self._param_ready(p)
+
     def _param_ready(self, p):
         if not is_distributed():
             return
@@ -203,8 +209,9 @@ class DistributedOptimizer:
             # out means a weight shared between two layers: its later contribution would be written into a slice that is
             # already being all-reduced (replicas stay identical, the gradient is silently wrong) -> refuse.
             if any(b in self._handles for b in self._bucket_of[id(p)]):
-                raise RuntimeError("DistributedOptimizer: a parameter received a second gradient contribution after its "
-                                   "bucket was launched (weight sharing is not supported by the fused gradient path)")
+                name = next((n for n, q in self.arena.module.named_parameters() if q is p), "?")
+                raise RuntimeError(f"DistributedOptimizer: parameter '{name}' received a second gradient contribution after "
+                                   "its bucket was launched (weight sharing is not supported by the fused gradient path)")
             return
         self._seen.add(id(p))
         for b in self._bucket_of[id(p)]:

@@ -313,7 +313,8 @@ int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const
 
 /* Kernel-selection overrides for tests / A-B measurements (defaults come from FFVC_GEMM2_BM / FFVC_CONV_ROW):
  *   "gemm2_tile": 0 = register-staged kernel only, 1 = heuristic, 128 | 256 | 512 = force the LDS-DMA tile
- *                 (128x128 | 256x128 | 256x256);   "conv_row": 0 off, 1 heuristic, 2 force the haloed row-tile conv. */
+ *                 (128x128 | 256x128 | 256x256);   "conv_row": 0 off, 1 heuristic, 2 force the haloed row-tile conv;
+ *   "gemm8": 1 = every eligible 256x256 launch takes the 8-phase kernel (default: only where it measured faster). */
 int ffvc_set_option(const char* name, int value);
 
 /* Library / device info */

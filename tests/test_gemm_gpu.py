@@ -295,3 +295,63 @@ def test_splitk_slabs_all_written(cuda, dt, Kred, sk):
     K.gemm_splitk_accumulate(x, w, out, M, N, Kred, sk, ldx=Kred, ldw=Kred)
     assert torch.isfinite(out).all(), "an unwritten split-K slab leaked into the reduction"
     assert _rel(out, ref) < 1e-4           # fp32 accumulation order over up to 65536 terms
+
+
+# ----------------------------------------------------------------------------- every LDS-DMA tile configuration, forced
+@pytest.mark.parametrize("tile", [128, 256, 512])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_forced_tiles_nt_and_conv(cuda, tile, dt):
+    """Each tile configuration of the LDS-DMA path (512 = the 8-phase 256x256 kernel) on interior and ragged shapes,
+    K tails, fused epilogues, split-K slabs, batches and the generic implicit-GEMM conv; every launch is repeated and
+    must reproduce bit for bit (a staging race shows up as run-to-run differences long before it shows in a tolerance)."""
+    K.set_option("gemm2_tile", tile)
+    K.set_option("gemm8", 1)            # 256x256 launches take the 8-phase kernel wherever it is eligible
+    try:
+        for (M, N, K_) in [(512, 512, 64), (512, 256, 128), (768, 512, 1024), (1000, 520, 328), (256, 256, 4096),
+                           (2048, 1024, 192), (300, 264, 72)]:
+            x, w = _mk((M, K_), dt, cuda, 1, 0.5), _mk((N, K_), dt, cuda, 2, 0.5)
+            b = _mk((N,), torch.float32, cuda, 3)
+            res = _mk((M, N), torch.float32, cuda, 4)
+            ref = x.double() @ w.double().T + b.double() + res.double()
+            outs = []
+            for _ in range(3):
+                y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+                K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_, bias=b, residual=res)
+                outs.append(y)
+            assert _rel(outs[0], ref) < 2e-5, (M, N, K_)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, K_)
+            # 16-bit output + GELU + pre-activation
+            y16 = torch.empty(M, N, dtype=dt, device=cuda)
+            aux = torch.empty(M, N, dtype=dt, device=cuda)
+            K.gemm(x, w, y16, M, N, K_, ldx=K_, ldw=K_, bias=b, aux=aux, ldaux=N, act=K.ACT_GELU, flags=K.F_WRITE_PREACT)
+            pre = x.double() @ w.double().T + b.double()
+            assert _rel(aux, pre) < LOTOL[dt] and _rel(y16, F.gelu(pre)) < LOTOL[dt], (M, N, K_)
+        # split-K slabs + batch
+        M, N, K_ = 512, 512, 2048
+        x, w = _mk((M, K_), dt, cuda, 5, 0.3), _mk((N, K_), dt, cuda, 6, 0.3)
+        out = torch.zeros(M, N, dtype=torch.float32, device=cuda)
+        K.gemm_splitk_accumulate(x, w, out, M, N, K_, 4, ldx=K_, ldw=K_)
+        assert _rel(out, x.double() @ w.double().T) < 2e-5
+        xb, wb = _mk((3, 256, 320), dt, cuda, 7), _mk((3, 512, 320), dt, cuda, 8)
+        yb = torch.empty(3, 256, 512, dtype=torch.float32, device=cuda)
+        K.gemm(xb, wb, yb, 256, 512, 320, ldx=320, ldw=320, batch=3, xb=(256 * 320, 0), wb=(512 * 320, 0), yb=(256 * 512, 0))
+        assert _rel(yb, torch.einsum("bmk,bnk->bmn", xb.double(), wb.double())) < 2e-5
+        # generic implicit-GEMM conv (row-tile kernel off), with and without the fused upsample
+        K.set_option("conv_row", 0)
+        for (B, Hin, Cin, Cout, ups) in [(2, 16, 128, 256, False), (1, 16, 64, 512, True), (3, 12, 128, 320, False)]:
+            H = 2 * Hin if ups else Hin
+            xc = _mk((B, Hin, Hin, Cin), dt, cuda, 9)
+            wc = _mk((Cout, 3, 3, Cin), dt, cuda, 10, 0.05)
+            bc = _mk((Cout,), torch.float32, cuda, 11)
+            yc = torch.empty(B, H, H, Cout, dtype=dt, device=cuda)
+            K.gemm(xc, wc, yc, B * H * H, Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=bc, conv=(H, H, Cin),
+                   flags=K.F_UPSAMPLE2X if ups else 0)
+            xn = xc.double().permute(0, 3, 1, 2)
+            if ups:
+                xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+            refc = F.conv2d(xn, wc.double().permute(0, 3, 1, 2), bc.double(), padding=1).permute(0, 2, 3, 1)
+            assert _rel(yc, refc) < LOTOL[dt], (B, Hin, Cin, Cout, ups)
+    finally:
+        K.set_option("gemm2_tile", 1)
+        K.set_option("gemm8", 0)
+        K.set_option("conv_row", 1)
