@@ -36,7 +36,7 @@ namespace {
 // 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
 // (X 33 KiB + W 16 KiB) so that two workgroups share a CU and alternate DMA / MFMA phases.
 // K order: kh (3) x 64-channel block (Cin/64) x kw (3); the X tile is (re)loaded only when (kh, block) changes.
-template <typename L>
+template <typename L, bool BUF>
 __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
                                                           const uint16_t* zero) {
   constexpr int MT = 4, BM = 256, BN = 128;
@@ -54,10 +54,13 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int W = p.conv_W, Cin = p.conv_Cin;
-  ConvRowDma sx;
-  KMajorDma<BN, 4> sw;
+  typename std::conditional<BUF, ConvRowDmaB, ConvRowDma>::type sx;
+  typename std::conditional<BUF, KMajorDmaB<BN, 4>, KMajorDma<BN, 4>>::type sw;
   sx.init((const uint16_t*)p.x, m0, p.conv_H, W, Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
-  sw.init((const uint16_t*)p.w, p.ldw, n0, p.N, 0, 0, tid, 0, 0);
+  if constexpr (BUF)
+    sw.init((const uint16_t*)p.w + (int64_t)n0 * p.ldw, p.ldw, p.N - n0, tid);
+  else
+    sw.init((const uint16_t*)p.w, p.ldw, n0, p.N, 0, 0, tid, 0, 0);
 
   f32x16_t acc[2][MT];
 #pragma unroll
@@ -217,15 +220,24 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       const int tiles_n = d.N / 128, n_tiles = (d.M / 256) * tiles_n;
       constexpr int lds = 264 * 128 + 128 * 128 + 4 * 4096;
       static bool attr = false;
+      static int use_buf = 1;
       if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const char* e = getenv("FFVC_DMA_BUF");
+        use_buf = e ? atoi(e) : 1;
         attr = true;
       }
-      if (d.in_dtype == FFVC_F16)
-        hipLaunchKernelGGL(conv_row_kernel<f16_t>, dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
-      else
-        hipLaunchKernelGGL(conv_row_kernel<uint16_t>, dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+      const bool buf = use_buf && g8_offsets_ok<FFVC_OP_CONV3X3>(d);
+      if (d.in_dtype == FFVC_F16) {
+        if (buf) hipLaunchKernelGGL((conv_row_kernel<f16_t, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        else hipLaunchKernelGGL((conv_row_kernel<f16_t, false>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+      } else {
+        if (buf) hipLaunchKernelGGL((conv_row_kernel<uint16_t, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        else hipLaunchKernelGGL((conv_row_kernel<uint16_t, false>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+      }
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) {
         ffvc_set_error("conv_row launch failed: %s", hipGetErrorString(e));

@@ -25,6 +25,23 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_b
   __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)lds_wave_base, 16, 0, 0);
 }
 
+// ---- buffer-resource variants (buffer_load_dwordx4 ... lds): 32-bit byte offsets against a wave-uniform descriptor instead of
+// 64-bit per-lane addresses — half the address VALU per piece — and out-of-range rows / K tails / conv halo are simply an
+// offset beyond num_records (the hardware writes zeros), so no zero page and no select on pointers.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t DMA_OOB = 0xFFFFFFF0u;
+constexpr int DMA_NUMREC = 0x7FFFFF00;            // every valid offset must stay below 2 GiB (launcher-checked)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, DMA_NUMREC, 0x00020000);
+}
+__device__ __forceinline__ void dma16b(rsrc_t rs, uint32_t voff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dma16bs(rsrc_t rs, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // ---- K-major operand: 4 DMA pieces per thread per K step ------------------------------------------------
 // piece j of wave w covers LDS chunk positions p = (4j + w) * 64 + lane; line = p >> 4, slot = p & 15,
 // source chunk c' = slot ^ (line & 15): row = 2 * line + (c' >> 3), k-chunk = c' & 7.
@@ -206,6 +223,58 @@ struct ConvRowDma {
   }
 };
 
+// buffer-descriptor variant of ConvRowDma (same tile image): per piece the column part of the address is a per-thread
+// constant, the kernel row contributes one shift-multiply-add, the channel block rides in the scalar offset
+struct ConvRowDmaB {
+  static constexpr int NP = 9;
+  rsrc_t rs;
+  int colpart[NP];                  // ((img*Hin)*Win + (ix >> ups)) * Cin + kc, or -1: position beyond the tile, -2: column halo
+  int seg[NP];
+  int H, ups, oy0, wincin, w;
+  __device__ __forceinline__ void init(const uint16_t* base, int m0, int H_, int W_, int Cin_, int ups_, int tid) {
+    const int lane = tid & 63;
+    w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    rs = make_rsrc(base);
+    H = H_;
+    ups = ups_;
+    const int Win = W_ >> ups_, Hin = H_ >> ups_;
+    wincin = Win * Cin_;
+    const int img = m0 / (H_ * W_);
+    const int rem = m0 - img * (H_ * W_);
+    oy0 = rem / W_;
+    const int Wt = W_ < 256 ? W_ : 256;
+    const int x0 = W_ > 256 ? rem - oy0 * W_ : 0;
+    const int line = 4 * w + (lane >> 4);
+    const int cp = (lane & 15) ^ (line & 15);
+    const int kc = (cp & 7) * EPC;
+    const int r0 = 2 * line + (cp >> 3);
+    const int tr = (256 / Wt) * (Wt + 2);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int r = r0 + 32 * j;
+      if (r < tr) {
+        seg[j] = r / (Wt + 2);
+        const int ix = x0 + (r % (Wt + 2)) - 1;
+        colpart[j] = ((unsigned)ix < (unsigned)W_) ? (img * Hin * Win + (ix >> ups_)) * Cin_ + kc : -2;
+      } else {
+        seg[j] = 0;
+        colpart[j] = -1;
+      }
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int kh, int ci0, const uint16_t*, int) {
+    const uint32_t so = (uint32_t)ci0 * 2u;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      if (colpart[j] == -1) continue;                     // exec-masked lanes simply do not write
+      const int iy = oy0 + seg[j] + kh - 1;
+      const bool ok = colpart[j] >= 0 && (unsigned)iy < (unsigned)H;
+      const uint32_t off = (uint32_t)(colpart[j] + (iy >> ups) * wincin) * 2u;
+      dma16bs(rs, ok ? off : DMA_OOB, ok ? so : 0u, tile + (4 * j + w) * 1024);
+    }
+  }
+};
+
 // ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
 // source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
 template <int ROWS, int NW>
@@ -239,51 +308,46 @@ struct TransDma {
   }
 };
 
-// ---- buffer-resource variants (buffer_load_dwordx4 ... lds): 32-bit byte offsets against a wave-uniform descriptor instead of
-// 64-bit per-lane addresses — half the address VALU per piece — and out-of-range rows / K tails / conv halo are simply an
-// offset beyond num_records (the hardware writes zeros), so no zero page and no select on pointers.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr uint32_t DMA_OOB = 0xFFFFFFF0u;
-constexpr int DMA_NUMREC = 0x7FFFFF00;            // every valid offset must stay below 2 GiB (launcher-checked)
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, DMA_NUMREC, 0x00020000);
-}
-__device__ __forceinline__ void dma16b(rsrc_t rs, uint32_t voff, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)lds_wave_base, 16, voff, 0, 0, 0);
-}
-
-__device__ __forceinline__ void dma16bs(rsrc_t rs, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
 template <int ROWS, int NW>
 struct KMajorDmaB {
   static constexpr int NP = ROWS / (8 * NW);
   rsrc_t rs;
   uint32_t voff[NP];        // byte offset of this thread's chunk in piece j at k = 0; DMA_OOB for rows beyond the operand
-  int kc, w;
-  // base = pointer to (first row of the tile, k = 0); rows_ = rows of the operand left from there
-  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int rows_, int tid) {
+  int kc, w, kseg;
+  int64_t kso;
+  // Same arguments as KMajorDma::init.  The descriptor starts at the tile's first row (plain row map) or at the operand
+  // (split row map), every offset is relative to that.
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int row0, int rows, int kseg_, int64_t kso_, int tid,
+                                       int mi, int64_t so) {
     const int lane = tid & 63;
     w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int line = 4 * w + (lane >> 4);
     const int cp = (lane & 15) ^ (line & 15);
-    const int r0 = 2 * line + (cp >> 3);
+    const int r0 = row0 + 2 * line + (cp >> 3);
     kc = (cp & 7) * EPC;
-    rs = make_rsrc(base);
+    kseg = kseg_;
+    kso = kso_;
+    const int64_t origin = mi ? 0 : (int64_t)row0 * ld;
+    rs = make_rsrc(base + origin);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int r = r0 + (8 * NW) * j;
-      voff[j] = r < rows_ ? (uint32_t)(((int64_t)r * ld + kc) * 2) : DMA_OOB;
+      const int64_t ro = mi ? (int64_t)(r / mi) * so + (int64_t)(r % mi) * ld : (int64_t)r * ld;
+      voff[j] = r < rows ? (uint32_t)((ro - origin + kc) * 2) : DMA_OOB;
     }
+  }
+  // gemm8's shorthand: plain operand, base already at the tile's first row
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int rows_, int tid) {
+    init(base, ld, 0, rows_, 0, 0, tid, 0, 0);
   }
   // k0 is wave-uniform: it travels in the instruction's scalar offset, so an interior K tile costs no VALU at all
   __device__ __forceinline__ void issue1(unsigned char* tile, int j, int k0, int kend) {
+    const uint32_t so = (uint32_t)((kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0) * 2);
     if (k0 + BK <= kend) {
-      dma16bs(rs, voff[j], (uint32_t)k0 * 2u, tile + (NW * j + w) * 1024);
+      dma16bs(rs, voff[j], so, tile + (NW * j + w) * 1024);
     } else {                 // K tail: chunks beyond kend read as zero
       const bool ok = k0 + kc + EPC <= kend;
-      dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? (uint32_t)k0 * 2u : 0u, tile + (NW * j + w) * 1024);
+      dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? so : 0u, tile + (NW * j + w) * 1024);
     }
   }
   template <int J0, int J1>
@@ -292,8 +356,54 @@ struct KMajorDmaB {
     issue1(tile, J1, k0, kend);
   }
   __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend) {
+    const uint32_t so = (uint32_t)((kseg ? (int64_t)(k0 / kseg) * kso + (k0 % kseg) : (int64_t)k0) * 2);
+    if (k0 + BK <= kend) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) issue1(tile, j, k0, kend);
+      for (int j = 0; j < NP; ++j) dma16bs(rs, voff[j], so, tile + (NW * j + w) * 1024);
+    } else {
+      const bool ok = k0 + kc + EPC <= kend;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? so : 0u, tile + (NW * j + w) * 1024);
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t*, int) { issue(tile, k0, kend); }
+};
+
+// reduction-major operand [k][cols] through a buffer descriptor: the k index of a K tile is the scalar offset
+template <int ROWS, int NW>
+struct TransDmaB {
+  static constexpr int NP = ROWS / (8 * NW);
+  static constexpr int CPR = ROWS / 8;
+  rsrc_t rs;
+  uint32_t voff[NP];
+  int krow[NP];
+  int w;
+  int64_t ld;
+  __device__ __forceinline__ void init(const uint16_t* base, int64_t ld_, int col0, int cols, int tid) {
+    const int lane = tid & 63;
+    w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ld = ld_;
+    rs = make_rsrc(base + col0);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = (NW * j + w) * 64 + lane;
+      krow[j] = p / CPR;
+      const int c = ((p % CPR) ^ ((krow[j] & 3) << 2)) * EPC;
+      voff[j] = (col0 + c + EPC <= cols) ? (uint32_t)(((int64_t)krow[j] * ld_ + c) * 2) : DMA_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t*, int) {
+    const uint32_t so = (uint32_t)((int64_t)k0 * ld * 2);
+    if (k0 + BK <= kend) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) dma16bs(rs, voff[j], so, tile + (NW * j + w) * 1024);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const bool ok = k0 + krow[j] < kend;
+        dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? so : 0u, tile + (NW * j + w) * 1024);
+      }
+    }
   }
 };
 
@@ -352,6 +462,7 @@ struct ConvDmaB {
 #pragma unroll
     for (int j = 0; j < NP; ++j) issue1(tile, j, k0, kend);
   }
+  __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t*, int) { issue(tile, k0, kend); }
 };
 
 // ---- fragment reads (one 16-byte chunk = 8 bf16, k = 16*sub + 8*h + e) -----------------------------------
@@ -404,7 +515,9 @@ constexpr bool EXP_SKIP = true;    // timing experiment only (wrong results): em
 #else
 constexpr bool EXP_SKIP = false;
 #endif
-template <typename L, int XMODE, int WMODE, int BM, int BN>
+// BUF: K-major / implicit-im2col operands go through buffer-descriptor DMA (buffer_load ... lds, scalar K offset) instead of
+// global_load_lds with 64-bit per-lane addresses; plain operands only (no K segments, no split row map, offsets < 2 GiB).
+template <typename L, int XMODE, int WMODE, int BM, int BN, bool BUF = false>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2_kernel(
     const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero, int gm) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
@@ -446,9 +559,12 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
   const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
 
-  using XDma = typename std::conditional<XMODE == FFVC_OP_CONV3X3, ConvDma<BM, NW>,
-                                         typename std::conditional<XMODE == FFVC_OP_TRANS, TransDma<BM, NW>, KMajorDma<BM, NW>>::type>::type;
-  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, TransDma<BN, NW>, KMajorDma<BN, NW>>::type;
+  using XDma = typename std::conditional<
+      XMODE == FFVC_OP_CONV3X3, typename std::conditional<BUF, ConvDmaB<BM, NW>, ConvDma<BM, NW>>::type,
+      typename std::conditional<XMODE == FFVC_OP_TRANS, typename std::conditional<BUF, TransDmaB<BM, NW>, TransDma<BM, NW>>::type,
+                                typename std::conditional<BUF, KMajorDmaB<BM, NW>, KMajorDma<BM, NW>>::type>::type>::type;
+  using WDma = typename std::conditional<WMODE == FFVC_OP_TRANS, typename std::conditional<BUF, TransDmaB<BN, NW>, TransDma<BN, NW>>::type,
+                                         typename std::conditional<BUF, KMajorDmaB<BN, NW>, KMajorDma<BN, NW>>::type>::type;
   XDma sx;
   WDma sw;
   if constexpr (XMODE == FFVC_OP_CONV3X3)
@@ -943,17 +1059,24 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 
 #endif  // FFVC_BUILD_PERSIST
 
-// the buffer-descriptor DMA addresses a tile with 32-bit byte offsets below 2 GiB
-template <int XMODE>
-inline bool g8_offsets_ok(const ffvc_gemm_desc& d) {
+// the buffer-descriptor DMA addresses an operand with 32-bit byte offsets below 2 GiB from its descriptor's origin
+template <int MODE>
+inline bool dma_operand_ok(const ffvc_gemm_desc& d, bool is_x) {
   const int64_t lim = 0x7FFFFF00ll;
-  if (256 * d.ldw * 2 + (int64_t)d.K * 2 >= lim) return false;
-  if (XMODE == FFVC_OP_CONV3X3) {
+  const int64_t ld = is_x ? d.ldx : d.ldw;
+  const int64_t kspan = d.kseg ? (int64_t)(d.K / d.kseg) * (is_x ? d.xkso : d.wkso) + d.kseg : (int64_t)d.K;
+  if (MODE == FFVC_OP_CONV3X3) {
     const int ups = (d.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0;
     const int64_t images = d.M / ((int64_t)d.conv_H * d.conv_W);
     return images * (d.conv_H >> ups) * (d.conv_W >> ups) * d.conv_Cin * 2 < lim;
   }
-  return 256 * d.ldx * 2 + (int64_t)d.K * 2 < lim;
+  if (MODE == FFVC_OP_TRANS) return ((int64_t)d.K * ld + 256) * 2 < lim;           // k * ld + column
+  if (is_x && d.x_mi) return ((int64_t)(d.M / d.x_mi + 1) * d.x_so + (int64_t)d.x_mi * ld + kspan) * 2 < lim;
+  return (256 * ld + kspan) * 2 < lim;                                                // tile rows + k
+}
+template <int XMODE>
+inline bool g8_offsets_ok(const ffvc_gemm_desc& d) {
+  return dma_operand_ok<XMODE>(d, true) && dma_operand_ok<FFVC_OP_KMAJOR>(d, false);
 }
 
 template <typename L, int XMODE, int WMODE, int BM, int BN>
@@ -1026,13 +1149,13 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
 #endif
 #ifndef FFVC_NO_GEMM8
   if constexpr (BM == 256 && BN == 256 && WMODE == FFVC_OP_KMAJOR && (XMODE == FFVC_OP_KMAJOR || XMODE == FFVC_OP_CONV3X3)) {
-    // FFVC_GEMM8: 0 = ring kernel only | 1 (default) = 8-phase kernel where it measured faster (plain K-major x K-major,
-    // K >= 2048: +4..8 %, profiles/r02_gemm8_ab.txt; shorter reductions and the implicit-GEMM conv stay on the ring) |
-    // 2 = every eligible launch (tests)
+    // FFVC_GEMM8: 0 (default) = ring kernel only: once the ring kernel got the buffer-descriptor DMA it passed the 8-phase
+    // kernel on every shape (4096^3: 1175 vs 1004 TFLOP/s, profiles/r02_gemm8_ab.txt) | 1 = 8-phase for plain K-major x
+    // K-major launches with K >= 2048 | 2 = every eligible launch; ffvc_set_option("gemm8", 1) forces it for the tests
     static int use8 = -1;
     if (use8 < 0) {
       const char* e = getenv("FFVC_GEMM8");
-      use8 = e ? atoi(e) : 1;
+      use8 = e ? atoi(e) : 0;
     }
     const bool pays = XMODE == FFVC_OP_KMAJOR && d.K >= 2048;
     if ((use8 == 2 || (use8 == 1 && pays) || g_force_gemm8) && d.kseg == 0 && d.x_mi == 0 && g8_offsets_ok<XMODE>(d)) {
@@ -1052,6 +1175,28 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
     }
   }
 #endif
+  {
+    static int use_buf = -1;
+    if (use_buf < 0) {
+      const char* e = getenv("FFVC_DMA_BUF");
+      use_buf = e ? atoi(e) : 1;
+    }
+    if (use_buf && dma_operand_ok<XMODE>(d, true) && dma_operand_ok<WMODE>(d, false)) {
+      static bool attr_b = false;
+      if (!attr_b) {
+        (void)hipFuncSetAttribute((const void*)gemm2_kernel<L, XMODE, WMODE, BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_b = true;
+      }
+      hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN, true>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles,
+                         ksplit_len, vec_ok, zero, gm);
+      hipError_t eb = hipGetLastError();
+      if (eb != hipSuccess) {
+        ffvc_set_error("gemm2 (buffer DMA) launch failed: %s", hipGetErrorString(eb));
+        return -(int)eb - 1000;
+      }
+      return 1;
+    }
+  }
   hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
                      vec_ok, zero, gm);
   hipError_t e = hipGetLastError();

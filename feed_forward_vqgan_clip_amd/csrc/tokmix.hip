@@ -44,35 +44,36 @@ __device__ __forceinline__ void wait_vm() {
 }
 typedef const __attribute__((address_space(4))) float* const_f32p;   // constant address space: uniform loads become s_load
 
-// per-thread DMA sources of one [32 rows][T] K-major chunk (row stride `ld` elements) and of one [T rows][32] chunk
+// per-thread DMA sources of one [32 rows][T] K-major chunk (row stride `ld` elements) and of one [T rows][32] chunk, as byte
+// offsets against a buffer descriptor of the weight matrix; the chunk index travels in the scalar offset
 template <int T_>
 struct ChunkDma {
   static constexpr int NP = T_ / 128;          // 1-KiB pieces per thread per chunk half (512 threads x 16 B = 8 KiB)
-  int offA[NP];                                // [32][T] image: element offset of this thread's 16 bytes (+ chunk base)
-  int offB[NP];                                // [T][32] image
+  uint32_t offA[NP];                           // [32][T] image
+  uint32_t offB[NP];                           // [T][32] image
+  int w;
   __device__ __forceinline__ void init(int tid, int ldA, int ldB) {
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int SPR = T_ / 8;                // 16-byte slots per [32][T] row
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int p = (8 * j + w) * 64 + lane;
       const int row = p / SPR, slot = (p % SPR) ^ (row & 15);
-      offA[j] = row * ldA + slot * 8;
+      offA[j] = (uint32_t)(row * ldA + slot * 8) * 2u;
       const int e = (p & ~15) | ((p & 15) ^ ((p >> 4) & 15));
-      offB[j] = (e >> 2) * ldB + (e & 3) * 8;
+      offB[j] = (uint32_t)((e >> 2) * ldB + (e & 3) * 8) * 2u;
     }
   }
-  // chunk of rows [r0, r0+32) of a K-major [rows][T] matrix
-  __device__ __forceinline__ void issueA(unsigned char* dst, const uint16_t* base, int tid) const {
-    const int w = tid >> 6;
+  // rows [32c, 32c+32) of a K-major [rows][T] matrix: soff = c * 32 * T * 2 bytes
+  __device__ __forceinline__ void issueA(unsigned char* dst, rsrc_t rs, uint32_t soff) const {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) dma16(base + offA[j], dst + (8 * j + w) * 1024);
+    for (int j = 0; j < NP; ++j) dma16bs(rs, offA[j], soff, dst + (8 * j + w) * 1024);
   }
-  // columns [c0, c0+32) of a K-major [T][cols] matrix (base already offset by c0)
-  __device__ __forceinline__ void issueB(unsigned char* dst, const uint16_t* base, int tid) const {
-    const int w = tid >> 6;
+  // columns [32c, 32c+32) of a K-major [T][cols] matrix: soff = c * 32 * 2 bytes
+  __device__ __forceinline__ void issueB(unsigned char* dst, rsrc_t rs, uint32_t soff) const {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) dma16(base + offB[j], dst + (8 * j + w) * 1024);
+    for (int j = 0; j < NP; ++j) dma16bs(rs, offB[j], soff, dst + (8 * j + w) * 1024);
   }
 };
 
@@ -93,7 +94,7 @@ template <typename L, int T_>
 __device__ __forceinline__ void load_bfrags(u32x4_t (&f)[T_ / 16], unsigned char* smem, const uint16_t* act, int D, int d0,
                                             const uint16_t* zero, int tid) {
   const int lane = tid & 63, wid = tid >> 6;
-  TransDma<256, 8> sx;
+  TransDmaB<256, 8> sx;
   sx.init(act, D, d0, D, tid);
 #pragma unroll
   for (int kt = 0; kt < T_ / 64; ++kt) sx.issue(smem + kt * 32768, kt * 64, T_, zero, tid);
@@ -137,11 +138,12 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
 
   ChunkDma<T_> dm;
   dm.init(tid, T_, O);
+  const rsrc_t rs1 = make_rsrc(w1), rs2 = make_rsrc(w2);
   const int NC = O / TM_OC;
   auto issue = [&](int c) {
     unsigned char* st = smem + (c % TM_NST) * STAGE;
-    dm.issueA(st, w1 + (int64_t)c * TM_OC * T_, tid);
-    dm.issueB(st + HALF, w2 + c * TM_OC, tid);
+    dm.issueA(st, rs1, (uint32_t)c * (TM_OC * T_ * 2));
+    dm.issueB(st + HALF, rs2, (uint32_t)c * (TM_OC * 2));
   };
 #pragma unroll
   for (int c = 0; c < TM_NST - 1; ++c)
@@ -253,11 +255,12 @@ __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_
 
   ChunkDma<T_> dm;
   dm.init(tid, T_, T_);
+  const rsrc_t rs1 = make_rsrc(w1), rs2 = make_rsrc(w2t);
   const int NC = O / TM_OC;
   auto issue = [&](int c) {
     unsigned char* st = smem + (c % NST) * STAGE;
-    dm.issueA(st, w1 + (int64_t)c * TM_OC * T_, tid);
-    dm.issueA(st + HALF, w2t + (int64_t)c * TM_OC * T_, tid);
+    dm.issueA(st, rs1, (uint32_t)c * (TM_OC * T_ * 2));
+    dm.issueA(st + HALF, rs2, (uint32_t)c * (TM_OC * T_ * 2));
   };
 #pragma unroll
   for (int c = 0; c < NST - 1; ++c)
