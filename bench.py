@@ -103,7 +103,7 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     facs = (torch.rand(cutn * B, generator=g) * 0.1).view(-1, 1, 1, 1)
     noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
     from feed_forward_vqgan_clip_amd import augment as faug
-    prm = None if augs == "R" else faug.draw_params(cutn * B, 224, faug.SUPPORTED if augs == "default" else
+    prm = None if augs == "R" else faug.draw_params(cutn * B, 224, faug.DEFAULT if augs == "default" else
                                                     tuple(a for a in augs.split(",") if a != "R"), generator=g)
 
     def one(step):
@@ -164,7 +164,7 @@ def full_size_parity(args, sds, ref):
         tok = fmain.synthetic_tokens(B, seed=seed)
         facs = torch.rand(cutn * B, generator=g) * 0.1
         noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
-        names = faug.SUPPORTED if augs is None else tuple(a for a in augs if a != "R")
+        names = faug.DEFAULT if augs is None else tuple(a for a in augs if a != "R")
         prm = faug.draw_params(cutn * B, 224, names, generator=g) if names else None
         return tok, facs, noise, prm
 

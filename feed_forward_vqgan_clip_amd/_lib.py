@@ -127,7 +127,7 @@ _SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "ffvc_cutouts_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                  c_float, c_float, c_void_p]),
-    "ffvc_augment_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
+    "ffvc_augment_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
     "ffvc_augment_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                  c_void_p]),
     "ffvc_spherical_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
@@ -135,6 +135,7 @@ _SIGNATURES = {
     "ffvc_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float,
                           c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "ffvc_clip_coef": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "ffvc_dropout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_float, ctypes.c_uint32, c_void_p]),
     "ffvc_mean_sq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ffvc_mean_sq_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ffvc_tv_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -458,6 +458,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ---- dropout (mlp_mixer_pytorch.py:20-22, vitgan.py:34-41,105,114,133: nn.Dropout inside the mapper MLPs / after attention) ----
+// y[i] = (res ? res[i] : 0) + (keep(i) ? x[i] / (1 - p) : 0); keep(i) is a counter-based hash of (seed, i), so the backward
+// pass regenerates the identical mask from the seed instead of storing it.
+__device__ __forceinline__ bool drop_keep(uint64_t i, uint32_t seed, uint32_t thresh) {
+  uint32_t h = (uint32_t)i ^ seed ^ ((uint32_t)(i >> 32) * 0x9E3779B1u);
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >= thresh;           // P(keep) = 1 - thresh / 2^32
+}
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void dropout_kernel(const XT* __restrict__ x, const float* __restrict__ res, YT* __restrict__ y,
+                                                      int64_t n, uint32_t seed, uint32_t thresh, float inv_keep) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = drop_keep((uint64_t)i, seed, thresh) ? ElemTraits<XT>::load(x + i) * inv_keep : 0.0f;
+    if (res) v += res[i];
+    ElemTraits<YT>::store(y + i, v);
+  }
+}
+
 // ---- optional regularisers of the step (main.py:758-762 l2 = mean(z^2); :423-428,769-773 tv_loss) -------------------
 // out[0] += scale * sum x^2  (out zeroed by the launcher)
 __global__ __launch_bounds__(256) void mean_sq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
@@ -641,9 +663,9 @@ template <typename OT>
 __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ pinv,
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                           const int* __restrict__ erase, const float* __restrict__ noise,
-                                                          const float* __restrict__ facs, OT* __restrict__ out, int B, int S,
-                                                          int cutn, int P, float m0, float m1, float m2, float s0, float s1,
-                                                          float s2) {
+                                                          const float* __restrict__ facs, const float* __restrict__ coff,
+                                                          OT* __restrict__ out, int B, int S, int cutn, int P, float m0,
+                                                          float m1, float m2, float s0, float s1, float s2) {
   const int gw = S / P;
   const int64_t n_px = (int64_t)cutn * B * S * S;
   const int64_t per_img = (int64_t)3 * S * S;
@@ -668,7 +690,7 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float v = erased ? 0.0f : cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2];
+      float v = erased ? 0.0f : cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
       if (noise) v += facs[n] * noise[(int64_t)n * per_img + ((int64_t)c * S + oy) * S + ox];
       const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)c * P * P + ky * P + kx;
       ElemTraits<OT>::store(out + (int64_t)n * per_img + prow, (v - mean[c]) * istd[c]);
@@ -928,6 +950,20 @@ extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* sha
   return 0;
 }
 
+extern "C" int ffvc_dropout(const void* x, int x_dtype, const float* residual, void* y, int y_dtype, int64_t n, float p,
+                            uint32_t seed, void* stream) {
+  FFVC_CHECK_ARG(x && y && n > 0 && p >= 0.0f && p < 1.0f, "ffvc_dropout: bad args (p=%f)", (double)p);
+  FFVC_CHECK_ARG(ffvc_dtype_ok(x_dtype) && ffvc_dtype_ok(y_dtype), "ffvc_dropout: bad dtype");
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const float inv_keep = 1.0f / (1.0f - p);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(x_dtype, XT, DISPATCH_DT(y_dtype, YT,
+              hipLaunchKernelGGL((dropout_kernel<XT, YT>), dim3(ew_grid(n, 1024)), dim3(256), 0, st, (const XT*)x, residual,
+                                 (YT*)y, n, seed, thresh, inv_keep)));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ffvc_mean_sq(const float* x, float* out, int64_t n, void* stream) {
   FFVC_CHECK_ARG(x && out && n > 0, "ffvc_mean_sq: bad args");
   hipStream_t st = (hipStream_t)stream;
@@ -1060,7 +1096,7 @@ extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nsl
   return 0;
 }
 
-extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat,
+extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
                                 const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
                                 int S, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
                                 float std_g, float std_b, void* stream) {
@@ -1070,7 +1106,7 @@ extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const fl
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)cutn * B * S * S;
   DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
-                                                pinv, ainv, cmat, erase, noise, facs, (OT*)out, B, S, cutn, patch, mean_r,
+                                                pinv, ainv, cmat, erase, noise, facs, coff, (OT*)out, B, S, cutn, patch, mean_r,
                                                 mean_g, mean_b, std_r, std_g, std_b));
   FFVC_LAUNCH_CHECK();
   return 0;

@@ -532,6 +532,19 @@ def clip_coef(sumsq_buf, max_norm, grad_scale):
     return out
 
 
+def dropout(x, p, seed, residual=None, out=None, out_dtype=None):
+    """out = (residual) + mask * x / (1 - p), mask regenerated from `seed` (same call on the gradient = backward)."""
+    _need_cuda(x, out)
+    _req_f32(residual)
+    if not x.is_contiguous():
+        raise TypeError("dropout: expected a contiguous tensor")
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    _call("ffvc_dropout", x.data_ptr(), dtype_code(x.dtype), _ptr(residual), out.data_ptr(), dtype_code(out.dtype), x.numel(),
+          float(p), int(seed) & 0xFFFFFFFF, stream_ptr())
+    return out
+
+
 def mean_sq(x):
     _req_f32(x)
     out = torch.empty((), dtype=torch.float32, device=x.device)
@@ -687,13 +700,13 @@ def set_option(name, value):
     _call("ffvc_set_option", name.encode(), int(value))
 
 
-def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
-    _req_f32(pooled, pinv, ainv, cmat, noise, facs)
+def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None, coff=None):
+    _req_f32(pooled, pinv, ainv, cmat, noise, facs, coff)
     _req(torch.int32, erase)
     B, _, S, _ = pooled.shape
     g = S // patch
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
-    _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), erase.data_ptr(),
+    _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), erase.data_ptr(),
           _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, cutn, patch, mean[0], mean[1], mean[2],
           std[0], std[1], std[2], stream_ptr())
     return out

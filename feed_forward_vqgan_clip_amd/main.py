@@ -81,9 +81,11 @@ replace_grad = _ReplaceGrad.apply
 
 
 class MakeCutouts(nn.Module):
-    """main.py:154-229.  Implemented: the pooling branch ((AdaptiveAvg+AdaptiveMax)/2 -> repeat cutn), the 'R'
-    aug at pool_size == cut_size (identity resize) and the additive noise `U(0,noise_fac)*N(0,1)`.
-    The kornia augmentations ('Af','Pe','Ji','Er', ...) are the next hot-path row and raise."""
+    """main.py:154-229.  The pooling branch ((AdaptiveAvg+AdaptiveMax)/2 -> repeat cutn), the additive noise
+    `U(0,noise_fac)*N(0,1)` and the augmentation list as ONE fused resampling kernel (ffvc_augment_fwd/bwd) driven by
+    per-cutout parameters (augment.py): 'R' (identity at pool_size == cut_size), 'Af','Pe','Ji','Er' (the default set),
+    'Ro','Re','Re2','Cr','Cc','Ji2','Er2','Gn'.  'Sh','Et','Ts' (sharpness / elastic / thin-plate spline) and the
+    pool=False / interpolate / pool_size != cut_size branches are not built and raise."""
 
     def __init__(self, cut_size, cutn, cut_pow=1.0, pool_size=None, interp_size=None, augs=None, pool=True,
                  interpolate=False):
@@ -121,6 +123,11 @@ class MakeCutouts(nn.Module):
             return ops.cutouts(xr_nhwc, self.cut_size, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
         if aug_params is None:
             aug_params = self.draw_aug_params(n, xr_nhwc.device)
+        gn = aug_params.get("gn")
+        if gn is not None and "Gn" in self.augs:       # 'Gn' N(0,1) noise + the U(0,noise_fac)*N(0,1) term = one Gaussian
+            if noise is None:
+                noise = torch.randn(n, 3, self.cut_size, self.cut_size, device=xr_nhwc.device)
+            facs = gn.to(xr_nhwc.device) if facs is None else torch.sqrt(facs * facs + gn.to(facs.device) ** 2)
         pooled = ops.cutouts(xr_nhwc, self.cut_size, 1, self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32)
         pooled = pooled.view(B, 3, self.cut_size, self.cut_size)
         return ops.augment(pooled, aug_params, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)

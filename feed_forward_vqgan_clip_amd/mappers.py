@@ -67,8 +67,7 @@ class Mixer(_MapperBase):
         assert (image_size % patch_size) == 0, "image must be divisible by patch size"
         if patch_size != 1:
             raise NotImplementedError("ffvc Mixer supports patch_size=1 (the only value main.py:479-488 passes)")
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP path (configs use dropout: 0)")
+        self.dropout = float(dropout)       # nn.Dropout after GELU and after the second Linear of every FeedForward (:20-22)
         self.input_dim, self.channels, self.image_size, self.dim, self.depth = input_dim, channels, image_size, dim, depth
         P = image_size * image_size
         self.mixer = nn.Sequential(
@@ -99,11 +98,12 @@ class Mixer(_MapperBase):
         h = ops.linear(ops.cast(x.float(), cdt), self._w_proj)                  # mlp_mixer_pytorch.py:85
         h = ops.transpose_last2(h.view(B, C, S * S))                            # :86 + Rearrange (:31) -> (B, S*S, C)
         h = ops.linear(h, self._w_embed, out_dtype=f32)                         # :32  fp32 residual stream
+        drop = self.dropout if self.training else 0.0                           # the reference never .eval()s the net in train
         for (n1, t1, t2, n2, c1, c2) in self._blocks:
             hn, hid = ops.layernorm_fork(h, n1.weight, n1.bias, cdt)
-            h = ops.token_mlp(hn, t1, t2, residual=hid, out_dtype=f32)          # :34 (+ residual :14)
+            h = ops.token_mlp(hn, t1, t2, residual=hid, out_dtype=f32, drop=drop)          # :34 (+ residual :14)
             hn, hid = ops.layernorm_fork(h, n2.weight, n2.bias, cdt)
-            h = ops.mlp(hn, c1, c2, ACT_GELU, residual=hid, out_dtype=f32)      # :35
+            h = ops.mlp(hn, c1, c2, ACT_GELU, residual=hid, out_dtype=f32, drop=drop)      # :35
         fin = self.mixer[self.depth + 2]
         hn = ops.layernorm(h, fin.weight, fin.bias, cdt)                        # :37
         z = ops.linear(hn, self._w_final, out_dtype=f32)                        # :88
@@ -169,6 +169,7 @@ class _VitGANBase(_MapperBase):
     def _encode(self, hl, x):
         """GTransformerEncoder (vitgan.py:120-164): hl, x fp32 (B, T, dim)."""
         cdt, f32 = self.cdt, torch.float32
+        drop = self.dropout if self.training else 0.0      # after attention (:133) and inside MLP (:36-41)
         B, T, dim = x.shape
         align = 2 if cdt != torch.float32 else 1          # GEMM operands need 4-byte aligned head blocks
         for (n1, Wqkv, Wout, n2, W1, W2, att) in self._bp:
@@ -180,9 +181,9 @@ class _VitGANBase(_MapperBase):
             o = ops.attention(qkv, H, float(dim) ** -0.5)                                        # scale = dim^-0.5 :65
             if dhp != dh:
                 o = ops.copy2d(o, B * T * H, dh, dhp, dh)
-            hl = ops.linear(o.view(B, T, H * dh), Wout, residual=hid, out_dtype=f32)             # w_out + hl :97,132
+            hl = ops.linear(o.view(B, T, H * dh), Wout, residual=hid, out_dtype=f32, drop=drop)  # w_out + hl :97,132
             y, hid = ops.sln_fork(hl, x, n2.ln.weight, n2.ln.bias, n2.gamma, n2.beta, cdt)
-            hl = ops.mlp(y, W1, W2, ACT_GELU, residual=hid, out_dtype=f32)                       # :133
+            hl = ops.mlp(y, W1, W2, ACT_GELU, residual=hid, out_dtype=f32, drop=drop)            # :133
         return hl
 
 
@@ -190,8 +191,7 @@ class Generator(_VitGANBase):
     def __init__(self, initialize_size=8, dim=384, blocks=6, num_heads=6, dim_head=None, dropout=0, out_channels=3,
                  input_dim=1024):
         super().__init__()
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP path")
+        self.dropout = float(dropout)
         self.initialize_size, self.dim, self.out_channels = initialize_size, dim, out_channels
         T = initialize_size * 8
         self.pos_emb1D = nn.Parameter(torch.randn(T, dim))
@@ -220,8 +220,7 @@ class SimpleGenerator(_VitGANBase):
     def __init__(self, size=8, in_channels=256, dim=384, blocks=6, num_heads=6, dim_head=None, dropout=0,
                  out_channels=3, input_dim=1024):
         super().__init__()
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP path")
+        self.dropout = float(dropout)
         self.size, self.dim, self.out_channels = size, dim, out_channels
         N = size * size
         self.pos_emb1D = nn.Parameter(torch.randn(N, dim))

@@ -114,6 +114,17 @@ def join_side_stream():
         _SIDE["dirty"] = False
 
 
+_DROP = {"n": 0}
+
+
+def _drop_seeds(k):
+    """k fresh 32-bit mask seeds for one forward call: torch's seed (torch.manual_seed reproduces a run) + a call counter."""
+    base = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFF
+    out = [(base + 0x632BE5AB * (_DROP["n"] + i + 1)) & 0xFFFFFFFF for i in range(k)]
+    _DROP["n"] += k
+    return out
+
+
 def _grad_buf(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -184,14 +195,21 @@ def _contig(t):
 # ---------------------------------------------------------------------------
 class _LinearFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, W, out_dtype, gn_hw=0):
+    def forward(ctx, x, weight, bias, residual, W, out_dtype, gn_hw=0, drop=0.0):
         cdt = W.sh.dtype
         x = _contig(x)
         rows = x.numel() // W.K
         y = torch.empty(*x.shape[:-1], W.N, dtype=out_dtype or cdt, device=x.device)
-        sums = _gn_request(gn_hw > 0, y, rows // gn_hw if gn_hw else 0, gn_hw, W.N)
-        K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual,
-               gn_sums=None if sums is None else (sums, gn_hw, W.N // 32))
+        ctx.drop = (float(drop), _drop_seeds(1)[0]) if drop else None
+        if ctx.drop:                 # y = residual + dropout(x W^T + b)   (vitgan.py:114,133)
+            K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias)
+            if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
+                raise TypeError("linear(drop>0) with a residual needs the fp32 residual stream")
+            K.dropout(y, ctx.drop[0], ctx.drop[1], residual=residual, out=y)
+        else:
+            sums = _gn_request(gn_hw > 0, y, rows // gn_hw if gn_hw else 0, gn_hw, W.N)
+            K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual,
+                   gn_sums=None if sums is None else (sums, gn_hw, W.N // 32))
         ctx.W, ctx.rows = W, rows
         ctx.train = weight is not None and weight.requires_grad
         ctx.has_res = residual is not None
@@ -204,7 +222,7 @@ class _LinearFn(Function):
         W, rows = ctx.W, ctx.rows
         cdt = W.sh.dtype
         dy = _contig(dy)
-        dyt = _as(dy, cdt)
+        dyt = K.dropout(dy, ctx.drop[0], ctx.drop[1], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
@@ -212,12 +230,13 @@ class _LinearFn(Function):
         if ctx.train:
             (x,) = ctx.saved_tensors
             _wgrad(dyt, x, W, rows)
-        return dx, None, None, (dy if ctx.has_res else None), None, None, None
+        return dx, None, None, (dy if ctx.has_res else None), None, None, None, None
 
 
-def linear(x, W, residual=None, out_dtype=None, gn_hw=0):
-    """gn_hw > 0: the rows are NHWC pixels (gn_hw per image) feeding a GroupNorm(32) next (see conv3x3)."""
-    return _LinearFn.apply(x, W.weight, W.bias, residual, W, out_dtype, gn_hw)
+def linear(x, W, residual=None, out_dtype=None, gn_hw=0, drop=0.0):
+    """gn_hw > 0: the rows are NHWC pixels (gn_hw per image) feeding a GroupNorm(32) next (see conv3x3).
+    drop > 0: nn.Dropout(drop) on the linear's output, before the residual is added."""
+    return _LinearFn.apply(x, W.weight, W.bias, residual, W, out_dtype, gn_hw, drop)
 
 
 # ---------------------------------------------------------------------------
@@ -225,7 +244,7 @@ def linear(x, W, residual=None, out_dtype=None, gn_hw=0):
 # ---------------------------------------------------------------------------
 class _MLPFn(Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, W1, W2, act, out_dtype):
+    def forward(ctx, x, w1, b1, w2, b2, residual, W1, W2, act, out_dtype, drop=0.0):
         cdt = W1.sh.dtype
         x = _contig(x)
         rows = x.numel() // W1.K
@@ -234,7 +253,15 @@ class _MLPFn(Function):
         K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
                flags=K.F_WRITE_PREACT)
         y = torch.empty(*x.shape[:-1], W2.N, dtype=out_dtype or cdt, device=x.device)
-        K.gemm(h, W2.sh, y, rows, W2.N, W2.K, ldx=W2.K, ldw=W2.K, bias=W2.bias, residual=residual)
+        ctx.drop = (float(drop),) + tuple(_drop_seeds(2)) if drop else None
+        if ctx.drop:    # Linear, act, Dropout, Linear, Dropout (mlp_mixer_pytorch.py:16-23, vitgan.py:36-41), then + residual
+            if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
+                raise TypeError("mlp(drop>0) with a residual needs the fp32 residual stream")
+            K.dropout(h, ctx.drop[0], ctx.drop[1], out=h)
+            K.gemm(h, W2.sh, y, rows, W2.N, W2.K, ldx=W2.K, ldw=W2.K, bias=W2.bias)
+            K.dropout(y, ctx.drop[0], ctx.drop[2], residual=residual, out=y)
+        else:
+            K.gemm(h, W2.sh, y, rows, W2.N, W2.K, ldx=W2.K, ldw=W2.K, bias=W2.bias, residual=residual)
         ctx.W1, ctx.W2, ctx.rows, ctx.act = W1, W2, rows, act
         ctx.train = w1 is not None and w1.requires_grad
         ctx.has_res = residual is not None
@@ -248,10 +275,12 @@ class _MLPFn(Function):
         cdt = W1.sh.dtype
         x, h_pre, h = ctx.saved_tensors
         dy = _contig(dy)
-        dyt = _as(dy, cdt)
+        dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         dh = torch.empty_like(h_pre)
         K.gemm(dyt, W2.sht, dh, rows, W2.K, W2.N, ldx=W2.N, ldw=W2.N, aux=h_pre, ldaux=W2.K, act=ctx.act,
                flags=K.F_MUL_ACT_GRAD)
+        if ctx.drop:        # the hidden mask commutes with the element-wise act' factor the epilogue just applied
+            K.dropout(dh, ctx.drop[0], ctx.drop[1], out=dh)
         if ctx.train:
             _wgrad(dyt, h, W2, rows)
             _wgrad(dh, x, W1, rows)
@@ -259,11 +288,12 @@ class _MLPFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
             K.gemm(dh, W1.sht, dx, rows, W1.K, W1.N, ldx=W1.N, ldw=W1.N)
-        return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None, None
+        return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None, None, None
 
 
-def mlp(x, W1, W2, act, residual=None, out_dtype=None):
-    return _MLPFn.apply(x, W1.weight, W1.bias, W2.weight, W2.bias, residual, W1, W2, act, out_dtype)
+def mlp(x, W1, W2, act, residual=None, out_dtype=None, drop=0.0):
+    """drop > 0: nn.Dropout(drop) after the activation and after the second Linear (before the residual add)."""
+    return _MLPFn.apply(x, W1.weight, W1.bias, W2.weight, W2.bias, residual, W1, W2, act, out_dtype, drop)
 
 
 # ---------------------------------------------------------------------------
@@ -273,7 +303,7 @@ def mlp(x, W1, W2, act, residual=None, out_dtype=None):
 # ---------------------------------------------------------------------------
 class _TokenMLPFn(Function):
     @staticmethod
-    def forward(ctx, xn, w1, b1, w2, b2, residual, W1, W2, out_dtype):
+    def forward(ctx, xn, w1, b1, w2, b2, residual, W1, W2, out_dtype, drop=0.0):
         cdt = W1.sh.dtype
         xn = _contig(xn)
         B, T, D = xn.shape
@@ -282,8 +312,10 @@ class _TokenMLPFn(Function):
         ctx.train = w1 is not None and w1.requires_grad
         ctx.has_res = residual is not None
         ctx.dims = (B, T, D, O)
-        ctx.fused = (residual is not None and residual.dtype == torch.float32 and (out_dtype or cdt) == torch.float32 and
-                     W1.bias is not None and W2.bias is not None and K.tokmix_supported(cdt, T, D, O))
+        ctx.drop = (float(drop),) + tuple(_drop_seeds(2)) if drop else None
+        ctx.fused = (not ctx.drop and residual is not None and residual.dtype == torch.float32 and
+                     (out_dtype or cdt) == torch.float32 and W1.bias is not None and W2.bias is not None and
+                     K.tokmix_supported(cdt, T, D, O))
         if ctx.fused:
             # one launch, the hidden activation stays on chip; backward recomputes it (nothing saved but xn)
             ctx.save_for_backward(xn, None, None)
@@ -293,8 +325,16 @@ class _TokenMLPFn(Function):
         K.gemm(W1.sh, xn, h, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, bias=W1.bias, act=ACT_GELU, aux=h_pre, ldaux=D,
                flags=K.F_WRITE_PREACT | K.F_BIAS_ALONG_M, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
         y = torch.empty(B, T, D, dtype=out_dtype or cdt, device=xn.device)
-        K.gemm(W2.sh, h, y, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, bias=W2.bias, residual=residual,
-               flags=K.F_BIAS_ALONG_M, batch=B, wb=(O * D, 0), yb=(T * D, 0), rb=(T * D, 0))
+        if ctx.drop:
+            if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
+                raise TypeError("token_mlp(drop>0) with a residual needs the fp32 residual stream")
+            K.dropout(h, ctx.drop[0], ctx.drop[1], out=h)
+            K.gemm(W2.sh, h, y, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, bias=W2.bias, flags=K.F_BIAS_ALONG_M, batch=B,
+                   wb=(O * D, 0), yb=(T * D, 0))
+            K.dropout(y, ctx.drop[0], ctx.drop[2], residual=None if residual is None else _contig(residual), out=y)
+        else:
+            K.gemm(W2.sh, h, y, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, bias=W2.bias, residual=residual,
+                   flags=K.F_BIAS_ALONG_M, batch=B, wb=(O * D, 0), yb=(T * D, 0), rb=(T * D, 0))
         ctx.save_for_backward(xn if ctx.train else None, h_pre, h if ctx.train else None)
         return y
 
@@ -305,7 +345,7 @@ class _TokenMLPFn(Function):
         B, T, D, O = ctx.dims
         xn, h_pre, h = ctx.saved_tensors
         dy = _contig(dy)
-        dyt = _as(dy, cdt)
+        dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         if ctx.fused:
             h, dh = K.tokmix_bwd_hidden(xn, dyt, W1.sh, W1.bias, W2.sht)
         else:
@@ -313,6 +353,8 @@ class _TokenMLPFn(Function):
             dh = torch.empty_like(h_pre)
             K.gemm(W2.sht, dyt, dh, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, aux=h_pre, ldaux=D, act=ACT_GELU,
                    flags=K.F_MUL_ACT_GRAD, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
+            if ctx.drop:
+                K.dropout(dh, ctx.drop[0], ctx.drop[1], out=dh)
         if ctx.train:
             bk = 64 if cdt in K.LOWP else 32
             seg_ok = D % bk == 0
@@ -336,11 +378,11 @@ class _TokenMLPFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, T, D, dtype=cdt, device=dy.device)
             K.gemm(W1.sht, dh, dx, T, D, O, ldx=O, ldw=D, w_mode=K.OP_TRANS, batch=B, wb=(O * D, 0), yb=(T * D, 0))
-        return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None
+        return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None, None
 
 
-def token_mlp(xn, W1, W2, residual=None, out_dtype=None):
-    return _TokenMLPFn.apply(xn, W1.weight, W1.bias, W2.weight, W2.bias, residual, W1, W2, out_dtype)
+def token_mlp(xn, W1, W2, residual=None, out_dtype=None, drop=0.0):
+    return _TokenMLPFn.apply(xn, W1.weight, W1.bias, W2.weight, W2.bias, residual, W1, W2, out_dtype, drop)
 
 
 # ---------------------------------------------------------------------------
@@ -637,23 +679,24 @@ class _AugmentFn(Function):
     """Fused default augmentation chain on the pooled image (kernels.augment_fwd / augment_bwd)."""
 
     @staticmethod
-    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype):
+    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None):
         pooled = _contig(pooled)
         ctx.save_for_backward(pinv, ainv, cmat, erase)
         ctx.cfg = (pooled.shape[0], pooled.shape[2], cutn, patch, std)
-        return K.augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
+        return K.augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs,
+                             coff=coff)
 
     @staticmethod
     def backward(ctx, g):
         pinv, ainv, cmat, erase = ctx.saved_tensors
         B, S, cutn, patch, std = ctx.cfg
-        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std),) + (None,) * 11
+        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std),) + (None,) * 12
 
 
 def augment(pooled, params, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
     """pooled: (B,3,S,S) fp32 -> ViT patch rows (cutn*B, (S/patch)^2, 3*patch^2); params from augment.draw_params."""
     return _AugmentFn.apply(pooled, noise, facs, params["pinv"], params["ainv"], params["cmat"], params["erase"], cutn,
-                            patch, mean, std, out_dtype)
+                            patch, mean, std, out_dtype, params.get("coff"))
 
 
 class _PatchEmbedFn(Function):

@@ -258,7 +258,7 @@ int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr,
  * pinv [N,9] inverse perspective homography, ainv [N,6] inverse affine (pixel units), cmat [N,9] RGB colour matrix,
  * erase [N,4] int32 rectangle x0,y0,x1,y1 (x1 <= x0: none).  kornia 0.5.10 itself is absent: parity unpinned.
  * The backward scatters into dpooled [B,3,S,S] (zeroed inside); chain it with ffvc_cutouts_bwd(cutn 1, patch S). */
-int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const int32_t* erase,
+int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff /* (N,3) colour offset added after cmat, may be NULL */, const int32_t* erase,
                      const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int cutn, int patch,
                      float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
@@ -278,6 +278,11 @@ int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int sh
 /* clip_grad_norm_ (main.py:833-834) without a host round trip: out[0] = min(1, max_norm / (sqrt(sumsq[0])*|grad_scale|
  * + 1e-6)) (feed it to ffvc_adam's dev_scale), out[1] = the total norm. */
 int ffvc_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* out, void* stream);
+/* nn.Dropout of the mapper MLPs / attention outputs (mlp_mixer_pytorch.py:20-22; vitgan.py:34-41,114,133):
+ * y[i] = (residual ? residual[i] : 0) + (keep(seed, i) ? x[i] / (1 - p) : 0).  The mask is a counter-based hash of
+ * (seed, i): the backward pass calls the same function on the gradient with the same seed.  x may alias y. */
+int ffvc_dropout(const void* x, int x_dtype, const float* residual, void* y, int y_dtype, int64_t n, float p, uint32_t seed,
+                 void* stream);
 /* Optional regularisers of the step: l2 = mean(z^2) (main.py:758-762) and tv_loss (main.py:423-428,769-773) on the
  * NHWC fp32 image batch; backward kernels take the upstream scalar gradient from device memory (g[0]). */
 int ffvc_mean_sq(const float* x, float* out, int64_t n, void* stream);

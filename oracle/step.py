@@ -107,7 +107,7 @@ def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_s
     else:                                                                               # default augs, explicit parameters
         pooled = (F.adaptive_avg_pool2d(xr, cut_size) + F.adaptive_max_pool2d(xr, cut_size)) / 2   # :217
         x = augment_reference(pooled, aug_params["pinv"], aug_params["ainv"], aug_params["cmat"], aug_params["erase"], cutn,
-                              facs, noise)
+                              facs, noise, coff=aug_params.get("coff"))
     mean = torch.tensor(CLIP_MEAN, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     std = torch.tensor(CLIP_STD, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     x = (x - mean) / std                                                                # :797
@@ -127,7 +127,7 @@ def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-8):
         p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None):
+def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None):
     """Plain-PyTorch statement of ffvc_augment_fwd (the fused Af -> Pe -> Ji -> Er chain of main.py:164-198 with
     explicit per-cutout parameters): returns (cutn*B, 3, S, S) BEFORE mean/std normalisation.  kornia itself is not
     restated (absent offline, parity unpinned); this pins the HIP kernel to the documented resampling formula."""
@@ -156,6 +156,8 @@ def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=No
         wy[:, None] * ((1 - wx)[:, None] * tap(1, 0) + wx[:, None] * tap(1, 1))
     val = val * m[:, None]
     out = torch.einsum("nij,njhw->nihw", cmat.view(N, 3, 3).to(pooled.dtype), val)
+    if coff is not None:
+        out = out + coff.view(N, 3, 1, 1).to(pooled.dtype)
     e = erase.view(N, 4)
     er = (xs[None] >= e[:, 0].view(N, 1, 1)) & (xs[None] < e[:, 2].view(N, 1, 1)) & \
          (ys[None] >= e[:, 1].view(N, 1, 1)) & (ys[None] < e[:, 3].view(N, 1, 1))

@@ -50,3 +50,65 @@ def test_reference_identity_and_gradient():
     assert torch.allclose(out, pooled.repeat(cutn, 1, 1, 1))
     out.sum().backward()
     assert torch.allclose(pooled.grad, torch.full_like(pooled, float(cutn)))
+
+
+def test_wider_augmentation_set_parameters():
+    """Ro / Re / Re2 / Cr / Cc / Ji2 / Er2 / Gn (main.py:166-198) as parameters of the same fused resampling kernel."""
+    g = torch.Generator().manual_seed(4)
+    N, S = 3000, 64
+    eye = torch.eye(3).reshape(9)
+    prm = A.draw_params(N, S, augs=("Ro",), generator=g)
+    Hi = prm["pinv"].view(N, 3, 3)
+    on = (prm["pinv"] - eye).abs().sum(1) > 1e-6
+    assert abs(on.float().mean().item() - 0.7) < 0.04
+    ang = torch.rad2deg(torch.atan2(Hi[:, 1, 0], Hi[:, 0, 0]))[on]
+    assert ang.abs().max() <= 15.01 and ang.abs().max() > 13
+    c = torch.tensor([(S - 1) / 2, (S - 1) / 2, 1.0])
+    assert ((Hi @ c)[:, :2] - c[:2]).abs().max() < 1e-3                   # rotation about the image centre
+    assert (prm["ainv"] - torch.tensor([1.0, 0, 0, 0, 1.0, 0])).abs().max() == 0
+    # resized crops: axis-aligned, inverse map sends the output corners INTO the source image, area fraction in range
+    for name, lo in (("Re", 0.1), ("Re2", 0.9)):
+        prm = A.draw_params(N, S, augs=(name,), generator=g)
+        Hi = prm["pinv"].view(N, 3, 3).double()
+        assert Hi[:, 0, 1].abs().max() < 1e-6 and Hi[:, 1, 0].abs().max() < 1e-6
+        w, h = Hi[:, 0, 0] * (S - 1) + 1, Hi[:, 1, 1] * (S - 1) + 1         # crop size in source pixels
+        frac = w * h / (S * S)
+        assert frac.min() > lo * 0.85 and frac.max() <= 1.0 + 1e-6
+        x0, y0 = Hi[:, 0, 2], Hi[:, 1, 2]
+        assert x0.min() > -1e-6 and (x0 + w - 1).max() < S - 1 + 1e-3 and y0.min() > -1e-6
+    # identities
+    prm = A.draw_params(16, S, augs=("Cr", "Cc"), generator=g)
+    assert (prm["pinv"] - eye).abs().max() < 1e-6 and prm["coff"].abs().max() == 0
+    # Ji2: p = 0.5, brightness offset within +-0.1 (scaled by contrast <= 1.1), greys stay grey up to the offset
+    prm = A.draw_params(N, S, augs=("Ji2",), generator=g)
+    on = (prm["cmat"] - eye).abs().sum(1) > 1e-6
+    assert abs(on.float().mean().item() - 0.5) < 0.04
+    assert prm["coff"].abs().max() <= 0.1 * 1.1 + 1e-6 and prm["coff"][~on].abs().max() == 0
+    grey = prm["cmat"].view(N, 3, 3) @ torch.ones(3)
+    assert (grey.max(1).values - grey.min(1).values).max() < 1e-3 and grey.min() > 0.89 and grey.max() < 1.11
+    # Er2: independent rectangles, p = 0.7;  Gn: p = 0.5
+    prm = A.draw_params(N, S, augs=("Er2", "Gn"), generator=g)
+    e = prm["erase"]
+    has = (e[:, 2] > e[:, 0])
+    assert abs(has.float().mean().item() - 0.7) < 0.04 and not (e[has] == e[has][0]).all()
+    assert abs(prm["gn"].mean().item() - 0.5) < 0.04 and set(prm["gn"].unique().tolist()) == {0.0, 1.0}
+    # order of composition: 'Af' that is not first moves into the (zero padded) homography
+    prm = A.draw_params(64, S, augs=("Ro", "Af"), generator=g, p=1.0)
+    assert (prm["ainv"] - torch.tensor([1.0, 0, 0, 0, 1.0, 0])).abs().max() == 0
+    import pytest
+    with pytest.raises(NotImplementedError):
+        A.draw_params(4, S, augs=("Sh",))
+
+
+def test_reference_colour_offset_and_erase_per_sample():
+    S, B, cutn = 16, 2, 2
+    g = torch.Generator().manual_seed(2)
+    pooled = torch.rand(B, 3, S, S, generator=g, dtype=torch.float64)
+    prm = A.draw_params(cutn * B, S, augs=(), generator=g)
+    prm["coff"][:] = torch.tensor([0.1, -0.2, 0.05])
+    prm["erase"][1] = torch.tensor([2, 3, 7, 9], dtype=torch.int32)
+    out = ostep.augment_reference(pooled, prm["pinv"].double(), prm["ainv"].double(), prm["cmat"].double(), prm["erase"], cutn,
+                                  coff=prm["coff"].double())
+    ref = pooled.repeat(cutn, 1, 1, 1) + torch.tensor([0.1, -0.2, 0.05], dtype=torch.float64).view(1, 3, 1, 1)
+    ref[1, :, 3:9, 2:7] = 0
+    assert torch.allclose(out, ref, atol=1e-6)

@@ -293,3 +293,95 @@ def test_train_checkpoint_resume_load_model_and_test_cli(cuda, tmp_path):
     assert Image.open(out).size == (2 * 258 + 2, 3 * 258 + 2)
     assert fmain._cli(["test", str(tmp_path / "checkpoint.th"), "synthetic:2", "--out-path", str(tmp_path / "g2.png")]) == 0
     assert os.path.exists(tmp_path / "g2.png")
+
+
+# ----------------------------------------------------------------------------- the wider augmentation set
+def test_step_with_wider_augmentation_set_matches_oracle(cuda):
+    """augs: ['Ro','Re2','Ji2','Er2','Gn','Cc'] (main.py:166-198) run through the same fused resampling kernel; the drawn
+    parameters are handed to the oracle's statement of that formula (kornia itself is unpinned, see augment.py)."""
+    from feed_forward_vqgan_clip_amd import augment as A
+    augs = ["Ro", "Re2", "Ji2", "Er2", "Gn", "Cc"]
+    cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _setup(augs=augs)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    assert stepper.make_cutouts.augs == tuple(augs)
+    prm = A.draw_params(16, 32, augs=tuple(augs), generator=torch.Generator().manual_seed(8))
+    assert prm["coff"].abs().max() > 0 and prm["gn"].max() == 1 and (prm["erase"][:, 2] > prm["erase"][:, 0]).any()
+    msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(),
+                                     aug_params={k: v.cuda() for k, v in prm.items()})
+    opt.zero_grad()
+    loss.backward()
+    from oracle import mappers as omap
+    from oracle import step as ostep
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    facs_eff = torch.sqrt(facs * facs + prm["gn"] ** 2)                 # 'Gn' merged with the U(0,.1)*N(0,1) term
+    oloss, _ = ostep.train_step_loss(lambda sd, f: omap.mixer_forward(sd, f, image_size=12, channels=64, depth=2), osd, vq_sd,
+                                     clip_sd, tok, cutn=4, cut_size=32, z_min=vq.z_min, z_max=vq.z_max,
+                                     facs=facs_eff, noise=noise, vq_cfg=TINY_VQ, aug_params=prm)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) / oloss.item() < 1e-4
+    _check_grads(net, osd, tol=5e-3)
+    # unsupported names fail loudly at construction
+    with pytest.raises(NotImplementedError):
+        fmain.MakeCutouts(32, 4, augs=["Sh"])
+
+
+# ----------------------------------------------------------------------------- dropout in the mappers
+def test_dropout_kernel_statistics_and_mask_reuse(cuda):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1 << 20, generator=g).cuda()
+    res = torch.randn(1 << 20, generator=g).cuda()
+    p = 0.3
+    y = K.dropout(x, p, 1234)
+    keep = y != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 3e-3
+    assert torch.allclose(y[keep], x[keep] / (1 - p), rtol=1e-6)
+    assert torch.equal(K.dropout(x, p, 1234), y)                              # same seed -> same mask (what backward relies on)
+    assert not torch.equal(K.dropout(x, p, 1235) != 0, keep)                  # another seed -> another mask
+    yr = K.dropout(x, p, 1234, residual=res)
+    assert torch.allclose(yr, y + res, atol=1e-6)
+    x16 = x.half()
+    y16 = K.dropout(x16, p, 1234)
+    assert torch.equal(y16 != 0, keep | (x16 == 0)) or ((y16 != 0) == keep).float().mean() > 0.9999
+    assert torch.equal(K.dropout(x, 0.0, 7), x)                               # p = 0 is the identity
+
+
+@pytest.mark.parametrize("kind", ["mlp_mixer", "vitgan"])
+def test_mapper_dropout_train_eval_and_gradient(cuda, kind):
+    """dropout > 0 (mlp_mixer_pytorch.py:20-22, vitgan.py:34-41,133): active in train mode (the reference never calls
+    .eval() while training), off in eval mode; the backward pass regenerates the forward masks — checked against a
+    central finite difference of the (fp32, fixed-seed) forward."""
+    from feed_forward_vqgan_clip_amd.mappers import Generator, Mixer
+    torch.manual_seed(3)
+    if kind == "mlp_mixer":
+        mk = lambda p: Mixer(input_dim=16, image_size=4, channels=8, patch_size=1, dim=32, depth=2, dropout=p)  # noqa: E731
+    else:
+        mk = lambda p: Generator(initialize_size=1, out_channels=8, input_dim=16, dim=24, num_heads=6, blocks=2, dropout=p)  # noqa: E731
+    net0 = mk(0.0)
+    net = mk(0.25)
+    net.load_state_dict(net0.state_dict())
+    net0, net = net0.cuda().prepare(F32), net.cuda().prepare(F32)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(6, 16, generator=g).cuda()
+    with torch.no_grad():
+        y0 = net0(x)
+        ya, yb = net(x), net(x)
+        assert (ya - yb).abs().max() > 1e-4 and (ya - y0).abs().max() > 1e-4          # train mode: fresh masks each call
+        net.eval()
+        assert torch.allclose(net(x), y0, atol=1e-5)                                  # eval mode: dropout off
+        net.train()
+    gw = torch.randn(*y0.shape, generator=g).cuda()
+    v = torch.randn(6, 16, generator=g).cuda()
+
+    def f(xx):
+        ops._DROP["n"] = 1000                                                        # same masks for every evaluation
+        return net(xx)
+    xg = x.clone().requires_grad_(True)
+    net._ffvc_arena.zero_grad()
+    (f(xg) * gw).sum().backward()
+    eps = 1e-2
+    with torch.no_grad():
+        fd = ((f(x + eps * v) - f(x - eps * v)) * gw).sum().item() / (2 * eps)
+    an = (xg.grad * v).sum().item()
+    assert abs(fd - an) / (abs(fd) + 1e-6) < 2e-2, (fd, an)
+    assert all(torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in net.parameters())
