@@ -347,6 +347,7 @@ def main():
         # rank runs it (its gradient all-reduces are collectives: a step on rank 0 alone would hang the others); only
         # rank 0 keeps the per-launch events
         K.PROFILE = [] if rank == 0 else None
+        K.HBM_PROFILE = [] if rank == 0 else None
         stepper(toks[:B])
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
@@ -370,21 +371,39 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         name, (n, flops, secs) = dom
         peak = 157.3 if name.endswith("f32") else PEAK_BF16_TFLOPS
-        traffic, traffic_src = None, None
-        try:     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if name in pmc:
-                traffic, traffic_src = pmc[name]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        # HBM bytes per launch come from rocprofv3 PMC passes (bench.py cannot run the profiler itself): the committed JSON
+        # is stamped with the sha256 of the library it was measured on; a different library -> the number is stale -> null
+        traffic, traffic_src, traffic_stale = None, None, None
+        try:
+            import hashlib
+            from feed_forward_vqgan_clip_amd import _lib as flib
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            cls = name.rsplit("_", 1)[0]
+            if cls in pmc:
+                traffic_src = "profiles/r02_pmc_traffic.json"
+                traffic_stale = pmc.get("_lib_sha256") != hashlib.sha256(open(flib.LIB_PATH, "rb").read()).hexdigest()
+                if not traffic_stale:
+                    traffic = pmc[cls]["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         out["roofline"] = {"bound": "mfma", "kernel": name, "launches_per_step": n,
                            "avg_launch_ms": secs / n * 1e3, "achieved": flops / secs / 1e12, "peak": peak,
                            "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": traffic,
                            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                           "traffic_source": traffic_src, "flop_per_launch": flops / n}
+                           "traffic_source": traffic_src, "traffic_stale": traffic_stale, "flop_per_launch": flops / n}
         out["kernel_classes"] = {k: {"launches": v[0], "ms": v[2] * 1e3, "tflops": v[1] / max(v[2], 1e-12) / 1e12}
                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
         out["gemm_ms_per_step"] = sum(v[2] for v in agg.values()) * 1e3
+        hb, K.HBM_PROFILE = K.HBM_PROFILE, None
+        hagg = {}
+        for hname, nbytes, e0, e1 in hb or []:
+            a = hagg.setdefault(hname, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += nbytes
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        # HBM-bound kernels of the step: algorithmic bytes / HIP-event time, against the 8 TB/s HBM3E peak
+        out["hbm_kernels"] = {k_: {"launches": v[0], "ms": v[2] * 1e3, "GB/s": v[1] / max(v[2], 1e-12) / 1e9,
+                                   "frac_of_8TBps": v[1] / max(v[2], 1e-12) / 8e12} for k_, v in hagg.items()}
     if world > 1:
         torch.distributed.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -31,6 +31,28 @@ _GEMM_CLASS = {(OP_KMAJOR, OP_KMAJOR): "gemm_nt", (OP_CONV3X3, OP_KMAJOR): "conv
                (OP_KMAJOR, OP_TRANS): "gemm_nn", (OP_TRANS, OP_KMAJOR): "gemm_tk"}
 
 
+# Optional per-launch timing of the HBM-bound kernels (bench.py `hbm_kernels`): when HBM_PROFILE is a list, the launchers
+# below bracket their kernel with HIP events on the launch stream and append (name, algorithmic bytes, events).
+HBM_PROFILE = None
+
+
+class _hbm:
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if HBM_PROFILE is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if HBM_PROFILE is not None:
+            self.e1.record()
+            HBM_PROFILE.append((self.name, float(self.nbytes), self.e0, self.e1))
+        return False
+
+
 def dtype_code(dt):
     if dt == torch.bfloat16:
         return BF16
@@ -169,8 +191,9 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _call("ffvc_layernorm_fwd", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-          dtype_code(out_dtype), mean.data_ptr(), rstd.data_ptr(), rows, dim, eps, stream_ptr())
+    with _hbm("layernorm_fwd", x.numel() * (x.element_size() + y.element_size())):
+        _call("ffvc_layernorm_fwd", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+              dtype_code(out_dtype), mean.data_ptr(), rstd.data_ptr(), rows, dim, eps, stream_ptr())
     return y, mean, rstd
 
 
@@ -219,9 +242,12 @@ def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_l
     if dgamma.dtype != torch.float32 or dbeta.dtype != torch.float32 or not dgamma.is_contiguous() or not dbeta.is_contiguous():
         raise TypeError("layernorm_bwd_acc: gradients must be contiguous fp32")
     lo = _dx_lo(x, want_lo, dy.dtype)
-    _call("ffvc_layernorm_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
-          gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
-          dbeta.data_ptr(), _ptr(lo), rows, dim, stream_ptr())
+    nb = x.numel() * (dy.element_size() + 2 * x.element_size() + (x.element_size() if dres is not None else 0) +
+                      (2 if lo is not None else 0))
+    with _hbm("layernorm_bwd", nb):
+        _call("ffvc_layernorm_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), dtype_code(x.dtype),
+              gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
+              dbeta.data_ptr(), _ptr(lo), rows, dim, stream_ptr())
     if lo is not None:
         dx._ffvc_lo = lo
     return dx
@@ -255,8 +281,9 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None):
     if sums is not None:
         if sums.dtype != torch.float64 or tuple(sums.shape) != (B, G, 2):
             raise TypeError("groupnorm_fwd: sums must be fp64 [B, G, 2]")
-        _call("ffvc_groupnorm_fwd_sums", x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-              rstd.data_ptr(), sums.data_ptr(), B, HW, C, G, eps, int(swish), dtype_code(x.dtype), stream_ptr())
+        with _hbm("groupnorm_fwd", 2 * x.numel() * x.element_size()):
+            _call("ffvc_groupnorm_fwd_sums", x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), sums.data_ptr(), B, HW, C, G, eps, int(swish), dtype_code(x.dtype), stream_ptr())
         return y, mean, rstd
     ws = _gn_ws(B, HW, G, x.device)
     _call("ffvc_groupnorm_fwd", x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
@@ -272,9 +299,11 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True):
     HW = x.numel() // (B * C)
     dx = torch.empty_like(x)
     ws = _gn_ws(B, HW, G, x.device)
-    _call("ffvc_groupnorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-          rstd.data_ptr(), _ptr(dres), dx.data_ptr(), ws.data_ptr(), B, HW, C, G, int(swish), dtype_code(x.dtype),
-          stream_ptr())
+    # algorithmic bytes of the two-pass backward: statistics (dy, x) + apply (dy, x, dres, dx)
+    with _hbm("groupnorm_bwd", x.numel() * x.element_size() * (5 + (1 if dres is not None else 0))):
+        _call("ffvc_groupnorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), _ptr(dres), dx.data_ptr(), ws.data_ptr(), B, HW, C, G, int(swish), dtype_code(x.dtype),
+              stream_ptr())
     return dx
 
 
@@ -519,9 +548,10 @@ def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0, ema=No
     dev_scale (fp32 device scalar): multiplied into grad_scale on the device (clip_grad_norm_ coefficient)."""
     _req_f32(p, g, m, v, ema, dev_scale)
     _need_cuda(shadow)
-    _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
-          dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
-          _ptr(ema), float(ema_weight), _ptr(dev_scale), stream_ptr())
+    with _hbm("adam", p.numel() * (28 + (shadow.element_size() if shadow is not None else 0) + (8 if ema is not None else 0))):
+        _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
+              dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
+              _ptr(ema), float(ema_weight), _ptr(dev_scale), stream_ptr())
 
 
 def clip_coef(sumsq_buf, max_norm, grad_scale):

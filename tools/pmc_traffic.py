@@ -20,15 +20,29 @@ def per_kernel(d, counter):
     return agg, cnt
 
 
-CLASSES = {   # bench.py's GEMM classes -> kernel-name patterns
-    "gemm_nt_bf16": r"gemm2p?_kernel<0, 0,",
-    "conv3x3_bf16": r"conv_row_kernel|gemm2p?_kernel<2, 0,",
-    "gemm_nn_bf16": r"gemm2p?_kernel<0, 1,",
-    "gemm_tn_bf16": r"gemm_kernel<(unsigned short|bf16), 1, 1",
+CLASSES = {   # bench.py's GEMM classes (dtype suffix stripped) -> kernel-name patterns, demangled or mangled (rocprofv3 does
+    # not demangle the _Float16 instantiations: gemm2_kernelIDF16_Li0ELi0E...)
+    "gemm_nt": r"gemm[28]p?_kernel<[^,]*, ?0, 0,|gemm2p?_kernelI(DF16_|t)Li0ELi0E|gemm8_kernelI(DF16_|t)Li0E",
+    "conv3x3": r"conv_row_kernel|gemm2p?_kernel<[^,]*, ?2, 0,|gemm2p?_kernelI(DF16_|t)Li2ELi0E",
+    "gemm_nn": r"gemm2p?_kernel<[^,]*, ?0, 1,|gemm2p?_kernelI(DF16_|t)Li0ELi1E",
+    "gemm_tn": r"gemm_kernel<[^,]*, 1, 1|gemm_kernelI(DF16_|t)Li1ELi1E|gemm2p?_kernel<[^,]*, ?1, 1,|gemm2p?_kernelI(DF16_|t)Li1ELi1E",
+    "tokmix": r"tokmix_(fwd|bwd_hidden)_kernel",
 }
 fa, fc = per_kernel(sys.argv[1], "FETCH_SIZE")
 wa, wc = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py "
+import hashlib
+import os
+import subprocess
+
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = os.path.join(_root, "feed_forward_vqgan_clip_amd", "lib", "libffvc_hip.so")
+_sha = hashlib.sha256(open(_lib, "rb").read()).hexdigest() if os.path.exists(_lib) else None
+try:
+    _head = subprocess.run(["git", "-C", _root, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    _head = None
+out = {"_lib_sha256": _sha, "_git_head": _head,
+       "_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py "
                       "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline; per-kernel-class dispatch-weighted averages; "
                       "counter unit KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE uncorrected."}
 for cls, pat in CLASSES.items():
