@@ -92,6 +92,9 @@ _SIGNATURES = {
                                    c_int, c_float, c_void_p]),
     "ffvc_attn_small_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ffvc_attn_flash_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "ffvc_attn_flash_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_float, c_int, c_void_p]),
     "ffvc_transpose_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ffvc_layernorm_bwd_blocks": (c_int, [c_int64]),
     "ffvc_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

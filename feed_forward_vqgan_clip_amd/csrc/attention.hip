@@ -309,6 +309,277 @@ __global__ __launch_bounds__(64, 2) void attn_small_bwd_kernel(const uint16_t* _
   store_transposed<L, 2>(dK, ld, dKT, 0, T, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Flash-style attention for ANY sequence length (head dim 64): the x-transformer mapper's causal self-attention
+// (transformer.py:11-20, 1024 tokens at cfg4) and ViT-L/14's 257-token attention (cfg5).  Same transposed-tile scheme
+// as the short-sequence kernels above, with a loop over 64-key blocks and online softmax: no score matrix in HBM,
+// causal blocks above the diagonal are never visited.  One wave owns 64 queries (forward, dQ) or 64 keys (dK, dV).
+// The forward keeps lse[query] = log2(sum_k exp(scale * s_k)) (base-2 units) so the backward re-derives the
+// probabilities as exp2(scale*log2e*s - lse) without a second statistics pass.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr float NEG_BIG = -3.0e38f;
+
+template <typename L, bool CAUSAL>
+__global__ __launch_bounds__(64) void attn_flash_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[PANEL];
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const int q0 = 64 * blockIdx.x;
+  const float c = scale * LOG2E;
+
+  u32x4_t fq[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fq[qt][s] = rowfrag(Q, ld, q0 + 32 * qt + l31, T, s, h);
+  f32x16_t OT[2][2];
+  zero_tiles(OT);
+  float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.0f, 0.0f};
+  const int nkb = CAUSAL ? (int)blockIdx.x + 1 : (T + 63) / 64;
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = 64 * kb;
+    __syncthreads();
+    stage_transposed(Vt, V + (int64_t)k0 * ld, ld, T - k0, lane);
+    f32x16_t ST[2][2];
+    zero_tiles(ST);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4_t fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = rowfrag(Kp, ld, k0 + 32 * a + l31, T, s, h);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) mma(ST[a][qt], fa[a], fq[qt][s]);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = q0 + 32 * qt + l31;
+      const int klim = CAUSAL ? min(T, q + 1) : T;          // keys < klim are visible to this lane's query
+      float mloc = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + 32 * kt + reg_index(r, h) < klim) mloc = fmaxf(mloc, ST[kt][qt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(m[qt], mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m[qt] - mnew) * c);
+      float sum = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p =
+              (k0 + 32 * kt + reg_index(r, h) < klim) ? __builtin_amdgcn_exp2f((ST[kt][qt][r] - mnew) * c) : 0.0f;
+          ST[kt][qt][r] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      l[qt] = l[qt] * alpha + sum;
+      m[qt] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) OT[dt][qt][r] *= alpha;
+    }
+    __syncthreads();
+    lds_product<L, 2, 2>(OT, Vt, ST, 0, lane);
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float inv = l[qt] > 0.0f ? 1.0f / l[qt] : 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) OT[dt][qt][r] *= inv;
+    const int q = q0 + 32 * qt + l31;
+    if (h == 0 && q < T) lse[(int64_t)bh * T + q] = m[qt] * c + __builtin_amdgcn_logf(l[qt]);   // v_log_f32 = log2
+  }
+  store_transposed<L, 2>(o + (int64_t)b * T * D + hd * 64, D, OT, q0, T, lane);
+}
+
+// dQ for one 64-query block (lane = query); also writes delta[query] = sum_d dO O for the dK / dV kernel.
+template <typename L, bool CAUSAL>
+__global__ __launch_bounds__(64) void attn_flash_bwd_dq_kernel(const uint16_t* __restrict__ qkv,
+                                                               const uint16_t* __restrict__ out,
+                                                               const uint16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, float* __restrict__ delta,
+                                                               uint16_t* __restrict__ dqkv, int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t Kt[PANEL];
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const uint16_t* O = out + (int64_t)b * T * D + hd * 64;
+  const uint16_t* dO = dout + (int64_t)b * T * D + hd * 64;
+  const int q0 = 64 * blockIdx.x;
+  const float c = scale * LOG2E;
+
+  u32x4_t fq[2][4], fdo[2][4];
+  float dl[2], ls[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + 32 * qt + l31;
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fq[qt][s] = rowfrag(Q, ld, q, T, s, h);
+      fdo[qt][s] = rowfrag(dO, D, q, T, s, h);
+      const u32x4_t fo = rowfrag(O, D, q, T, s, h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += lo_unpack<L>((uint16_t)(fo[e] & 0xffffu)) * lo_unpack<L>((uint16_t)(fdo[qt][s][e] & 0xffffu));
+        acc += lo_unpack<L>((uint16_t)(fo[e] >> 16)) * lo_unpack<L>((uint16_t)(fdo[qt][s][e] >> 16));
+      }
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    dl[qt] = acc;
+    ls[qt] = q < T ? lse[(int64_t)bh * T + q] : 0.0f;
+    if (h == 0 && q < T) delta[(int64_t)bh * T + q] = acc;
+  }
+  f32x16_t dQT[2][2];
+  zero_tiles(dQT);
+  const int nkb = CAUSAL ? (int)blockIdx.x + 1 : (T + 63) / 64;
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = 64 * kb;
+    __syncthreads();
+    stage_transposed(Kt, Kp + (int64_t)k0 * ld, ld, T - k0, lane);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16_t PT[1][2], dPT[1][2];
+      zero_tiles(PT);
+      zero_tiles(dPT);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4_t fk = rowfrag(Kp, ld, k0 + 32 * kt + l31, T, s, h);
+        const u32x4_t fv = rowfrag(V, ld, k0 + 32 * kt + l31, T, s, h);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          mma(PT[0][qt], fk, fq[qt][s]);
+          mma(dPT[0][qt], fv, fdo[qt][s]);
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 32 * qt + l31;
+        const int klim = q < T ? (CAUSAL ? min(T, q + 1) : T) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p =
+              (k0 + 32 * kt + reg_index(r, h) < klim) ? __builtin_amdgcn_exp2f(PT[0][qt][r] * c - ls[qt]) : 0.0f;
+          dPT[0][qt][r] = p * (dPT[0][qt][r] - dl[qt]) * scale;          // dS^T[key][query]
+        }
+      }
+      // dQ^T[d][query] += sum_key K^T[d][key] dS^T[key][query]
+      lds_product<L, 1, 2>(dQT, Kt, dPT, 32 * kt, lane);
+    }
+  }
+  store_transposed<L, 2>(dqkv + (int64_t)b * T * ld + hd * 64, ld, dQT, q0, T, lane);
+}
+
+// dK, dV for one 64-key block (lane = key), walking the query blocks that see it.
+template <typename L, bool CAUSAL>
+__global__ __launch_bounds__(64) void attn_flash_bwd_dkv_kernel(const uint16_t* __restrict__ qkv,
+                                                                const uint16_t* __restrict__ dout,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ delta,
+                                                                uint16_t* __restrict__ dqkv, int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t dOt[PANEL];    // dO^T[d][query]
+  __shared__ __attribute__((aligned(16))) uint16_t Qt[PANEL];     // Q^T[d][query]
+  __shared__ __attribute__((aligned(16))) float stat[2][64];      // lse, delta of the current query block
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const uint16_t* dO = dout + (int64_t)b * T * D + hd * 64;
+  const int k0 = 64 * blockIdx.x;
+  const float c = scale * LOG2E;
+
+  u32x4_t fk[2][4], fv[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fk[kt][s] = rowfrag(Kp, ld, k0 + 32 * kt + l31, T, s, h);
+      fv[kt][s] = rowfrag(V, ld, k0 + 32 * kt + l31, T, s, h);
+    }
+  f32x16_t dVT[2][2], dKT[2][2];               // [d tile][key tile]
+  zero_tiles(dVT);
+  zero_tiles(dKT);
+  const int nqb = (T + 63) / 64;
+#pragma unroll 1
+  for (int qb = CAUSAL ? (int)blockIdx.x : 0; qb < nqb; ++qb) {
+    const int q0 = 64 * qb;
+    __syncthreads();
+    stage_transposed(dOt, dO + (int64_t)q0 * D, D, T - q0, lane);
+    stage_transposed(Qt, Q + (int64_t)q0 * ld, ld, T - q0, lane);
+    {
+      const int q = q0 + lane;
+      stat[0][lane] = q < T ? lse[(int64_t)bh * T + q] : 0.0f;
+      stat[1][lane] = q < T ? delta[(int64_t)bh * T + q] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
+      if (q0 + 32 * qt >= T) break;
+      f32x16_t S[1][2], dP[1][2];              // [.][key tile], registers = queries of tile qt
+      zero_tiles(S);
+      zero_tiles(dP);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4_t fa = rowfrag(Q, ld, q0 + 32 * qt + l31, T, s, h);
+        const u32x4_t fb = rowfrag(dO, D, q0 + 32 * qt + l31, T, s, h);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          mma(S[0][kt], fa, fk[kt][s]);
+          mma(dP[0][kt], fb, fv[kt][s]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qi = 32 * qt + 8 * g + 4 * h;
+        const f32x4_t l4 = *(const f32x4_t*)&stat[0][qi];
+        const f32x4_t d4 = *(const f32x4_t*)&stat[1][qi];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const int key = k0 + 32 * kt + l31;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const int q = q0 + qi + j;
+            const bool ok = key < T && q < T && (!CAUSAL || key <= q);
+            const float p = ok ? __builtin_amdgcn_exp2f(S[0][kt][r] * c - l4[j]) : 0.0f;
+            S[0][kt][r] = p;                                           // P[query][key]
+            dP[0][kt][r] = p * (dP[0][kt][r] - d4[j]) * scale;         // dS[query][key]
+          }
+        }
+      }
+      lds_product<L, 1, 2>(dVT, dOt, S, 32 * qt, lane);
+      lds_product<L, 1, 2>(dKT, Qt, dP, 32 * qt, lane);
+    }
+  }
+  uint16_t* dKp = dqkv + (int64_t)b * T * ld + hd * 64 + D;
+  store_transposed<L, 2>(dKp + D, ld, dVT, k0, T, lane);
+  store_transposed<L, 2>(dKp, ld, dKT, k0, T, lane);
+}
+
 #undef mma
 
 }  // namespace
@@ -344,6 +615,72 @@ extern "C" int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv
   else
     hipLaunchKernelGGL(attn_small_bwd_kernel<uint16_t>, dim3(B * heads), dim3(64), 0, (hipStream_t)stream,
                        (const uint16_t*)qkv, (const uint16_t*)dout, (uint16_t*)dqkv, T, heads, scale);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename L>
+static void flash_fwd_launch(const void* qkv, void* out, float* lse, int B, int T, int heads, float scale, int causal,
+                             hipStream_t st) {
+  const dim3 grid((T + 63) / 64, B * heads);
+  if (causal)
+    hipLaunchKernelGGL((attn_flash_fwd_kernel<L, true>), grid, dim3(64), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse, T,
+                       heads, scale);
+  else
+    hipLaunchKernelGGL((attn_flash_fwd_kernel<L, false>), grid, dim3(64), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse, T,
+                       heads, scale);
+}
+
+template <typename L>
+static void flash_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                             int B, int T, int heads, float scale, int causal, hipStream_t st) {
+  const dim3 grid((T + 63) / 64, B * heads);
+  if (causal) {
+    hipLaunchKernelGGL((attn_flash_bwd_dq_kernel<L, true>), grid, dim3(64), 0, st, (const uint16_t*)qkv, (const uint16_t*)out,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, T, heads, scale);
+    hipLaunchKernelGGL((attn_flash_bwd_dkv_kernel<L, true>), grid, dim3(64), 0, st, (const uint16_t*)qkv,
+                       (const uint16_t*)dout, lse, (const float*)delta, (uint16_t*)dqkv, T, heads, scale);
+  } else {
+    hipLaunchKernelGGL((attn_flash_bwd_dq_kernel<L, false>), grid, dim3(64), 0, st, (const uint16_t*)qkv,
+                       (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, T, heads, scale);
+    hipLaunchKernelGGL((attn_flash_bwd_dkv_kernel<L, false>), grid, dim3(64), 0, st, (const uint16_t*)qkv,
+                       (const uint16_t*)dout, lse, (const float*)delta, (uint16_t*)dqkv, T, heads, scale);
+  }
+}
+
+extern "C" int ffvc_attn_flash_fwd(const void* qkv, void* out, void* lse, int dtype, int B, int T, int heads, int head_dim,
+                                   float scale, int causal, void* stream) {
+  FFVC_CHECK_ARG(dtype == FFVC_BF16 || dtype == FFVC_F16, "ffvc_attn_flash_fwd: 16-bit storage only (dtype %d)", dtype);
+  FFVC_CHECK_ARG(qkv && out && lse && B > 0 && heads > 0 && T > 0, "ffvc_attn_flash_fwd: bad args");
+  FFVC_CHECK_ARG(head_dim == 64, "ffvc_attn_flash_fwd: head_dim must be 64 (got %d)", head_dim);
+  FFVC_CHECK_ARG((int64_t)B * heads <= 65535, "ffvc_attn_flash_fwd: B*heads = %lld exceeds the grid limit",
+                 (long long)B * heads);
+  FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ffvc_attn_flash_fwd: misaligned pointers");
+  if (dtype == FFVC_F16)
+    flash_fwd_launch<f16_t>(qkv, out, (float*)lse, B, T, heads, scale, causal, (hipStream_t)stream);
+  else
+    flash_fwd_launch<uint16_t>(qkv, out, (float*)lse, B, T, heads, scale, causal, (hipStream_t)stream);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_attn_flash_bwd(const void* qkv, const void* out, const void* dout, const void* lse, void* delta_ws,
+                                   void* dqkv, int dtype, int B, int T, int heads, int head_dim, float scale, int causal,
+                                   void* stream) {
+  FFVC_CHECK_ARG(dtype == FFVC_BF16 || dtype == FFVC_F16, "ffvc_attn_flash_bwd: 16-bit storage only (dtype %d)", dtype);
+  FFVC_CHECK_ARG(qkv && out && dout && lse && delta_ws && dqkv && B > 0 && heads > 0 && T > 0, "ffvc_attn_flash_bwd: bad args");
+  FFVC_CHECK_ARG(head_dim == 64, "ffvc_attn_flash_bwd: head_dim must be 64 (got %d)", head_dim);
+  FFVC_CHECK_ARG((int64_t)B * heads <= 65535, "ffvc_attn_flash_bwd: B*heads = %lld exceeds the grid limit",
+                 (long long)B * heads);
+  FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0 &&
+                     ((uintptr_t)dqkv % 8) == 0,
+                 "ffvc_attn_flash_bwd: misaligned pointers");
+  if (dtype == FFVC_F16)
+    flash_bwd_launch<f16_t>(qkv, out, dout, (const float*)lse, (float*)delta_ws, dqkv, B, T, heads, scale, causal,
+                            (hipStream_t)stream);
+  else
+    flash_bwd_launch<uint16_t>(qkv, out, dout, (const float*)lse, (float*)delta_ws, dqkv, B, T, heads, scale, causal,
+                               (hipStream_t)stream);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

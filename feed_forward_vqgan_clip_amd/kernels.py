@@ -689,6 +689,37 @@ def attn_small_bwd(qkv, do, heads, scale):
     return dqkv
 
 
+def attn_flash_ok(qkv, heads):
+    """Shapes the flash-style attention kernels cover: 16-bit storage, head dim 64, any length, causal or not."""
+    B, T, D3 = qkv.shape
+    return (qkv.dtype in LOWP and D3 == 3 * heads * 64 and B * heads <= 65535 and
+            os.environ.get("FFVC_ATTN_FLASH", "1") != "0")
+
+
+def attn_flash_fwd(qkv, heads, scale, causal):
+    """-> (out [B,T,heads*64], lse fp32 [B*heads,T])"""
+    _req(qkv.dtype if qkv.dtype in LOWP else torch.bfloat16, qkv)
+    B, T, D3 = qkv.shape
+    o = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B * heads, T, dtype=torch.float32, device=qkv.device)
+    _call("ffvc_attn_flash_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
+          float(scale), int(bool(causal)), stream_ptr())
+    return o, lse
+
+
+def attn_flash_bwd(qkv, o, do, lse, heads, scale, causal):
+    _req(qkv.dtype if qkv.dtype in LOWP else torch.bfloat16, qkv, o, do)
+    _req_f32(lse)
+    B, T, D3 = qkv.shape
+    if tuple(do.shape) != (B, T, D3 // 3) or tuple(o.shape) != (B, T, D3 // 3) or tuple(lse.shape) != (B * heads, T):
+        raise ValueError("attn_flash_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    _call("ffvc_attn_flash_bwd", qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+          dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
+    return dqkv
+
+
 def tokmix_supported(dtype, T, D, O):
     """Shapes / dtypes the fused token-mixing kernels cover (FFVC_TOKMIX=0 switches them off for A/B runs)."""
     if dtype not in LOWP or os.environ.get("FFVC_TOKMIX", "1") == "0":

@@ -131,10 +131,15 @@ def _grad_buf(p):
     return p.grad
 
 
+_WGRAD_SK = int(os.environ.get("FFVC_WGRAD_SK", "0"))     # A/B: cap of the split-K factor of the 256x256-tile wgrads
+
+
 def _split_k(n_out, k_out, red, bk, big_tiles=False):
     if big_tiles and n_out >= 1024 and k_out >= 1024 and n_out % 256 == 0 and k_out % 256 == 0 and red >= 8192:
         t256 = (n_out // 256) * (k_out // 256)          # 256x256 LDS-DMA tiles: one workgroup per CU (gemm2.hip, TT mode)
         if t256 < 256:
+            if _WGRAD_SK:
+                return max(1, min(_WGRAD_SK, 256 // t256, red // (32 * bk)))
             return max(1, min(256 // t256, red // (32 * bk)))
     tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
     if tiles >= 512:
@@ -552,6 +557,12 @@ class _AttentionFn(Function):
             ctx.small = True
             return K.attn_small_fwd(qkv, heads, scale)
         ctx.small = False
+        ctx.flash = K.attn_flash_ok(qkv, heads)
+        if ctx.flash:       # any length, head dim 64: online-softmax kernel, scores never reach HBM, causal blocks skipped
+            o, lse = K.attn_flash_fwd(qkv, heads, scale, causal)
+            ctx.save_for_backward(qkv, o, lse)
+            ctx.cfg = (heads, scale, causal)
+            return o
         Tp = _pad8(T)
         cdt = qkv.dtype
         BH = B * heads
@@ -575,6 +586,10 @@ class _AttentionFn(Function):
             (qkv,) = ctx.saved_tensors
             heads, scale = ctx.cfg
             return K.attn_small_bwd(qkv, _as(_contig(do), qkv.dtype), heads, scale), None, None, None
+        if ctx.flash:
+            qkv, o, lse = ctx.saved_tensors
+            heads, scale, causal = ctx.cfg
+            return K.attn_flash_bwd(qkv, o, _as(_contig(do), qkv.dtype), lse, heads, scale, causal), None, None, None
         qkv, P = ctx.saved_tensors
         B, T, D, heads, dh, Tp, scale = ctx.cfg
         D3, BH, cdt = 3 * D, B * heads, qkv.dtype

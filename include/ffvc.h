@@ -198,6 +198,16 @@ int ffvc_attn_small_fwd(const void* qkv, void* out, int dtype, int B, int T, int
 int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int B, int T, int heads, int head_dim,
                         float scale, void* stream);
 
+/* Flash-style attention for any sequence length, head_dim 64, optional causal mask: the x-transformer mapper's
+ * self-attention (transformer.py:11-20 -> x-transformers Decoder, 1024 tokens at cfg4) and ViT-L/14's 257 tokens
+ * (cfg5).  Same packed qkv layout as ffvc_attn_small_*.  No score matrix in HBM; causal blocks above the diagonal are
+ * skipped.  lse: fp32 [B*heads, T] written by the forward (log2-sum-exp of the scaled scores), read by the backward;
+ * delta_ws: fp32 [B*heads, T] scratch of the backward (row sums of dO*O).  out is the forward's result. */
+int ffvc_attn_flash_fwd(const void* qkv, void* out, void* lse, int dtype, int B, int T, int heads, int head_dim,
+                        float scale, int causal, void* stream);
+int ffvc_attn_flash_bwd(const void* qkv, const void* out, const void* dout, const void* lse, void* delta_ws, void* dqkv,
+                        int dtype, int B, int T, int heads, int head_dim, float scale, int causal, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Glue kernels of the train step (main.py:715-837)
  * ------------------------------------------------------------------------- */

@@ -1,5 +1,7 @@
 """GPU parity of the norm / softmax / glue kernels against plain PyTorch fp32/fp64 math of the same op.
 Tolerances: fp32 storage 2e-5 rel (op order only); bf16 storage adds one 2^-8 rounding of the output."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -304,6 +306,50 @@ def test_attention_small_fused(cuda, B, T, heads, ldt):
     o3 = ops.attention(x3, heads, scale)
     o3.backward(do)
     assert torch.equal(o3, o) and torch.equal(x3.grad, dqkv)
+
+
+@pytest.mark.parametrize("ldt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("B,T,heads", [(2, 257, 3), (1, 1024, 2), (3, 100, 1), (2, 64, 2), (1, 65, 1), (2, 7, 2)])
+def test_attention_flash(cuda, B, T, heads, causal, ldt):
+    """Flash-style attention (online softmax over 64-key blocks, no score matrix in HBM) vs fp64 math on the same 16-bit
+    inputs, forward + backward, causal and not; and vs the GEMM + softmax path it replaces (transformer.py:11-20)."""
+    import os
+    from feed_forward_vqgan_clip_amd import ops
+    D = heads * 64
+    qkv = _mk((B, T, 3 * D), ldt, cuda, 1, 0.7)
+    do = _mk((B, T, D), ldt, cuda, 2)
+    scale = 64 ** -0.5
+    f = 1.0 if ldt == torch.bfloat16 else 0.125
+    assert K.attn_flash_ok(qkv, heads)
+    o, lse = K.attn_flash_fwd(qkv, heads, scale, causal)
+    dqkv = K.attn_flash_bwd(qkv, o, do, lse, heads, scale, causal)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = [t.view(B, T, heads, 64).transpose(1, 2) for t in x.split(D, dim=-1)]
+    s = q @ k.transpose(-1, -2) * scale
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, dtype=torch.bool, device=cuda).triu(1), float("-inf"))
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, T, D)
+    ref.backward(do.double())
+    assert _rel(o, ref) < 1.2e-2 * f
+    assert _rel(dqkv, x.grad) < 2.5e-2 * f
+    ref_lse = torch.logsumexp(s, -1).reshape(B * heads, T) / math.log(2.0)
+    assert (lse.double() - ref_lse).abs().max().item() < 2e-2 * f + 1e-3
+    os.environ["FFVC_ATTN_FLASH"] = "0"
+    os.environ["FFVC_ATTN_SMALL"] = "0"
+    try:
+        x2 = qkv.clone().requires_grad_(True)
+        o2 = ops.attention(x2, heads, scale, causal)
+        o2.backward(do)
+    finally:
+        os.environ.pop("FFVC_ATTN_FLASH")
+        os.environ.pop("FFVC_ATTN_SMALL")
+    assert _rel(o, o2) < 1.2e-2 * f and _rel(dqkv, x2.grad) < 2.5e-2 * f
+    if T > 64 or causal:          # what ops.attention dispatches to for these shapes
+        x3 = qkv.clone().requires_grad_(True)
+        o3 = ops.attention(x3, heads, scale, causal)
+        o3.backward(do)
+        assert torch.equal(o3, o) and torch.equal(x3.grad, dqkv)
 
 
 def test_bad_arguments_fail_loudly(cuda):
