@@ -24,6 +24,7 @@ F_TR_SAFE = 64
 F_UPSAMPLE2X = 128
 F_ACCUM_OUT = 256
 F_GN_SUMS = 512
+F_COLSUM = 1024
 
 
 class GemmDesc(Structure):
@@ -79,6 +80,7 @@ class GemmDesc(Structure):
         ("gn_sums", c_void_p),
         ("gn_hw", c_int32),
         ("gn_cpg", c_int32),
+        ("colsum", c_void_p),
     ]
 
 
@@ -152,7 +154,7 @@ _SIGNATURES = {
     "ffvc_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ffvc_tokmix_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "ffvc_tokmix_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "ffvc_tokmix_bwd_hidden": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_tokmix_bwd_hidden": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_set_option": (c_int, [c_char_p, c_int]),
     "ffvc_last_error": (c_char_p, []),
     "ffvc_version": (c_int, []),

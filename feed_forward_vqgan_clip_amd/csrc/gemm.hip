@@ -531,6 +531,7 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
     if (r2 < 0) return r2;
   }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_GN_SUMS), "ffvc_gemm: FFVC_F_GN_SUMS is only available on the bf16 LDS-DMA path");
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_COLSUM), "ffvc_gemm: FFVC_F_COLSUM is only available on the 16-bit LDS-DMA path");
   if (d.in_dtype == FFVC_BF16) return dispatch<uint16_t>(d, st, vec_ok);
   if (d.in_dtype == FFVC_F16) return dispatch<f16_t>(d, st, vec_ok);
   return dispatch<float>(d, st, vec_ok);

@@ -184,6 +184,12 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       return FFVC_E_BADARG;
     }
   }
+  if (d.flags & FFVC_F_COLSUM) {
+    if (!(vec_ok == 2 && d.colsum && d.batch == 1 && d.split_k <= 1 && !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)))) {
+      ffvc_set_error("ffvc_gemm: FFVC_F_COLSUM needs the row-store epilogue (N %% 8 == 0, aligned rows), batch 1, no split-K");
+      return FFVC_E_BADARG;
+    }
+  }
   // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
   const int env_bm = opt_value(g_opt_gemm2_tile, "FFVC_GEMM2_BM", 1);
   if (env_bm == 0) return 0;

@@ -219,6 +219,12 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
   const int wsw = l31 & 7;
   const bool gn = flags & FFVC_F_GN_SUMS;
   float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [nt][4-channel half]
+  const bool cs_on = flags & FFVC_F_COLSUM;
+  float cs[2][8];                                                                      // [nt][column of this lane]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[nt][j] = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int mbase = m0 + wm * (32 * MT) + mt * 32;
@@ -269,11 +275,29 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
               gs2[nt][j >> 2] += v.v[j] * v.v[j];
             }
           }
+          if (cs_on) {   // bias gradient of the layer whose pre-activation gradient this GEMM just produced
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[nt][j] += v.v[j];
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (cs_on) {
+    // column sums of everything this wave stored: fold the 16 row-lanes, one fp32 atomic per column and wave
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + (NSPLIT ? nt * 128 + wn * 32 : wn * 64 + nt * 32) + 8 * cc;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = cs[nt][j];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (rr == 0 && n < p.N) atomicAdd(p.colsum + n + j, a);
+      }
     }
   }
   if (gn) {

@@ -233,8 +233,8 @@ template <typename L, int T_>
 __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ dy,
                                                                    const uint16_t* __restrict__ w1, const float* __restrict__ b1,
                                                                    const uint16_t* __restrict__ w2t, uint16_t* __restrict__ hout,
-                                                                   uint16_t* __restrict__ dhout, int D, int O,
-                                                                   const uint16_t* zero) {
+                                                                   uint16_t* __restrict__ dhout, float* __restrict__ db1,
+                                                                   int D, int O, const uint16_t* zero) {
   constexpr int NK1 = T_ / 16;
   constexpr int HALF = 64 * T_;
   constexpr int STAGE = 2 * HALF;
@@ -278,6 +278,17 @@ __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_
         uint16_t* dst = (row < 32 ? hout : dhout) + out0 + (int64_t)(c * TM_OC + (row & 31)) * D + d;
         *(u32x4_t*)dst = v;
       }
+      if (db1 && i >= 2) {     // rows 32..63 are dh: its sum over (sample, d) is the first Conv1d's bias gradient
+        float sum = 0.0f;
+        if (d < D) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            sum += lo_unpack<L>((uint16_t)(v[e] & 0xffffu)) + lo_unpack<L>((uint16_t)(v[e] >> 16));
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        if ((lane & 31) == 0) atomicAdd(db1 + c * TM_OC + (row & 31), sum);   // (2 extra vm ops per flush: the counted
+      }                                                                        //  waits below stay conservative)
     }
   };
 
@@ -358,8 +369,8 @@ int launch_fwd(const void* xn, const void* w1, const float* b1, const void* w2, 
 }
 
 template <typename L, int T_>
-int launch_bwd(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t, void* h, void* dh, int B,
-               int D, int O, hipStream_t st, const uint16_t* zero) {
+int launch_bwd(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t, void* h, void* dh, float* db1,
+               int B, int D, int O, hipStream_t st, const uint16_t* zero) {
   constexpr int lds_main = 3 * 128 * T_ + 2 * (2 * TM_OC * TM_DT * 2);
   constexpr int lds_stage = (T_ / 64) * 32768;
   constexpr int lds = lds_main > lds_stage ? lds_main : lds_stage;
@@ -370,7 +381,7 @@ int launch_bwd(const void* xn, const void* dy, const void* w1, const float* b1, 
     attr = true;
   }
   hipLaunchKernelGGL((tokmix_bwd_hidden_kernel<L, T_>), dim3(ceil_div(D, TM_DT), B), dim3(512), lds, st, (const uint16_t*)xn,
-                     (const uint16_t*)dy, (const uint16_t*)w1, b1, (const uint16_t*)w2t, (uint16_t*)h, (uint16_t*)dh, D, O, zero);
+                     (const uint16_t*)dy, (const uint16_t*)w1, b1, (const uint16_t*)w2t, (uint16_t*)h, (uint16_t*)dh, db1, D, O, zero);
   FFVC_LAUNCH_CHECK();
   return 0;
 }
@@ -408,7 +419,7 @@ extern "C" int ffvc_tokmix_fwd(const void* xn, const void* w1, const float* b1, 
 }
 
 extern "C" int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t,
-                                      void* h, void* dh, int dtype, int B, int T, int D, int O, void* stream) {
+                                      void* h, void* dh, float* db1, int dtype, int B, int T, int D, int O, void* stream) {
   FFVC_CHECK_ARG(xn && dy && w1 && b1 && w2t && h && dh, "ffvc_tokmix_bwd_hidden: null pointer");
   if (int e = tm_check("ffvc_tokmix_bwd_hidden", dtype, B, T, D, O)) return e;
   FFVC_CHECK_ARG(((uintptr_t)xn % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)w1 % 16) == 0 &&
@@ -418,8 +429,8 @@ extern "C" int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void
   FFVC_CHECK_ARG(zero != nullptr, "ffvc_tokmix_bwd_hidden: zero page allocation failed");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FFVC_F16)
-    return T == 256 ? launch_bwd<f16_t, 256>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero)
-                    : launch_bwd<f16_t, 128>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero);
-  return T == 256 ? launch_bwd<uint16_t, 256>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero)
-                  : launch_bwd<uint16_t, 128>(xn, dy, w1, b1, w2t, h, dh, B, D, O, st, zero);
+    return T == 256 ? launch_bwd<f16_t, 256>(xn, dy, w1, b1, w2t, h, dh, db1, B, D, O, st, zero)
+                    : launch_bwd<f16_t, 128>(xn, dy, w1, b1, w2t, h, dh, db1, B, D, O, st, zero);
+  return T == 256 ? launch_bwd<uint16_t, 256>(xn, dy, w1, b1, w2t, h, dh, db1, B, D, O, st, zero)
+                  : launch_bwd<uint16_t, 128>(xn, dy, w1, b1, w2t, h, dh, db1, B, D, O, st, zero);
 }

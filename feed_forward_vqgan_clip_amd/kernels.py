@@ -93,7 +93,8 @@ def _req_f32(*ts):
 def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, bias=None,
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
-         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0, gn_sums=None):
+         xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0, gn_sums=None,
+         colsum=None):
     """Enqueue `ffvc_gemm`. See include/ffvc.h for the index maps.
 
     y_map / r_map = (mi, so, sm): row offset(m) = (m // mi) * so + (m % mi) * sm (mi = 0: m * sm).
@@ -147,6 +148,11 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
             raise TypeError("gemm: gn_sums buffer must be a contiguous fp64 device tensor")
         d.gn_sums, d.gn_hw, d.gn_cpg = buf.data_ptr(), hw, cpg
         d.flags |= _lib.F_GN_SUMS
+    if colsum is not None:                        # fp32 [N]: += column sums of the stored output (colsum_fusable() first)
+        if colsum.dtype != torch.float32 or not colsum.is_cuda or not colsum.is_contiguous() or colsum.numel() != N:
+            raise TypeError("gemm: colsum must be a contiguous fp32 [N] device tensor")
+        d.colsum = colsum.data_ptr()
+        d.flags |= _lib.F_COLSUM
     lib = _lib.load()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -262,6 +268,14 @@ def gn_sums_ok(M, N, HW, dtype, G=32):
     """Can the GEMM that produces an (M = images*HW, N = C) NHWC tensor also accumulate its GroupNorm moments?"""
     return (dtype in LOWP and HW % 256 == 0 and M % HW == 0 and N % G == 0 and (N // G) % 4 == 0 and
             os.environ.get("FFVC_GN_FUSE", "1") != "0")
+
+
+def colsum_fusable(dtype, N, K, *lds):
+    """Can a K-major x K-major GEMM of this shape also accumulate the column sums of its output (FFVC_F_COLSUM)?  Needs the
+    LDS-DMA kernels with the row-store epilogue: 16-bit operands, 8-element aligned rows everywhere."""
+    return (dtype in LOWP and N % 8 == 0 and K % 8 == 0 and all(int(v) % 8 == 0 for v in lds) and
+            os.environ.get("FFVC_COLSUM_FUSE", "1") != "0" and os.environ.get("FFVC_GEMM2_BM", "1") != "0" and
+            os.environ.get("FFVC_EPI_ROWS", "1") != "0")
 
 
 def gn_sums_buffer(images, G, device):
@@ -741,18 +755,21 @@ def tokmix_fwd(xn, w1, b1, w2, b2, residual):
     return y
 
 
-def tokmix_bwd_hidden(xn, dy, w1, b1, w2t):
-    """-> (h, dh) as (B,O,D) in xn's dtype: h = gelu(W1 xn + b1), dh = (W2^T dy) * gelu'(W1 xn + b1); w2t = W2^T (O,T)."""
+def tokmix_bwd_hidden(xn, dy, w1, b1, w2t, db1=None):
+    """-> (h, dh) as (B,O,D) in xn's dtype: h = gelu(W1 xn + b1), dh = (W2^T dy) * gelu'(W1 xn + b1); w2t = W2^T (O,T).
+    db1 (fp32 [O]): += sum_{b,d} dh, the first Conv1d's bias gradient, accumulated while dh is written."""
     _req(xn.dtype, xn, dy, w1, w2t)
-    _req_f32(b1)
+    _req_f32(b1, db1)
     B, T, D = xn.shape
     O = w1.shape[0]
     if tuple(w1.shape) != (O, T) or tuple(w2t.shape) != (O, T) or tuple(dy.shape) != (B, T, D):
         raise ValueError("tokmix_bwd_hidden: shape mismatch")
     h = torch.empty(B, O, D, dtype=xn.dtype, device=xn.device)
     dh = torch.empty_like(h)
+    if db1 is not None and (db1.numel() != O or not db1.is_contiguous()):
+        raise ValueError("tokmix_bwd_hidden: db1 must be a contiguous [O] tensor")
     _call("ffvc_tokmix_bwd_hidden", xn.data_ptr(), dy.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), h.data_ptr(),
-          dh.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
+          dh.data_ptr(), _ptr(db1), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
     return h, dh
 
 

@@ -147,10 +147,11 @@ def _split_k(n_out, k_out, red, bk, big_tiles=False):
     return max(1, min((768 + tiles - 1) // tiles, red // (8 * bk)))
 
 
-def _wgrad(dy2d, x2d, W, rows, ldy=None):
-    """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N)."""
+def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
+    """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N).
+    bias_done: the kernel that produced dy already accumulated its column sums into bias.grad."""
     wg = _grad_buf(W.weight)
-    bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad) else None
+    bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad and not bias_done) else None
     bk = 64 if dy2d.dtype in K.LOWP else 32
     sk = _split_k(W.N, W.K, rows, bk, big_tiles=dy2d.dtype in K.LOWP and (ldy or W.N) == W.N)
     with _on_side(dy2d, x2d):
@@ -282,13 +283,16 @@ class _MLPFn(Function):
         dy = _contig(dy)
         dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         dh = torch.empty_like(h_pre)
+        # the first Linear's bias gradient = column sums of dh: accumulated by the epilogue that writes dh
+        b1_fused = (ctx.train and not ctx.drop and W1.bias is not None and W1.bias.requires_grad and
+                    K.colsum_fusable(cdt, W2.K, W2.N))
         K.gemm(dyt, W2.sht, dh, rows, W2.K, W2.N, ldx=W2.N, ldw=W2.N, aux=h_pre, ldaux=W2.K, act=ctx.act,
-               flags=K.F_MUL_ACT_GRAD)
+               flags=K.F_MUL_ACT_GRAD, colsum=_grad_buf(W1.bias) if b1_fused else None)
         if ctx.drop:        # the hidden mask commutes with the element-wise act' factor the epilogue just applied
             K.dropout(dh, ctx.drop[0], ctx.drop[1], out=dh)
         if ctx.train:
             _wgrad(dyt, h, W2, rows)
-            _wgrad(dh, x, W1, rows)
+            _wgrad(dh, x, W1, rows, bias_done=b1_fused)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
@@ -351,8 +355,11 @@ class _TokenMLPFn(Function):
         xn, h_pre, h = ctx.saved_tensors
         dy = _contig(dy)
         dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
+        # db1 inside the fused kernel is available (FFVC_TOKMIX_DB1=1) but measured +1.1..2 ms/step (atomics in its chunk
+        # loop, profiles/r02_bias_grad_fusion_ab.txt): the rowsum launch on the side stream stays the default
+        b1_fused = ctx.fused and ctx.train and W1.bias.requires_grad and os.environ.get("FFVC_TOKMIX_DB1", "0") != "0"
         if ctx.fused:
-            h, dh = K.tokmix_bwd_hidden(xn, dyt, W1.sh, W1.bias, W2.sht)
+            h, dh = K.tokmix_bwd_hidden(xn, dyt, W1.sh, W1.bias, W2.sht, db1=_grad_buf(W1.bias) if b1_fused else None)
         else:
             # dh_pre[b] = (W2^T @ dy[b]) * gelu'(h_pre[b])
             dh = torch.empty_like(h_pre)
@@ -375,7 +382,7 @@ class _TokenMLPFn(Function):
                     else:
                         for b in range(B):
                             K.gemm(g[b], a[b], wg, n_out, k_out, D, ldx=D, ldw=D, flags=K.F_ACCUM_OUT)
-                    if bg is not None:
+                    if bg is not None and not (b1_fused and W is W1):
                         K.rowsum(g, bg, n_out, accumulate=True)
                 if W.on_grad is not None:
                     W.on_grad(W)

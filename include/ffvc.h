@@ -56,6 +56,7 @@ extern "C" {
 #define FFVC_F_TR_SAFE 64       /* transposed bf16 fragments via scalar LDS gathers (debug/verification) */
 #define FFVC_F_UPSAMPLE2X 128   /* conv: input is nearest-2x upsampled on the fly */
 #define FFVC_F_GN_SUMS 512      /* also accumulate GroupNorm moments of the stored output (see gn_sums below) */
+#define FFVC_F_COLSUM 1024      /* also accumulate the column sums of the stored output into colsum[N] (see below) */
 #define FFVC_F_ACCUM_OUT 256    /* y += acc with plain read-modify-write (fp32 y, split_k == 1: one owner per element) */
 
 /*
@@ -122,6 +123,11 @@ typedef struct ffvc_gemm_desc {
    * instead of by a separate read pass).  bf16 LDS-DMA path only; gn_hw % 256 == 0, gn_cpg % 4 == 0. */
   double* gn_sums;
   int32_t gn_hw, gn_cpg;
+  /* FFVC_F_COLSUM: colsum[n] += sum_m y[m, n] of the values just stored (fp32 atomics, one per column and wave): the
+   * bias gradient of a Linear whose pre-activation gradient this GEMM produces (FFVC_F_MUL_ACT_GRAD epilogue), computed
+   * where the tensor is produced instead of by a separate read pass.  16-bit LDS-DMA path with the row-store epilogue
+   * only, batch == 1, no split-K. */
+  float* colsum;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
@@ -319,12 +325,13 @@ int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stre
  *   shadows), b1: [O], b2: [T] fp32, residual / y: [B,T,D] fp32.  The hidden activation never leaves the CU.
  * ffvc_tokmix_bwd_hidden recomputes it for the backward pass: h = gelu(W1 xn + b1), dh = (W2^T dy) * gelu'(W1 xn + b1),
  *   written once as [B,O,D] 16-bit (w2t = W2^T as [O,T]); dx = W1^T dh and the weight gradients stay ffvc_gemm calls.
+ *   db1 (fp32 [O], may be NULL): += sum over (sample, d) of the stored dh = the first Conv1d's bias gradient.
  * Supported: dtype FFVC_BF16 | FFVC_F16, T in {128, 256}, D % 32 == 0, O % 32 == 0, O <= 4096 (ffvc_tokmix_supported). */
 int ffvc_tokmix_supported(int dtype, int T, int D, int O);
 int ffvc_tokmix_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* residual,
                     float* y, int dtype, int B, int T, int D, int O, void* stream);
 int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t, void* h,
-                           void* dh, int dtype, int B, int T, int D, int O, void* stream);
+                           void* dh, float* db1, int dtype, int B, int T, int D, int O, void* stream);
 
 /* Kernel-selection overrides for tests / A-B measurements (defaults come from FFVC_GEMM2_BM / FFVC_CONV_ROW):
  *   "gemm2_tile": 0 = register-staged kernel only, 1 = heuristic, 128 | 256 | 512 = force the LDS-DMA tile
