@@ -29,9 +29,22 @@ PEAK_BF16_TFLOPS = 2516.6      # 256 CU x 4096 FLOP/clk x 2.4 GHz dense bf16 / f
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
 
 
-def step_tflop(B, cutn):
-    """FLOP/step = 2 * [B*txt + B*(3*mapper + vq + 2*dec + 2*cutn*img)]  (BASELINE.md §2), in TFLOP."""
-    return 2.0 * (B * GMAC["txt"] + B * (3 * GMAC["mixer"] + GMAC["vq"] + 2 * GMAC["dec"] + 2 * cutn * GMAC["img"])) / 1e3
+# SURVEY.md §8d table, per (mapper, depth, dim, vq_image_size) / decode size / perceptor
+GMAC_MAPPER = {("mlp_mixer", 32, 1024, 16): 86.07, ("mlp_mixer", 8, 128, 16): 0.856, ("mlp_mixer", 1, 1024, 32): 17.85,
+               ("vitgan", 32, 1024, 16): 6.53, ("xtransformer", 16, 256, 32): 28.12}
+GMAC_DEC = {16: (126.37, 2.147), 32: (508.72, 8.590)}                     # vq_image_size -> (decoder, VQ as written)
+GMAC_CLIP = {"ViT-B/32": (4.409, 2.980), "ViT-L/14": (81.01, 6.65)}        # image per cutout, text per prompt
+
+
+def step_tflop(B, cutn, mapper=("mlp_mixer", 32, 1024, 16), clip_model="ViT-B/32"):
+    """FLOP/step = 2 * [B*txt + B*(3*mapper + vq + 2*dec + 2*cutn*img)]  (SURVEY.md §8d / BASELINE.md §2), in TFLOP;
+    None for a configuration the survey's table does not cover."""
+    arch = {"openclip/ViT-L-14/laion2b_s32b_b82k": "ViT-L/14"}.get(clip_model, clip_model)
+    if mapper not in GMAC_MAPPER or mapper[3] not in GMAC_DEC or arch not in GMAC_CLIP:
+        return None
+    dec, vq = GMAC_DEC[mapper[3]]
+    img, txt = GMAC_CLIP[arch]
+    return 2.0 * (B * txt + B * (3 * GMAC_MAPPER[mapper] + vq + 2 * dec + 2 * cutn * img)) / 1e3
 
 
 def build(args, device):
@@ -43,7 +56,7 @@ def build(args, device):
 
     cdt = DTYPES[args.dtype]
     cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
-                       batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
+                       batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model=args.clip_model,
                        model_type=args.model_type, vq_image_size=args.vq_image_size,
                        augs=None if args.augs == "default" else args.augs.split(","))
     torch.manual_seed(1234)
@@ -51,9 +64,10 @@ def build(args, device):
     mixer_sd = {k: v.detach().clone() for k, v in net.state_dict().items()} if args.keep_cpu_weights else None
     net = net.to(device).prepare(cdt)
     vq_sd = fvq.random_state_dict(fvq.F16_16384, seed=1234)
-    clip_sd = fclip.random_state_dict(fclip.VIT_B32, seed=1234)
+    arch, quick = fmain.clip_arch(args.clip_model)
+    clip_sd = fclip.random_state_dict(arch, seed=1234)
     vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
-    perceptor = fclip.CLIP(clip_sd, cdt)
+    perceptor = fclip.CLIP(clip_sd, cdt, quick_gelu=quick)
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
     opt.loss_scale = args.loss_scale if cdt == torch.float16 else 1.0
     if hvd.is_distributed():
@@ -248,6 +262,8 @@ def main():
     ap.add_argument("--model-type", default="mlp_mixer", choices=["mlp_mixer", "vitgan", "simple_vitgan", "xtransformer"],
                     help="mapper family (the headline workload cfg2 is mlp_mixer; others are dev / parity configs)")
     ap.add_argument("--vq-image-size", type=int, default=16, help="latent grid S (image = 16*S)")
+    ap.add_argument("--clip-model", default="ViT-B/32", help="perceptor (main.py:1308-1333 names): ViT-B/32 (headline), "
+                    "ViT-B/16, ViT-L/14, openclip/<arch>/<pretrained> (cfg5: openclip/ViT-L-14/laion2b_s32b_b82k)")
     ap.add_argument("--augs", default="default", help="'default' = the reference's Af,Pe,Ji,Er (main.py:164-165), or a "
                     "comma list, e.g. 'R'")
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp32"],
@@ -279,7 +295,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(hvd.local_rank())
     device = torch.device("cuda", hvd.local_rank())
-    if args.model_type != "mlp_mixer":
+    if args.model_type != "mlp_mixer" or args.clip_model != "ViT-B/32" or args.vq_image_size != 16:
         args.no_cpu_baseline = True
     args.keep_cpu_weights = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     cfg, stepper, sds = build(args, device)
@@ -327,17 +343,17 @@ def main():
                              "f16": "IEEE f16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
                                     f"fp32 text tower, VQ distances and loss, backward loss-scaled x{args.loss_scale:g}",
                              "fp32": "exact fp32 MFMA everywhere"}[args.dtype],
-        "config": {"workload": (f"cfg2: MLP-Mixer {args.depth}x{args.dim}" if args.model_type == "mlp_mixer" else
+        "config": {"workload": (("cfg2: " if (args.depth, args.dim, args.vq_image_size, args.clip_model) == (32, 1024, 16, "ViT-B/32")
+                                 else "") + f"MLP-Mixer {args.depth}x{args.dim}" if args.model_type == "mlp_mixer" else
                                 f"{args.model_type} {args.depth}x{args.dim}") +
                                f" mapper + VQGAN f16-16384 decoder {16 * args.vq_image_size}x{16 * args.vq_image_size} + CLIP "
-                               f"ViT-B/32, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
+                               f"{args.clip_model}, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
                    "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire,
                    "dp": hvd.describe()},
         "final_loss": float(loss.item()),
     }
-    tf_step = step_tflop(B, args.cutn) if (args.model_type, args.depth, args.dim, args.vq_image_size) == \
-        ("mlp_mixer", 32, 1024, 16) else None
+    tf_step = step_tflop(B, args.cutn, (args.model_type, args.depth, args.dim, args.vq_image_size), args.clip_model)
     if tf_step:
         out["step_tflop"] = tf_step
         out["step_mfma_frac"] = tf_step / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS

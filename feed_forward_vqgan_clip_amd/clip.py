@@ -15,9 +15,11 @@ import torch
 
 from . import kernels as K
 from . import ops
-from .kernels import ACT_QUICKGELU
+from .kernels import ACT_GELU, ACT_QUICKGELU
 
 VIT_B32 = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+               context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
+VIT_B16 = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
                context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
 VIT_L14 = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
                context_length=77, vocab_size=49408, transformer_width=768, transformer_heads=12, transformer_layers=12)
@@ -72,7 +74,8 @@ def _f(t):
 
 
 class _Block:
-    def __init__(self, sd, p, cdt, need_dgrad):
+    def __init__(self, sd, p, cdt, need_dgrad, act=ACT_QUICKGELU):
+        self.act = act
         fz = lambda w, b: ops.Weights.frozen(sd[w], sd[b], cdt, need_dgrad)  # noqa: E731
         self.ln1 = (_f(sd[p + ".ln_1.weight"]), _f(sd[p + ".ln_1.bias"]))
         self.ln2 = (_f(sd[p + ".ln_2.weight"]), _f(sd[p + ".ln_2.bias"]))
@@ -89,7 +92,7 @@ class _Block:
         o = ops.attention(ops.linear(xn, self.in_proj), heads, dh ** -0.5, causal)
         x = ops.linear(o, self.out_proj, residual=xid, out_dtype=f32)
         xn, xid = ops.layernorm_fork(x, *self.ln2, cdt)
-        return ops.mlp(xn, self.c_fc, self.c_proj, ACT_QUICKGELU, residual=xid, out_dtype=f32)
+        return ops.mlp(xn, self.c_fc, self.c_proj, self.act, residual=xid, out_dtype=f32)
 
 
 class _TakeToken(torch.autograd.Function):
@@ -112,10 +115,14 @@ class _TakeToken(torch.autograd.Function):
 
 
 class CLIP:
-    def __init__(self, state_dict, cdt=torch.bfloat16, vision_heads=None, text_heads=None):
+    def __init__(self, state_dict, cdt=torch.bfloat16, vision_heads=None, text_heads=None, quick_gelu=True):
+        """quick_gelu: OpenAI checkpoints and open_clip's `-quickgelu` architectures use x*sigmoid(1.702x) in the MLPs
+        (cloob.py:179-181); the other open_clip architectures (ViT-B-32 / ViT-L-14 on LAION-2B, main.py:1323-1329) use
+        the exact erf GELU."""
         if not torch.cuda.is_available():
             raise RuntimeError("CLIP needs a HIP device; there is no CPU fallback")
         sd, self.cdt = state_dict, cdt
+        act = ACT_QUICKGELU if quick_gelu else ACT_GELU
         w = sd["visual.conv1.weight"]
         self.width, self.patch = w.shape[0], w.shape[-1]
         self.vision_heads = vision_heads or self.width // 64                       # cloob.py:446
@@ -130,7 +137,7 @@ class CLIP:
         n = 0
         self.vblocks = []
         while f"visual.transformer.resblocks.{n}.ln_1.weight" in sd:
-            self.vblocks.append(_Block(sd, f"visual.transformer.resblocks.{n}", cdt, True))
+            self.vblocks.append(_Block(sd, f"visual.transformer.resblocks.{n}", cdt, True, act))
             n += 1
         self.vproj = ops.Weights.frozen(sd["visual.proj"].t().contiguous(), None, cdt)
         self.embed_dim = sd["visual.proj"].shape[1]
@@ -144,7 +151,7 @@ class CLIP:
         self.tblocks = []
         n = 0
         while f"transformer.resblocks.{n}.ln_1.weight" in sd:
-            self.tblocks.append(_Block(sd, f"transformer.resblocks.{n}", f32, False))
+            self.tblocks.append(_Block(sd, f"transformer.resblocks.{n}", f32, False, act))
             n += 1
         self.ln_final = (_f(sd["ln_final.weight"]), _f(sd["ln_final.bias"]))
         self.tproj = ops.Weights.frozen(sd["text_projection"].t().contiguous(), None, f32, False)

@@ -157,19 +157,37 @@ def _cdt(config):
     return {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "fp32": torch.float32, "f32": torch.float32}[name]
 
 
+def clip_arch(model_type):
+    """(architecture dict, quick_gelu) of a perceptor name: OpenAI names (main.py:1330-1332) or
+    `openclip/<arch>/<pretrained>` (main.py:1323-1329; open_clip architectures use the erf GELU unless the name says
+    `-quickgelu`)."""
+    table = {"ViT-B/32": _clip.VIT_B32, "ViT-B/16": _clip.VIT_B16, "ViT-L/14": _clip.VIT_L14,
+             "ViT-B-32": _clip.VIT_B32, "ViT-B-16": _clip.VIT_B16, "ViT-L-14": _clip.VIT_L14}
+    if model_type.startswith("openclip/"):
+        parts = model_type.split("/")
+        if len(parts) != 3:
+            raise ValueError(f"clip_model '{model_type}': expected openclip/<arch>/<pretrained>")
+        name = parts[1]
+        quick = name.endswith("-quickgelu")
+        arch = table.get(name[:-len("-quickgelu")] if quick else name)
+    else:
+        arch, quick = table.get(model_type), True
+    if arch is None:
+        raise ValueError(f"clip_model '{model_type}' is not built on the HIP path (ViT-B/32, ViT-B/16, ViT-L/14 and their "
+                         f"open_clip spellings; the ResNet / CLOOB perceptors are out of scope)")
+    return arch, quick
+
+
 def load_clip_model(model_type, path=None, cdt=torch.bfloat16):
     """main.py:1308-1333 for the OpenAI / OpenCLIP ViT families (state_dict in clip.model.CLIP layout)."""
-    arch = {"ViT-B/32": _clip.VIT_B32, "openclip/ViT-B-32-quickgelu/laion400m_e32": _clip.VIT_B32,
-            "ViT-L/14": _clip.VIT_L14}.get(model_type)
-    if arch is None:
-        raise ValueError(f"clip_model '{model_type}' is not built on the HIP path (ViT-B/32, ViT-L/14)")
+    arch, quick = clip_arch(model_type)
     if path is None or str(path).startswith("random:"):
         seed = int(str(path).split(":", 1)[1]) if path else 1234
         sd = _clip.random_state_dict(arch, seed)
     else:
         obj = torch.load(path, map_location="cpu", weights_only=False)
         sd = obj.state_dict() if hasattr(obj, "state_dict") else obj.get("state_dict", obj)
-    return _clip.CLIP(sd, cdt)
+    return _clip.CLIP(sd, cdt, quick_gelu=quick)
 
 
 def synthetic_tokens(n, seed=0, context_length=77):
@@ -217,9 +235,21 @@ def tokenize(paths, out="tokenized.pkl", max_length=None, batch_size=None, bpe_p
     return toks
 
 
+def clip_dim_size(config):
+    """(clip_dim, clip_size) of a config: explicit keys, then the reference's tables (main.py:53-80), then the architecture
+    of an `openclip/<arch>/<pretrained>` name the tables do not list."""
+    dim = config.get("clip_dim", CLIP_DIM.get(config.clip_model))
+    size = config.get("clip_size", CLIP_SIZE.get(config.clip_model))
+    if dim is None or size is None:
+        arch, _ = clip_arch(config.clip_model)
+        dim = dim if dim is not None else arch["embed_dim"]
+        size = size if size is not None else arch["image_resolution"]
+    return dim, size
+
+
 def build_model(config, vq_channels=None):
     """main.py:448-502 (the VQGAN is NOT re-loaded here just to read z_channels; pass it in)."""
-    clip_dim = config.get("clip_dim", CLIP_DIM.get(config.clip_model))
+    clip_dim = clip_dim_size(config)[0]
     if vq_channels is None:
         vq_channels = config.get("vq_channels", 256)
     vq_image_size = config.get("vq_image_size", 16)
@@ -254,8 +284,7 @@ class TrainStep:
     def __init__(self, config, net, vq, perceptor, opt, scheduler=None):
         self.config, self.net, self.vq, self.perceptor, self.opt, self.scheduler = config, net, vq, perceptor, opt, scheduler
         clip_model = config.clip_model
-        self.clip_size = config.get("clip_size", CLIP_SIZE.get(clip_model))
-        self.clip_dim = config.get("clip_dim", CLIP_DIM.get(clip_model))
+        self.clip_dim, self.clip_size = clip_dim_size(config)
         self.cutn, self.repeat = config.cutn, config.repeat
         self.make_cutouts = MakeCutouts(cut_size=config.get("cut_size", self.clip_size), cutn=self.cutn,
                                         augs=config.get("augs"), pool=config.get("pool", True),

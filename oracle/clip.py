@@ -37,10 +37,11 @@ def _mha(x, sd, p, heads, mask):
     return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 
 
-def _resblock(x, sd, p, heads, mask):
+def _resblock(x, sd, p, heads, mask, quick_gelu=True):
     x = x + _mha(_ln(x, sd, p + ".ln_1"), sd, p + ".attn", heads, mask)          # cloob.py:203
     h = F.linear(_ln(x, sd, p + ".ln_2"), sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"])
-    h = F.linear(_quick_gelu(h), sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
+    # open_clip architectures without the `-quickgelu` suffix (main.py:1323-1329) use nn.GELU() here [upstream]
+    h = F.linear(_quick_gelu(h) if quick_gelu else F.gelu(h), sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
     return x + h                                                                   # cloob.py:204
 
 
@@ -51,7 +52,7 @@ def _n_layers(sd, prefix):
     return n
 
 
-def encode_image(sd, image, heads=None):
+def encode_image(sd, image, heads=None, quick_gelu=True):
     """cloob.py:236-255 (VisualTransformer.forward). image: (N,3,R,R), already mean/std normalised."""
     w = sd["visual.conv1.weight"]
     width, patch = w.shape[0], w.shape[-1]
@@ -63,12 +64,12 @@ def encode_image(sd, image, heads=None):
     x = x + sd["visual.positional_embedding"]                                      # :244
     x = _ln(x, sd, "visual.ln_pre")                                                # :245
     for i in range(_n_layers(sd, "visual.transformer")):
-        x = _resblock(x, sd, f"visual.transformer.resblocks.{i}", heads, None)     # :247-249
+        x = _resblock(x, sd, f"visual.transformer.resblocks.{i}", heads, None, quick_gelu)     # :247-249
     x = _ln(x[:, 0, :], sd, "visual.ln_post")                                      # :251
     return x @ sd["visual.proj"]                                                   # :253-254
 
 
-def encode_text(sd, text, heads=None):
+def encode_text(sd, text, heads=None, quick_gelu=True):
     """cloob.py:525-538 (CLIP.encode_text). text: int64 (B, 77)."""
     x = sd["token_embedding.weight"][text]                                         # :526
     L = x.shape[1]
@@ -77,7 +78,7 @@ def encode_text(sd, text, heads=None):
     heads = heads or width // 64                                                   # transformer_heads = width/64 upstream (8 for ViT-B/32)
     mask = torch.full((L, L), float("-inf"), device=x.device).triu_(1)             # cloob.py:510-516
     for i in range(_n_layers(sd, "transformer")):
-        x = _resblock(x, sd, f"transformer.resblocks.{i}", heads, mask)
+        x = _resblock(x, sd, f"transformer.resblocks.{i}", heads, mask, quick_gelu)
     x = _ln(x, sd, "ln_final")                                                     # :532
     eot = text.argmax(dim=-1)                                                      # :536 (EOT = highest id)
     return x[torch.arange(x.shape[0]), eot] @ sd["text_projection"]

@@ -90,6 +90,49 @@ def test_clip_matches_reference_golden(cuda, cdt, tol):
     assert_close(et.cpu(), z["text_embed"], 2e-4, 1e-5, "text_embed")
 
 
+@pytest.mark.parametrize("cdt,tol", [(F32, 2e-4), (BF16, 3e-2), (F16, 4e-3)])
+@pytest.mark.parametrize("quick", [True, False])
+def test_clip_patch14_long_sequence_matches_oracle(cuda, cdt, tol, quick):
+    """ViT-L/14-shaped image tower (patch 14, > 64 tokens -> the flash-style attention kernels in the 16-bit modes, 3*14*14
+    = 588-wide patch rows that are not 16-byte multiples) and the erf-GELU MLP of the open_clip architectures
+    (main.py:1323-1329), forward + image gradient against the oracle (cloob.py:219-255 math)."""
+    from oracle import clip as oclip
+    cfg = dict(embed_dim=48, image_resolution=126, vision_layers=2, vision_width=128, vision_patch_size=14,
+               context_length=16, vocab_size=96, transformer_width=64, transformer_heads=1, transformer_layers=1)
+    sd = fclip.random_state_dict(cfg, seed=21)
+    g = torch.Generator().manual_seed(5)
+    for k in list(sd):                       # non-trivial biases / LN affine so every epilogue term is exercised
+        if k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    model = fclip.CLIP(sd, cdt, quick_gelu=quick)
+    assert model.grid == 9 and len(model.vblocks) == 2
+    img = torch.randn(3, 3, 126, 126, generator=g)
+    gw = torch.randn(3, 48, generator=g)
+    x = img.clone().requires_grad_(True)
+    ref = oclip.encode_image(sd, x, quick_gelu=quick)
+    (ref * gw).sum().backward()
+    xi = img.cuda().requires_grad_(True)
+    e = model.encode_image(xi)
+    (e * gw.cuda()).sum().backward()
+    assert _relrms(e, ref.detach()) < tol
+    assert _relrms(xi.grad, x.grad) < 2 * tol
+    tok = torch.zeros(2, 16, dtype=torch.long)
+    tok[:, 0], tok[0, 1:4], tok[0, 4], tok[1, 1:9], tok[1, 9] = 94, torch.tensor([5, 6, 7]), 95, torch.arange(10, 18), 95
+    assert _relrms(model.encode_text(tok.cuda()), oclip.encode_text(sd, tok, quick_gelu=quick)) < 2e-4
+
+
+def test_clip_arch_names():
+    """main.py:1308-1333: OpenAI names and openclip/<arch>/<pretrained> spellings -> architecture + activation."""
+    from feed_forward_vqgan_clip_amd import main as fmain
+    assert fmain.clip_arch("ViT-B/32") == (fclip.VIT_B32, True)
+    assert fmain.clip_arch("ViT-L/14") == (fclip.VIT_L14, True)
+    assert fmain.clip_arch("openclip/ViT-B-32-quickgelu/laion400m_e32") == (fclip.VIT_B32, True)
+    assert fmain.clip_arch("openclip/ViT-B-32/laion2b_e16") == (fclip.VIT_B32, False)
+    assert fmain.clip_arch("openclip/ViT-L-14/laion2b_s32b_b82k") == (fclip.VIT_L14, False)
+    with pytest.raises(ValueError):
+        fmain.clip_arch("RN50")
+
+
 # ----------------------------------------------------------------------------- VQGAN decoder vs oracle
 @pytest.mark.parametrize("cdt,tol", [(F32, 1e-4), (BF16, 3e-2), (F16, 4e-3)])
 def test_vqgan_decoder_matches_oracle(cuda, cdt, tol):
