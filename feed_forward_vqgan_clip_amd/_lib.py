@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FFVC_LIB") or os.path.join(_HERE, "lib", "libffvc_hip.so")   # FFVC_LIB: A/B builds of the same ABI
 
 BF16, F32, F16 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3, 4
 OP_KMAJOR, OP_TRANS, OP_CONV3X3 = 0, 1, 2
 F_BIAS_ALONG_M = 1
 F_WRITE_PREACT = 2

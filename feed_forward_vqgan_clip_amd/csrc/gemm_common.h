@@ -11,12 +11,19 @@ template <typename T>
 __device__ __forceinline__ float apply_act(int act, float v) {
   if (act == FFVC_ACT_GELU) return sizeof(T) == 2 ? act_gelu_fast(v) : act_gelu(v);
   if (act == FFVC_ACT_QUICKGELU) return act_quickgelu(v);
+  if (act == FFVC_ACT_LRELU) return v > 0.0f ? v : 0.01f * v;
+  if (act == FFVC_ACT_TANH) return tanhf(v);
   return v;
 }
 template <typename T>
 __device__ __forceinline__ float apply_act_grad(int act, float pre) {
   if (act == FFVC_ACT_GELU) return sizeof(T) == 2 ? act_gelu_grad_fast(pre) : act_gelu_grad(pre);
   if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad(pre);
+  if (act == FFVC_ACT_LRELU) return pre > 0.0f ? 1.0f : 0.01f;
+  if (act == FFVC_ACT_TANH) {
+    const float t = tanhf(pre);
+    return 1.0f - t * t;
+  }
   return 1.0f;
 }
 
@@ -133,6 +140,7 @@ __device__ __forceinline__ f32x2_t apply_act2(int act, f32x2_t v) {
   if constexpr (sizeof(T) == 2) {
     if (act == FFVC_ACT_GELU) return act_gelu_fast2(v);
     if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_fast2(v);
+    if (act == FFVC_ACT_LRELU || act == FFVC_ACT_TANH) return f32x2_t{apply_act<T>(act, v[0]), apply_act<T>(act, v[1])};
     return v;
   } else {
     f32x2_t r;
@@ -146,6 +154,8 @@ __device__ __forceinline__ f32x2_t apply_act_grad2(int act, f32x2_t pre) {
   if constexpr (sizeof(T) == 2) {
     if (act == FFVC_ACT_GELU) return act_gelu_grad_fast2(pre);
     if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad_fast2(pre);
+    if (act == FFVC_ACT_LRELU || act == FFVC_ACT_TANH)
+      return f32x2_t{apply_act_grad<T>(act, pre[0]), apply_act_grad<T>(act, pre[1])};
     f32x2_t one = {1.0f, 1.0f};
     return one;
   } else {

@@ -247,6 +247,62 @@ def clip_dim_size(config):
     return dim, size
 
 
+def encode_text(data_path, out="text_features.pkl", clip_model="ViT-B/32", clip_path=None, batch_size=256, bpe_path=None):
+    """Text-feature cache: run the frozen text tower ONCE over a prompt dataset and save the fp32
+    features; `train` on the resulting `.pkl` takes the pre-computed-feature branch of main.py:733,737 (anything that is
+    not torch.long is used as features), so the text tower leaves the training step altogether."""
+    toks = load_dataset(data_path, bpe_path=bpe_path)
+    toks = toks[0] if isinstance(toks, tuple) else toks
+    if toks.dtype != torch.long:
+        raise TypeError("encode_text: the dataset already holds features")
+    perceptor = load_clip_model(clip_model, path=clip_path)
+    feats = torch.cat([perceptor.encode_text(toks[i:i + batch_size].cuda()).float().cpu()
+                       for i in range(0, len(toks), batch_size)])
+    torch.save(feats, out)
+    return feats
+
+
+def clip_preprocess(img, size):
+    """clip.load's eval transform [upstream clip-anytorch]: bicubic resize of the short side to `size`, centre crop,
+    RGB, [0,1], CLIP mean/std.  img: PIL image -> (3, size, size) fp32."""
+    import numpy as np
+    from PIL import Image
+    w, h = img.size
+    s = size / min(w, h)
+    img = img.convert("RGB").resize((max(size, round(w * s)), max(size, round(h * s))), Image.BICUBIC)
+    w, h = img.size
+    l, t_ = (w - size) // 2, (h - size) // 2
+    a = torch.from_numpy(np.asarray(img.crop((l, t_, l + size, t_ + size)), dtype=np.float32) / 255.0).permute(2, 0, 1)
+    return (a - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+
+
+def encode_text_and_images(folder, *, img_ext="jpg", text_ext="txt", out="features.pkl", clip_model="ViT-B/32",
+                           clip_path=None, bpe_path=None, batch_size=64):
+    """main.py:231-279: (caption, image) file pairs of a folder -> (text_features, image_features) `.pkl`, the pair
+    dataset `train` consumes with `input_loss` (main.py:812-824): inputs = text features, targets = image features."""
+    from glob import glob
+
+    from PIL import Image
+
+    from . import tokenizer
+    text_paths = sorted(glob(os.path.join(folder, "*." + text_ext)))
+    if not text_paths:
+        raise FileNotFoundError(f"encode_text_and_images: no *.{text_ext} files in {folder}")
+    img_paths = [t[:-len(text_ext)] + img_ext for t in text_paths]
+    perceptor = load_clip_model(clip_model, path=clip_path)
+    size = clip_dim_size(Config(clip_model=clip_model))[1]
+    tf, imf = [], []
+    for i in range(0, len(text_paths), batch_size):
+        toks = tokenizer.tokenize([open(p).read() for p in text_paths[i:i + batch_size]], truncate=True, bpe_path=bpe_path)
+        tf.append(perceptor.encode_text(toks.cuda()).float().cpu())
+        imgs = torch.stack([clip_preprocess(Image.open(p), size) for p in img_paths[i:i + batch_size]])
+        with torch.no_grad():
+            imf.append(perceptor.encode_image(imgs.cuda()).float().cpu())
+    feats = (torch.cat(tf), torch.cat(imf))
+    torch.save(feats, out)
+    return feats
+
+
 def build_model(config, vq_channels=None):
     """main.py:448-502 (the VQGAN is NOT re-loaded here just to read z_channels; pass it in)."""
     clip_dim = clip_dim_size(config)[0]
@@ -593,8 +649,9 @@ def _save_fixed_batch(stepper, first_batch, use_ema, prefix, step, bs):
 
 
 def test(model_path, text_or_path, *, nb_repeats=1, out_path="gen.png", images_per_row=None, seed=None,
-         cdt=torch.bfloat16, bpe_path=None):
-    """main.py:977-1061 (without the Net2Net prior): prompts -> PNG grid.  `text_or_path`: "a|b|c", a `.txt` file with
+         cdt=torch.bfloat16, bpe_path=None, prior_path=None):
+    """main.py:977-1061: prompts -> PNG grid; prior_path: a `train_prior` checkpoint whose flow maps the text embedding
+    to an image-embedding sample before the mapper (main.py:1022-1023,1037-1040; prior.py).  `text_or_path`: "a|b|c", a `.txt` file with
     one prompt per line, a `.pkl` of token rows / features, or `synthetic:<n>[:seed]` token rows."""
     if seed is not None:
         torch.manual_seed(seed)
@@ -614,6 +671,9 @@ def test(model_path, text_or_path, *, nb_repeats=1, out_path="gen.png", images_p
     if config.get("normalize_input", False):
         H = torch.nn.functional.normalize(H, dim=1)
     H = H.repeat(nb_repeats, 1)
+    if prior_path:                                                                # main.py:1037-1040
+        from . import prior as _prior
+        H = _prior.load_prior_model(prior_path).sample(H.view(len(H), -1, 1, 1)).view(len(H), -1)
     if config.noise_dim:                                                          # main.py:1041-1053
         bank = getattr(net, "NOISE", None)
         if bank is not None:
@@ -639,11 +699,22 @@ def _cli(argv):
         ap.add_argument("--images-per-row", type=int, default=None)
         ap.add_argument("--seed", type=int, default=None)
         ap.add_argument("--bpe-path", default=None)
+        ap.add_argument("--prior-path", default=None)
         a = ap.parse_args(argv[1:])
         test(a.model_path, a.text_or_path, nb_repeats=a.nb_repeats, out_path=a.out_path, images_per_row=a.images_per_row,
-             seed=a.seed, bpe_path=a.bpe_path)
+             seed=a.seed, bpe_path=a.bpe_path, prior_path=a.prior_path)
         return 0
-    print("usage: python -m feed_forward_vqgan_clip_amd.main train <config.yaml> | test <model.th> <prompts> [...]",
+    if len(argv) >= 2 and argv[0] == "tokenize":
+        tokenize(argv[1], *(argv[2:3] or ["tokenized.pkl"]))
+        return 0
+    if len(argv) >= 2 and argv[0] == "encode_text":
+        encode_text(argv[1], *(argv[2:3] or ["text_features.pkl"]))
+        return 0
+    if len(argv) >= 2 and argv[0] == "encode_text_and_images":
+        encode_text_and_images(argv[1], out=(argv[2:3] or ["features.pkl"])[0])
+        return 0
+    print("usage: python -m feed_forward_vqgan_clip_amd.main train <config.yaml> | test <model.th> <prompts> [...] | "
+          "tokenize <prompts> [out.pkl] | encode_text <dataset> [out.pkl] | encode_text_and_images <folder> [out.pkl]",
           file=sys.stderr)
     return 2
 

@@ -40,6 +40,8 @@ extern "C" {
 #define FFVC_ACT_NONE 0
 #define FFVC_ACT_GELU 1      /* exact erf GELU: mlp_mixer_pytorch.py:19, vitgan.py:33 */
 #define FFVC_ACT_QUICKGELU 2 /* x*sigmoid(1.702x): cloob.py:179-181 */
+#define FFVC_ACT_LRELU 3     /* LeakyReLU(0.01): the MLPs of the Net2Net prior (main.py:1453-1462) [upstream net2net] */
+#define FFVC_ACT_TANH 4      /* tanh: scale heads of the prior's coupling blocks */
 
 /* operand storage modes */
 #define FFVC_OP_KMAJOR 0  /* operand[row][k], k contiguous                      */

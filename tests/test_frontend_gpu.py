@@ -1,0 +1,104 @@
+"""GPU tests of the rows either side of the hot path: the Net2Net prior's sampling direction against the
+oracle (parity unpinned upstream: net2net is absent, see oracle/prior.py), the text-feature cache and the (text, image)
+pair-feature dataset that `train` consumes with `input_loss` (main.py:231-279, 733-737, 812-824), and `test(...,
+prior_path=...)` (main.py:1022-1023,1037-1040)."""
+import gzip
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from feed_forward_vqgan_clip_amd import main as fmain  # noqa: E402
+from feed_forward_vqgan_clip_amd import prior as fprior  # noqa: E402
+
+
+def _relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("C,D,E,H,depth,flows,B", [(16, 24, 8, 32, 2, 3, 5), (512, 512, 64, 256, 2, 4, 7), (6, 4, 4, 8, 1, 1, 1)])
+def test_prior_reverse_matches_oracle_and_inverts_forward(cuda, C, D, E, H, depth, flows, B):
+    from oracle import prior as oprior
+    sd = fprior.random_state_dict(C, D, E, H, depth, flows, seed=3)
+    flow = fprior.ConditionalFlatCouplingFlow(sd, in_channels=C, conditioning_dim=D, n_flows=flows)
+    g = torch.Generator().manual_seed(9)
+    z, cond = torch.randn(B, C, generator=g), torch.randn(B, D, generator=g)
+    x = flow.reverse(z, cond.view(B, D, 1, 1))
+    assert tuple(x.shape) == (B, C, 1, 1)
+    ref = oprior.reverse(sd, z, cond, flows)
+    assert _relmax(x.view(B, C), ref) < 2e-4          # exact-fp32 MFMA vs CPU fp32: summation order only
+    zz, logdet = flow.forward(x, cond)
+    assert _relmax(zz.view(B, C), z) < 1e-3 and tuple(logdet.shape) == (B,) and torch.isfinite(logdet).all()
+    s = flow.sample(cond.view(B, D, 1, 1), generator=torch.Generator().manual_seed(1))
+    s2 = flow.sample(cond.view(B, D, 1, 1), generator=torch.Generator().manual_seed(1))
+    assert torch.equal(s, s2) and tuple(s.shape) == (B, C, 1, 1)
+
+
+def test_prior_checkpoint_layout_roundtrip(cuda, tmp_path):
+    """The dict `train_prior` writes (main.py:1423-1431) loads through load_prior_model (main.py:1447-1451)."""
+    sd = fprior.random_state_dict(8, 8, 4, 16, 2, 2, seed=1)
+    cfg = {"model": {"embedding_dim": 4, "hidden_dim": 16, "hidden_depth": 2, "n_flows": 2}}
+    p = tmp_path / "prior.th"
+    torch.save({"model": sd, "step": 7, "input_size": 8, "output_size": 8, "config": cfg}, p)
+    flow = fprior.load_prior_model(str(p))
+    assert flow.n_flows == 2 and flow.in_channels == 8
+    assert tuple(flow.sample(torch.randn(3, 8, 1, 1)).shape) == (3, 8, 1, 1)
+
+
+def _vocab(tmp_path):
+    p = tmp_path / "bpe.txt.gz"
+    with gzip.open(p, "wt", encoding="utf-8") as f:
+        f.write("\n".join(["#version: test", "c a", "ca t</w>", "d o", "do g</w>", "a t</w>"]) + "\n")
+    return str(p)
+
+
+def test_text_feature_cache_feeds_the_feature_branch(cuda, tmp_path):
+    """encode_text writes what encode_text returns; a TrainStep fed those rows (not torch.long -> used as features,
+    main.py:733) reproduces the loss of the same step fed the tokens."""
+    toks = fmain.synthetic_tokens(6, seed=4)
+    tp = tmp_path / "tok.pkl"
+    torch.save(toks, tp)
+    out = tmp_path / "feat.pkl"
+    feats = fmain.encode_text(str(tp), out=str(out), clip_path="random:5", batch_size=4)
+    assert feats.dtype == torch.float32 and tuple(feats.shape) == (6, 512)
+    loaded = fmain.load_dataset(str(out))
+    assert torch.equal(loaded, feats)
+    perceptor = fmain.load_clip_model("ViT-B/32", path="random:5", cdt=torch.float32)
+    assert _relmax(perceptor.encode_text(toks.cuda()), feats) < 1e-5
+    with pytest.raises(TypeError):
+        fmain.encode_text(str(out), out=str(tmp_path / "again.pkl"), clip_path="random:5")
+
+
+def test_encode_text_and_images_pairs(cuda, tmp_path):
+    """main.py:231-279 on a folder of (caption, image) files: features equal the towers' outputs on the same inputs, in
+    sorted file order, and the saved tuple is what load_dataset hands to train (inputs, targets)."""
+    import numpy as np
+    from PIL import Image
+    vocab = _vocab(tmp_path)
+    folder = tmp_path / "pairs"
+    folder.mkdir()
+    rng = np.random.RandomState(0)
+    caps = {"a": "cat", "b": "dog cat", "c": "a dog"}
+    for name, cap in caps.items():
+        (folder / f"{name}.txt").write_text(cap)
+        Image.fromarray(rng.randint(0, 255, (40 + 8 * len(cap), 56, 3), dtype=np.uint8)).save(folder / f"{name}.png")
+    out = tmp_path / "features.pkl"
+    tf, imf = fmain.encode_text_and_images(str(folder), img_ext="png", out=str(out), clip_path="random:5", bpe_path=vocab,
+                                           batch_size=2)
+    assert tuple(tf.shape) == (3, 512) and tuple(imf.shape) == (3, 512)
+    inp, tgt = fmain.load_dataset(str(out))
+    assert torch.equal(inp, tf) and torch.equal(tgt, imf)
+    perceptor = fmain.load_clip_model("ViT-B/32", path="random:5")
+    from feed_forward_vqgan_clip_amd import tokenizer
+    toks = tokenizer.tokenize([caps[k] for k in sorted(caps)], truncate=True, bpe_path=vocab)
+    assert _relmax(perceptor.encode_text(toks.cuda()), tf) < 1e-5
+    img = fmain.clip_preprocess(Image.open(folder / "b.png"), 224)
+    assert tuple(img.shape) == (3, 224, 224)
+    with torch.no_grad():
+        e = perceptor.encode_image(img[None].cuda()).float().cpu()
+    assert _relmax(e, imf[1:2]) < 2e-2                                    # bf16 tower, batch-size independent up to rounding
+    with pytest.raises(FileNotFoundError):
+        fmain.encode_text_and_images(str(tmp_path), out=str(out), clip_path="random:5", bpe_path=vocab)

@@ -293,6 +293,15 @@ def test_train_checkpoint_resume_load_model_and_test_cli(cuda, tmp_path):
     assert Image.open(out).size == (2 * 258 + 2, 3 * 258 + 2)
     assert fmain._cli(["test", str(tmp_path / "checkpoint.th"), "synthetic:2", "--out-path", str(tmp_path / "g2.png")]) == 0
     assert os.path.exists(tmp_path / "g2.png")
+    # with a Net2Net prior between the text embedding and the mapper (main.py:1022-1023,1037-1040)
+    from feed_forward_vqgan_clip_amd import prior as fprior
+    clip_dim = fmain.clip_dim_size(net.config)[0]
+    torch.save({"model": fprior.random_state_dict(clip_dim, clip_dim, 16, 32, 2, 2, seed=2), "step": 0, "input_size": clip_dim,
+                "output_size": clip_dim, "config": {"model": {"embedding_dim": 16, "hidden_dim": 32, "hidden_depth": 2,
+                                                              "n_flows": 2}}}, tmp_path / "prior.th")
+    xp = fmain.test(str(tmp_path / "checkpoint.th"), "synthetic:3:1", out_path=str(tmp_path / "g3.png"), seed=0,
+                    prior_path=str(tmp_path / "prior.th"))
+    assert tuple(xp.shape) == (3, 3, 256, 256) and not torch.equal(xp, xr[:3])
 
 
 # ----------------------------------------------------------------------------- the wider augmentation set
