@@ -12,7 +12,13 @@ resample  out(x) = C * in(A^-1(P^-1(x))) + c0  (zero outside P's source square, 
     'Ro'  RandomRotation(degrees=15, p=0.7)                   angle U(-15,15) deg about the centre
     'Re'  RandomResizedCrop(scale=(0.1,1), ratio=(3/4,4/3), p=1)   crop of area U(.1,1)*S^2, log-uniform aspect, resized
     'Re2' RandomResizedCrop(scale=(0.9,1), ...)
-    'Cr'  RandomCrop(cut_size, p=0.5), 'Cc' CenterCrop(cut_size)   identities here: the batch already has cut_size
+    'R'   Resize(cut_size): bilinear, align_corners=False (main.py:145-152) — identity when the source already has cut_size
+    'Cr'  RandomCrop(cut_size, p=0.5), 'Cc' CenterCrop(cut_size)   identities when the source already has cut_size; on a
+          larger source (pool_size > cut_size or pool=False) a random / centred integer window (the crop is always taken:
+          a batch cannot mix sizes)
+  The chain tracks the current image side: it starts at `src_size` (pool_size, or the raw image side with pool=False) and
+  becomes cut_size after 'R' / 'Re' / 'Re2' / 'Cr' / 'Cc' (out_size()).  Zero padding of
+  'Pe' / 'Ro' is tested against the source frame (exact for resizes, approximate after a crop).
   colour (a 3x3 matrix + offset, composed in list order):
     'Ji'  ColorJitter(hue=0.1, saturation=0.1, p=0.7)         hue U(-.1,.1) turns, saturation U(.9,1.1), in the YIQ plane
     'Ji2' ColorJitter(brightness=.1, contrast=.1, saturation=.05, hue=.05, p=0.5)   brightness additive U(-.1,.1),
@@ -27,7 +33,8 @@ import math
 
 import torch
 
-SUPPORTED = ("Af", "Pe", "Ji", "Er", "Ro", "Re", "Re2", "Cr", "Cc", "Ji2", "Er2", "Gn")
+SUPPORTED = ("Af", "Pe", "Ji", "Er", "Ro", "Re", "Re2", "Cr", "Cc", "Ji2", "Er2", "Gn", "R")
+RESIZING = ("R", "Re", "Re2", "Cr", "Cc")
 DEFAULT = ("Af", "Pe", "Ji", "Er")
 _YIQ = torch.tensor([[0.299, 0.587, 0.114], [0.5959, -0.2746, -0.3213], [0.2115, -0.5227, 0.3112]], dtype=torch.float64)
 _YIQ_INV = torch.linalg.inv(_YIQ)
@@ -56,14 +63,24 @@ def _rot_about_centre(th, c):
     return M
 
 
-def draw_params(N, S, augs=DEFAULT, generator=None, p=0.7):
+def out_size(S, augs, src_size=None):
+    """Side of the augmented batch: cut_size once the chain holds a resize / crop, else the source's side."""
+    return S if (src_size is None or src_size == S or any(a in RESIZING for a in augs)) else src_size
+
+
+def draw_params(N, S, augs=DEFAULT, generator=None, p=0.7, src_size=None):
     """-> dict of CPU tensors: pinv (N,9) f32, ainv (N,6) f32, cmat (N,9) f32, coff (N,3) f32, erase (N,4) i32,
-    gn (N,) f32 (std of the extra per-sample Gaussian noise, 0 = none).  `p` overrides the 0.7 of the default set."""
+    gn (N,) f32 (std of the extra per-sample Gaussian noise, 0 = none).  S = cut_size, src_size = side of the image the
+    chain starts from (default S; the finished batch then has side out_size(S, augs, src_size)).  `p` overrides the 0.7 of
+    the default set."""
     for a in augs:
         if a not in SUPPORTED:
             raise NotImplementedError(f"augmentation '{a}' is not built on the HIP path (built: {SUPPORTED} and 'R')")
     g = generator
     rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    cut = S
+    S = int(src_size or cut)                                          # current side of the image as the chain advances
+    fin = out_size(cut, augs, S)                                       # side of the finished batch (erase rectangles live there)
     c = (S - 1) / 2.0
     eye3 = torch.eye(3, dtype=torch.float64)
     ainv = torch.tensor([1.0, 0, 0, 0, 1.0, 0], dtype=torch.float64).repeat(N, 1)
@@ -76,12 +93,12 @@ def draw_params(N, S, augs=DEFAULT, generator=None, p=0.7):
 
     def rect(n):
         """n erase rectangles (x0, y0, x1, y1): area U(.1,.4)*S^2, aspect log-uniform in (.3, 1/.3)."""
-        area = (0.1 + 0.3 * rnd(n)) * S * S
+        area = (0.1 + 0.3 * rnd(n)) * fin * fin
         aspect = torch.exp(math.log(0.3) + rnd(n) * (math.log(1 / 0.3) - math.log(0.3)))
-        h = torch.sqrt(area * aspect).round().clamp(1, S)
-        w = torch.sqrt(area / aspect).round().clamp(1, S)
-        x0 = (rnd(n) * (S - w + 1)).floor()
-        y0 = (rnd(n) * (S - h + 1)).floor()
+        h = torch.sqrt(area * aspect).round().clamp(1, fin)
+        w = torch.sqrt(area / aspect).round().clamp(1, fin)
+        x0 = (rnd(n) * (fin - w + 1)).floor()
+        y0 = (rnd(n) * (fin - h + 1)).floor()
         return torch.stack([x0, y0, x0 + w, y0 + h], dim=1).to(torch.int32)
 
     for a in augs:
@@ -119,16 +136,38 @@ def draw_params(N, S, augs=DEFAULT, generator=None, p=0.7):
             w = torch.sqrt(area * ratio).clamp(1, S)
             h = torch.sqrt(area / ratio).clamp(1, S)
             x0, y0 = rnd(N) * (S - w), rnd(N) * (S - h)
-            M = torch.zeros(N, 3, 3, dtype=torch.float64)            # crop [x0, x0+w-1] x [y0, y0+h-1] -> [0, S-1]^2
-            M[:, 0, 0] = (S - 1) / (w - 1).clamp_min(1e-6)
-            M[:, 1, 1] = (S - 1) / (h - 1).clamp_min(1e-6)
+            M = torch.zeros(N, 3, 3, dtype=torch.float64)            # crop [x0, x0+w-1] x [y0, y0+h-1] -> [0, cut-1]^2
+            M[:, 0, 0] = (cut - 1) / (w - 1).clamp_min(1e-6)
+            M[:, 1, 1] = (cut - 1) / (h - 1).clamp_min(1e-6)
             M[:, 0, 2] = -x0 * M[:, 0, 0]
             M[:, 1, 2] = -y0 * M[:, 1, 1]
             M[:, 2, 2] = 1.0
             Hfwd = M @ Hfwd
             first_geo = False
+            S, c = cut, (cut - 1) / 2.0
+        elif a == "R":
+            if S != cut:                                             # x_out = (x_in + .5) * cut / S - .5  (align_corners=False)
+                M = torch.zeros(N, 3, 3, dtype=torch.float64)
+                M[:, 0, 0] = M[:, 1, 1] = cut / S
+                M[:, 0, 2] = M[:, 1, 2] = 0.5 * cut / S - 0.5
+                M[:, 2, 2] = 1.0
+                Hfwd = M @ Hfwd
+                first_geo = False
+                S, c = cut, (cut - 1) / 2.0
         elif a in ("Cr", "Cc"):
-            pass                                                     # crop to cut_size of a cut_size image
+            if S < cut:
+                raise ValueError(f"'{a}': the image ({S}) is smaller than cut_size ({cut})")
+            if S > cut:                                              # integer window of the current image
+                if a == "Cr":
+                    x0 = (rnd(N) * (S - cut + 1)).floor()
+                    y0 = (rnd(N) * (S - cut + 1)).floor()
+                else:
+                    x0 = y0 = torch.full((N,), float((S - cut) // 2), dtype=torch.float64)
+                M = eye3.reshape(1, 3, 3).repeat(N, 1, 1)
+                M[:, 0, 2], M[:, 1, 2] = -x0, -y0
+                Hfwd = M @ Hfwd
+                first_geo = False
+                S, c = cut, (cut - 1) / 2.0
         elif a in ("Ji", "Ji2"):
             hue, sat, pj = (0.1, 0.1, p) if a == "Ji" else (0.05, 0.05, 0.5)
             on = rnd(N) < pj

@@ -639,6 +639,8 @@ struct AugSample {
   int x0, y0;
   float wx, wy, m;
 };
+// S = side of the SOURCE image (the frame of the affine slot); the output grid may have another size (a resize / crop
+// in the chain is part of pinv).
 __device__ __forceinline__ AugSample aug_coords(const float* __restrict__ pinv, const float* __restrict__ ainv, int ox,
                                                 int oy, int S) {
   const float x2 = (float)ox, y2 = (float)oy;
@@ -664,8 +666,8 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                           const int* __restrict__ erase, const float* __restrict__ noise,
                                                           const float* __restrict__ facs, const float* __restrict__ coff,
-                                                          OT* __restrict__ out, int B, int S, int cutn, int P, float m0,
-                                                          float m1, float m2, float s0, float s1, float s2) {
+                                                          OT* __restrict__ out, int B, int S, int Ss, int cutn, int P,
+                                                          float m0, float m1, float m2, float s0, float s1, float s2) {
   const int gw = S / P;
   const int64_t n_px = (int64_t)cutn * B * S * S;
   const int64_t per_img = (int64_t)3 * S * S;
@@ -676,14 +678,14 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
     const int oy = (int)(t % S);
     const int n = (int)(t / S);
     const int b = n % B;
-    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, S);
+    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, Ss);
     const int* er = erase + n * 4;
     const bool erased = ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3];
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float* src = pooled + ((int64_t)b * 3 + c) * S * S + (int64_t)a.y0 * S + a.x0;
-      const float v00 = src[0], v01 = src[1], v10 = src[S], v11 = src[S + 1];
+      const float* src = pooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
+      const float v00 = src[0], v01 = src[1], v10 = src[Ss], v11 = src[Ss + 1];
       rgb[c] = a.m * ((1.f - a.wy) * ((1.f - a.wx) * v00 + a.wx * v01) + a.wy * ((1.f - a.wx) * v10 + a.wx * v11));
     }
     const float* cm = cmat + n * 9;
@@ -703,7 +705,7 @@ template <typename GT>
 __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__ gout, const float* __restrict__ pinv,
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                           const int* __restrict__ erase, float* __restrict__ dpooled, int B,
-                                                          int S, int cutn, int P, float s0, float s1, float s2) {
+                                                          int S, int Ss, int cutn, int P, float s0, float s1, float s2) {
   const int gw = S / P;
   const int64_t n_px = (int64_t)cutn * B * S * S;
   const int64_t per_img = (int64_t)3 * S * S;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
     const int b = n % B;
     const int* er = erase + n * 4;
     if (ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3]) continue;
-    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, S);
+    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, Ss);
     if (a.m == 0.0f) continue;
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
     float g[3];
@@ -730,12 +732,74 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float gc = cm[c] * g[0] + cm[3 + c] * g[1] + cm[6 + c] * g[2];          // transpose of the colour matrix
-      float* dst = dpooled + ((int64_t)b * 3 + c) * S * S + (int64_t)a.y0 * S + a.x0;
+      float* dst = dpooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
       atomicAdd(dst, gc * w00);
       atomicAdd(dst + 1, gc * w01);
-      atomicAdd(dst + S, gc * w10);
-      atomicAdd(dst + S + 1, gc * w11);
+      atomicAdd(dst + Ss, gc * w10);
+      atomicAdd(dst + Ss + 1, gc * w11);
     }
+  }
+}
+
+// MakeCutouts(interpolate=True) (main.py:226-228): adaptive average pooling of the augmented batch x [N,3,S,S] fp32 to So x So,
+// then mean/std and the ViT patch layout.  The backward spreads g/std/|window| over each window.
+template <typename OT>
+__global__ __launch_bounds__(256) void avgpool_patches_fwd_kernel(const float* __restrict__ x, OT* __restrict__ out, int N, int S,
+                                                                  int So, int P, float m0, float m1, float m2, float s0,
+                                                                  float s1, float s2) {
+  const int gw = So / P;
+  const int64_t n = (int64_t)N * 3 * So * So;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % So);
+    int64_t t = i / So;
+    const int oy = (int)(t % So);
+    t /= So;
+    const int ch = (int)(t % 3);
+    const int img = (int)(t / 3);
+    const int y0 = apool_start(oy, S, So), y1 = apool_end(oy, S, So);
+    const int x0 = apool_start(ox, S, So), x1 = apool_end(ox, S, So);
+    const float* src = x + ((int64_t)img * 3 + ch) * S * S;
+    float sum = 0.f;
+    for (int y = y0; y < y1; ++y)
+      for (int xx = x0; xx < x1; ++xx) sum += src[(int64_t)y * S + xx];
+    const float v = sum / (float)((y1 - y0) * (x1 - x0));
+    const float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+    const float istd = 1.0f / (ch == 0 ? s0 : (ch == 1 ? s1 : s2));
+    const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+    const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)ch * P * P + ky * P + kx;
+    ElemTraits<OT>::store(out + (int64_t)img * 3 * So * So + prow, (v - mean) * istd);
+  }
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void avgpool_patches_bwd_kernel(const GT* __restrict__ gout, float* __restrict__ dx, int N, int S,
+                                                                  int So, int P, float s0, float s1, float s2) {
+  const int gw = So / P;
+  const int64_t n = (int64_t)N * 3 * S * S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % S);
+    int64_t t = i / S;
+    const int y = (int)(t % S);
+    t /= S;
+    const int ch = (int)(t % 3);
+    const int img = (int)(t / 3);
+    const float istd = 1.0f / (ch == 0 ? s0 : (ch == 1 ? s1 : s2));
+    // output cells whose window [start(o), end(o)) holds this pixel: a contiguous range around floor(y*So/S)
+    float acc = 0.f;
+    const int oyc = (int)(((int64_t)y * So) / S), oxc = (int)(((int64_t)x * So) / S);
+    const int r = So > S ? (So + S - 1) / S + 1 : 1;
+    for (int oy = max(0, oyc - r); oy <= min(So - 1, oyc + r); ++oy) {
+      const int y0 = apool_start(oy, S, So), y1 = apool_end(oy, S, So);
+      if (y < y0 || y >= y1) continue;
+      for (int ox = max(0, oxc - r); ox <= min(So - 1, oxc + r); ++ox) {
+        const int x0 = apool_start(ox, S, So), x1 = apool_end(ox, S, So);
+        if (x < x0 || x >= x1) continue;
+        const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+        const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)ch * P * P + ky * P + kx;
+        acc += ElemTraits<GT>::load(gout + (int64_t)img * 3 * So * So + prow) / (float)((y1 - y0) * (x1 - x0));
+      }
+    }
+    dx[i] = acc * istd;
   }
 }
 
@@ -1098,35 +1162,56 @@ extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nsl
 
 extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
                                 const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
-                                int S, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
+                                int S, int S_src, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
                                 float std_g, float std_b, void* stream) {
   FFVC_CHECK_ARG(pooled && pinv && ainv && cmat && erase && out, "ffvc_augment_fwd: null pointer");
-  FFVC_CHECK_ARG(B > 0 && S > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_fwd: bad geometry");
+  FFVC_CHECK_ARG(B > 0 && S > 1 && S_src > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_fwd: bad geometry");
   FFVC_CHECK_ARG((noise == nullptr) == (facs == nullptr), "ffvc_augment_fwd: noise and facs go together");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)cutn * B * S * S;
   DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
-                                                pinv, ainv, cmat, erase, noise, facs, coff, (OT*)out, B, S, cutn, patch, mean_r,
+                                                pinv, ainv, cmat, erase, noise, facs, coff, (OT*)out, B, S, S_src, cutn, patch, mean_r,
                                                 mean_g, mean_b, std_r, std_g, std_b));
   FFVC_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
-                                const int32_t* erase, float* dpooled, int B, int S, int cutn, int patch, float std_r,
-                                float std_g, float std_b, void* stream) {
+                                const int32_t* erase, float* dpooled, int B, int S, int S_src, int cutn, int patch,
+                                float std_r, float std_g, float std_b, void* stream) {
   FFVC_CHECK_ARG(gout && pinv && ainv && cmat && erase && dpooled, "ffvc_augment_bwd: null pointer");
-  FFVC_CHECK_ARG(B > 0 && S > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_bwd: bad geometry");
+  FFVC_CHECK_ARG(B > 0 && S > 1 && S_src > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_bwd: bad geometry");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dpooled, 0, (size_t)B * 3 * S * S * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(dpooled, 0, (size_t)B * 3 * S_src * S_src * sizeof(float), st);
   if (e != hipSuccess) {
     ffvc_set_error("ffvc_augment_bwd: memset failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   const int64_t n = (int64_t)cutn * B * S * S;
   DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
-                                              (const GT*)gout, pinv, ainv, cmat, erase, dpooled, B, S, cutn, patch, std_r,
+                                              (const GT*)gout, pinv, ainv, cmat, erase, dpooled, B, S, S_src, cutn, patch, std_r,
                                               std_g, std_b));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_avgpool_patches_fwd(const float* x, void* out, int out_dtype, int N, int S, int So, int patch, float mean_r,
+                                        float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(x && out && N > 0 && S > 0 && So > 0 && patch > 0 && So % patch == 0, "ffvc_avgpool_patches_fwd: bad args");
+  const int64_t n = (int64_t)N * 3 * So * So;
+  DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((avgpool_patches_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0,
+                                                (hipStream_t)stream, x, (OT*)out, N, S, So, patch, mean_r, mean_g, mean_b,
+                                                std_r, std_g, std_b));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_avgpool_patches_bwd(const void* gout, int g_dtype, float* dx, int N, int S, int So, int patch, float std_r,
+                                        float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(gout && dx && N > 0 && S > 0 && So > 0 && patch > 0 && So % patch == 0, "ffvc_avgpool_patches_bwd: bad args");
+  const int64_t n = (int64_t)N * 3 * S * S;
+  DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((avgpool_patches_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0,
+                                              (hipStream_t)stream, (const GT*)gout, dx, N, S, So, patch, std_r, std_g, std_b));
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -778,23 +778,46 @@ def set_option(name, value):
     _call("ffvc_set_option", name.encode(), int(value))
 
 
-def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None, coff=None):
+def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None, coff=None,
+                out_size=None):
+    """pooled (B,3,Ss,Ss) fp32 -> patch rows of cutn*B cutouts of side out_size (default Ss)."""
     _req_f32(pooled, pinv, ainv, cmat, noise, facs, coff)
     _req(torch.int32, erase)
-    B, _, S, _ = pooled.shape
+    B, _, Ss, _ = pooled.shape
+    S = out_size or Ss
     g = S // patch
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
     _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), erase.data_ptr(),
-          _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, cutn, patch, mean[0], mean[1], mean[2],
+          _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, Ss, cutn, patch, mean[0], mean[1], mean[2],
           std[0], std[1], std[2], stream_ptr())
     return out
 
 
-def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std):
+def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=None):
     _req_f32(pinv, ainv, cmat)
     _req(torch.int32, erase)
     _need_cuda(gout)
-    dpooled = torch.empty(B, 3, S, S, dtype=torch.float32, device=gout.device)
+    Ss = src_size or S
+    dpooled = torch.empty(B, 3, Ss, Ss, dtype=torch.float32, device=gout.device)
     _call("ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
-          erase.data_ptr(), dpooled.data_ptr(), B, S, cutn, patch, std[0], std[1], std[2], stream_ptr())
+          erase.data_ptr(), dpooled.data_ptr(), B, S, Ss, cutn, patch, std[0], std[1], std[2], stream_ptr())
     return dpooled
+
+
+def avgpool_patches_fwd(x, out_size, patch, mean, std, out_dtype):
+    """x (N,3,S,S) fp32 -> adaptive average pool to out_size, mean/std, ViT patch rows (main.py:226-228 + :797)."""
+    _req_f32(x)
+    N, _, S, _ = x.shape
+    g = out_size // patch
+    out = torch.empty(N, g * g, 3 * patch * patch, dtype=out_dtype, device=x.device)
+    _call("ffvc_avgpool_patches_fwd", x.data_ptr(), out.data_ptr(), dtype_code(out_dtype), N, S, out_size, patch, mean[0],
+          mean[1], mean[2], std[0], std[1], std[2], stream_ptr())
+    return out
+
+
+def avgpool_patches_bwd(gout, N, S, out_size, patch, std):
+    _need_cuda(gout)
+    dx = torch.empty(N, 3, S, S, dtype=torch.float32, device=gout.device)
+    _call("ffvc_avgpool_patches_bwd", gout.data_ptr(), dtype_code(gout.dtype), dx.data_ptr(), N, S, out_size, patch, std[0],
+          std[1], std[2], stream_ptr())
+    return dx

@@ -81,32 +81,52 @@ replace_grad = _ReplaceGrad.apply
 
 
 class MakeCutouts(nn.Module):
-    """main.py:154-229.  The pooling branch ((AdaptiveAvg+AdaptiveMax)/2 -> repeat cutn), the additive noise
-    `U(0,noise_fac)*N(0,1)` and the augmentation list as ONE fused resampling kernel (ffvc_augment_fwd/bwd) driven by
-    per-cutout parameters (augment.py): 'R' (identity at pool_size == cut_size), 'Af','Pe','Ji','Er' (the default set),
-    'Ro','Re','Re2','Cr','Cc','Ji2','Er2','Gn'.  'Sh','Et','Ts' (sharpness / elastic / thin-plate spline) and the
-    pool=False / interpolate / pool_size != cut_size branches are not built and raise."""
+    """main.py:154-229.  Source image = (AdaptiveAvg+AdaptiveMax)/2 pooling to pool_size (pool=True, :213-215) or the
+    decoded image itself (pool=False, :216-217), repeated cutn times; then the augmentation list as ONE fused resampling
+    kernel (ffvc_augment_fwd/bwd) driven by per-cutout parameters (augment.py): 'R' (bilinear resize to cut_size),
+    'Af','Pe','Ji','Er' (the default set), 'Ro','Re','Re2','Cr','Cc','Ji2','Er2','Gn'; the additive noise
+    `U(0,noise_fac)*N(0,1)` (:222-225); with interpolate=True adaptive average pooling to interp_size (:226-228).
+    'Sh','Et','Ts' (sharpness / elastic / thin-plate spline: 3x3 and displacement-field operators that do not compose into
+    one homography) are not built and raise."""
 
     def __init__(self, cut_size, cutn, cut_pow=1.0, pool_size=None, interp_size=None, augs=None, pool=True,
                  interpolate=False):
         super().__init__()
         augs = tuple(augs) if augs else ("Af", "Pe", "Ji", "Er")      # main.py:164-165 (empty list -> defaults)
-        self.augs = tuple(a for a in augs if a != "R")                # 'R' = resize to cut_size: identity at pool_size == cut_size
-        for a in self.augs:
+        for a in augs:
             if a not in _augment.SUPPORTED:
-                raise NotImplementedError(f"augs={list(augs)}: '{a}' is not built on the HIP path (built: 'R' and "
+                raise NotImplementedError(f"augs={list(augs)}: '{a}' is not built on the HIP path (built: "
                                           f"{list(_augment.SUPPORTED)})")
-        pool_size = pool_size or cut_size
-        if not pool or interpolate or pool_size != cut_size:
-            raise NotImplementedError("MakeCutouts: only pool=True, interpolate=False, pool_size == cut_size")
+        self.all_augs = augs
+        self.augs = tuple(a for a in augs if a != "R")                # what is left when 'R' is the identity
+        self.pool, self.interpolate = bool(pool), bool(interpolate)
+        self.pool_size = pool_size or cut_size                         # main.py:200-201
+        self.interp_size = interp_size or self.pool_size              # main.py:202-203
         self.cut_size, self.cutn, self.noise_fac = cut_size, cutn, 0.1
         self.generator = None                                         # torch.Generator for reproducible parameter draws
 
-    def draw_aug_params(self, n, device):
-        """Per-cutout augmentation parameters (None when only 'R' is configured)."""
-        if not self.augs:
+    def _plain(self, H):
+        """Only the pooling branch + noise: the single-kernel cutouts path."""
+        return self.pool and self.pool_size == self.cut_size and not self.augs and \
+            not (self.interpolate and self.interp_size != self.cut_size)
+
+    def source_size(self, H):
+        return self.pool_size if self.pool else H
+
+    def batch_size_px(self, H):
+        """Side of the augmented batch before the optional interpolate step (what the noise tensor must have)."""
+        return _augment.out_size(self.cut_size, self.all_augs, self.source_size(H))
+
+    def out_size_px(self, H):
+        return self.interp_size if self.interpolate else self.batch_size_px(H)
+
+    def draw_aug_params(self, n, device, H=None):
+        """Per-cutout augmentation parameters (None when the configuration needs no resampling)."""
+        src = self.source_size(H if H is not None else self.cut_size)
+        if not self.augs and src == self.cut_size:
             return None
-        prm = _augment.draw_params(n, self.cut_size, self.augs, generator=self.generator)
+        prm = _augment.draw_params(n, self.cut_size, self.all_augs if src != self.cut_size else self.augs,
+                                   generator=self.generator, src_size=src)
         if torch.device(device).type != "cuda":
             return prm
         # pinned staging (caching host allocator) keeps the upload asynchronous: a pageable copy would stall the host
@@ -115,36 +135,48 @@ class MakeCutouts(nn.Module):
 
     def patches(self, xr_nhwc, patch, mean, std, out_dtype, facs=None, noise=None, aug_params=None):
         """NHWC fp32 image batch -> normalised ViT patch rows with the configured augmentations (fused path)."""
-        B = xr_nhwc.shape[0]
+        B, H = xr_nhwc.shape[0], xr_nhwc.shape[1]
         n = self.cutn * B
+        size = self.batch_size_px(H)
         if facs is None and self.noise_fac:
-            facs, noise = self.draw_noise(n, xr_nhwc.device)
-        if not self.augs:
+            facs, noise = self.draw_noise(n, xr_nhwc.device, size)
+        if self._plain(H):
             return ops.cutouts(xr_nhwc, self.cut_size, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
+        src = self.source_size(H)
         if aug_params is None:
-            aug_params = self.draw_aug_params(n, xr_nhwc.device)
+            aug_params = self.draw_aug_params(n, xr_nhwc.device, H)
+        if aug_params is None:                                        # identity chain: still goes through the resampler
+            aug_params = _augment.draw_params(n, self.cut_size, (), src_size=src)
+            aug_params = {k: v.to(xr_nhwc.device) for k, v in aug_params.items()}
         gn = aug_params.get("gn")
         if gn is not None and "Gn" in self.augs:       # 'Gn' N(0,1) noise + the U(0,noise_fac)*N(0,1) term = one Gaussian
             if noise is None:
-                noise = torch.randn(n, 3, self.cut_size, self.cut_size, device=xr_nhwc.device)
+                noise = torch.randn(n, 3, size, size, device=xr_nhwc.device)
             facs = gn.to(xr_nhwc.device) if facs is None else torch.sqrt(facs * facs + gn.to(facs.device) ** 2)
-        pooled = ops.cutouts(xr_nhwc, self.cut_size, 1, self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32)
-        pooled = pooled.view(B, 3, self.cut_size, self.cut_size)
-        return ops.augment(pooled, aug_params, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs)
+        # pool=False: the same kernel at cut == H is the identity pooling, i.e. a NHWC -> NCHW copy of the decoded image
+        pooled = ops.cutouts(xr_nhwc, src, 1, src, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32).view(B, 3, src, src)
+        if not self.interpolate or self.interp_size == size:
+            return ops.augment(pooled, aug_params, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs,
+                               out_size=size)
+        batch = ops.augment(pooled, aug_params, self.cutn, size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32, noise=noise,
+                            facs=facs, out_size=size).view(n, 3, size, size)
+        return ops.avgpool_patches(batch, self.interp_size, patch, mean, std, out_dtype)          # main.py:226-228
 
-    def draw_noise(self, n, device):
+    def draw_noise(self, n, device, size=None):
         if not self.noise_fac:
             return None, None
+        size = size or self.cut_size
         facs = torch.empty(n, device=device).uniform_(0, self.noise_fac)             # main.py:224
-        noise = torch.randn(n, 3, self.cut_size, self.cut_size, device=device)       # main.py:225
+        noise = torch.randn(n, 3, size, size, device=device)                         # main.py:225
         return facs, noise
 
     def forward(self, input, facs=None, noise=None, aug_params=None):
-        """(B,3,H,W) in [0,1] -> (cutn*B, 3, cut, cut) fp32, cut-major like `repeat(cutn,1,1,1)` (main.py:218)."""
+        """(B,3,H,W) in [0,1] -> (cutn*B, 3, S, S) fp32, cut-major like `repeat(cutn,1,1,1)` (main.py:218); S = cut_size
+        for every configuration whose chain resizes / crops (or interp_size with interpolate=True)."""
         xr = input.permute(0, 2, 3, 1)
-        out = self.patches(xr.float(), self.cut_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32, facs, noise,
-                           aug_params)
-        return out.view(self.cutn * input.shape[0], 3, self.cut_size, self.cut_size)
+        S = self.out_size_px(input.shape[2])
+        out = self.patches(xr.float(), S, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32, facs, noise, aug_params)
+        return out.view(self.cutn * input.shape[0], 3, S, S)
 
 
 def tv_loss(Y_hat):

@@ -698,27 +698,47 @@ def cutouts(xr, cut, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
 
 
 class _AugmentFn(Function):
-    """Fused default augmentation chain on the pooled image (kernels.augment_fwd / augment_bwd)."""
+    """Fused augmentation chain on the pooled image (kernels.augment_fwd / augment_bwd)."""
 
     @staticmethod
-    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None):
+    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None, out_size=None):
         pooled = _contig(pooled)
         ctx.save_for_backward(pinv, ainv, cmat, erase)
-        ctx.cfg = (pooled.shape[0], pooled.shape[2], cutn, patch, std)
+        ctx.cfg = (pooled.shape[0], out_size or pooled.shape[2], pooled.shape[2], cutn, patch, std)
         return K.augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs,
-                             coff=coff)
+                             coff=coff, out_size=out_size)
 
     @staticmethod
     def backward(ctx, g):
         pinv, ainv, cmat, erase = ctx.saved_tensors
-        B, S, cutn, patch, std = ctx.cfg
-        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std),) + (None,) * 12
+        B, S, Ss, cutn, patch, std = ctx.cfg
+        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=Ss),) + (None,) * 13
 
 
-def augment(pooled, params, cutn, patch, mean, std, out_dtype, noise=None, facs=None):
-    """pooled: (B,3,S,S) fp32 -> ViT patch rows (cutn*B, (S/patch)^2, 3*patch^2); params from augment.draw_params."""
+def augment(pooled, params, cutn, patch, mean, std, out_dtype, noise=None, facs=None, out_size=None):
+    """pooled: (B,3,Ss,Ss) fp32 -> ViT patch rows (cutn*B, (S/patch)^2, 3*patch^2), S = out_size or Ss; params from
+    augment.draw_params (drawn for that source / output size pair)."""
     return _AugmentFn.apply(pooled, noise, facs, params["pinv"], params["ainv"], params["cmat"], params["erase"], cutn,
-                            patch, mean, std, out_dtype, params.get("coff"))
+                            patch, mean, std, out_dtype, params.get("coff"), out_size)
+
+
+class _AvgPoolPatchesFn(Function):
+    """MakeCutouts(interpolate=True): adaptive average pooling of the augmented batch, then mean/std + patch rows."""
+
+    @staticmethod
+    def forward(ctx, x, out_size, patch, mean, std, out_dtype):
+        x = _contig(x)
+        ctx.cfg = (x.shape[0], x.shape[2], out_size, patch, std)
+        return K.avgpool_patches_fwd(x, out_size, patch, mean, std, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, S, So, patch, std = ctx.cfg
+        return K.avgpool_patches_bwd(_contig(g), N, S, So, patch, std), None, None, None, None, None
+
+
+def avgpool_patches(x, out_size, patch, mean, std, out_dtype):
+    return _AvgPoolPatchesFn.apply(x, out_size, patch, mean, std, out_dtype)
 
 
 class _PatchEmbedFn(Function):

@@ -277,11 +277,19 @@ int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr,
  * erase [N,4] int32 rectangle x0,y0,x1,y1 (x1 <= x0: none).  kornia 0.5.10 itself is absent: parity unpinned.
  * The backward scatters into dpooled [B,3,S,S] (zeroed inside); chain it with ffvc_cutouts_bwd(cutn 1, patch S). */
 int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff /* (N,3) colour offset added after cmat, may be NULL */, const int32_t* erase,
-                     const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int cutn, int patch,
-                     float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+                     const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int S_src, int cutn,
+                     int patch, float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
-                     const int32_t* erase, float* dpooled, int B, int S, int cutn, int patch, float std_r, float std_g,
-                     float std_b, void* stream);
+                     const int32_t* erase, float* dpooled, int B, int S, int S_src, int cutn, int patch, float std_r,
+                     float std_g, float std_b, void* stream);
+/* S = side of the cutouts written, S_src = side of the source image `pooled` [B,3,S_src,S_src]: they differ when the chain
+ * holds a resize / crop ('R','Re','Cr','Cc' on a pool_size != cut_size or pool=False source, main.py:203-221), which is then
+ * part of pinv.  MakeCutouts(interpolate=True) (main.py:226-228): adaptive average pooling of the augmented batch
+ * x [N,3,S,S] fp32 (ffvc_augment_fwd with patch S, mean 0, std 1) to So x So, then mean/std and the ViT patch rows. */
+int ffvc_avgpool_patches_fwd(const float* x, void* out, int out_dtype, int N, int S, int So, int patch, float mean_r,
+                             float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+int ffvc_avgpool_patches_bwd(const void* gout, int g_dtype, float* dx, int N, int S, int So, int patch, float std_r,
+                             float std_g, float std_b, void* stream);
 /* Spherical distance loss (main.py:801-811), repeat=1: loss = coef*mean_n 2*asin(|H-E|/2)^2 with
  * H = normalize(feats[n % B]), E = normalize(embed[n]); dembed (may be NULL) <- d loss / d embed. */
 int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, float* loss, float* dembed, int N,

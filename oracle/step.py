@@ -127,14 +127,15 @@ def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-8):
         p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None):
+def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None, out_size=None):
     """Plain-PyTorch statement of ffvc_augment_fwd (the fused Af -> Pe -> Ji -> Er chain of main.py:164-198 with
     explicit per-cutout parameters): returns (cutn*B, 3, S, S) BEFORE mean/std normalisation.  kornia itself is not
     restated (absent offline, parity unpinned); this pins the HIP kernel to the documented resampling formula."""
-    B, _, S, _ = pooled.shape
+    B, _, S, _ = pooled.shape                      # S: side of the source frame; So: side of the cutouts (a resize / crop in
+    So = out_size or S                             # the chain is part of pinv)
     N = cutn * B
-    ys, xs = torch.meshgrid(torch.arange(S, dtype=pooled.dtype), torch.arange(S, dtype=pooled.dtype), indexing="ij")
-    x2, y2 = xs[None].expand(N, S, S), ys[None].expand(N, S, S)
+    ys, xs = torch.meshgrid(torch.arange(So, dtype=pooled.dtype), torch.arange(So, dtype=pooled.dtype), indexing="ij")
+    x2, y2 = xs[None].expand(N, So, So), ys[None].expand(N, So, So)
     P, A = pinv.view(N, 9).to(pooled.dtype), ainv.view(N, 6).to(pooled.dtype)
     pe = lambda i: P[:, i].view(N, 1, 1)  # noqa: E731
     ae = lambda i: A[:, i].view(N, 1, 1)  # noqa: E731
@@ -150,8 +151,8 @@ def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=No
     wx, wy = x0 - xi, y0 - yi
     src = pooled.repeat(cutn, 1, 1, 1).reshape(N, 3, S * S)
     def tap(dy, dx):
-        idx = ((yi + dy) * S + (xi + dx)).view(N, 1, S * S).expand(N, 3, S * S)
-        return src.gather(2, idx).view(N, 3, S, S)
+        idx = ((yi + dy) * S + (xi + dx)).view(N, 1, So * So).expand(N, 3, So * So)
+        return src.gather(2, idx).view(N, 3, So, So)
     val = (1 - wy)[:, None] * ((1 - wx)[:, None] * tap(0, 0) + wx[:, None] * tap(0, 1)) + \
         wy[:, None] * ((1 - wx)[:, None] * tap(1, 0) + wx[:, None] * tap(1, 1))
     val = val * m[:, None]

@@ -15,7 +15,7 @@ from feed_forward_vqgan_clip_amd import prior as fprior  # noqa: E402
 
 
 def _relmax(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
@@ -102,3 +102,75 @@ def test_encode_text_and_images_pairs(cuda, tmp_path):
     assert _relmax(e, imf[1:2]) < 2e-2                                    # bf16 tower, batch-size independent up to rounding
     with pytest.raises(FileNotFoundError):
         fmain.encode_text_and_images(str(tmp_path), out=str(out), clip_path="random:5", bpe_path=vocab)
+
+
+# ----------------------------------------------------------------------------- MakeCutouts: the non-default branches
+def _cut_oracle(x, mc, prm, facs, noise):
+    """main.py:203-229 restated with the oracle's resampling formula: source (pooled or raw) -> chain -> noise -> interpolate."""
+    import torch.nn.functional as F
+    from oracle import step as ostep
+    B, H = x.shape[0], x.shape[2]
+    src = (F.adaptive_avg_pool2d(x, mc.pool_size) + F.adaptive_max_pool2d(x, mc.pool_size)) / 2 if mc.pool else x
+    size = mc.batch_size_px(H)
+    batch = ostep.augment_reference(src, prm["pinv"], prm["ainv"], prm["cmat"], prm["erase"], mc.cutn, facs=facs, noise=noise,
+                                    coff=prm.get("coff"), out_size=size)
+    if mc.interpolate:
+        batch = F.adaptive_avg_pool2d(batch, mc.interp_size)
+    return batch
+
+
+@pytest.mark.parametrize("kw", [
+    dict(augs=["R", "Af", "Ji"], pool=False),                                   # raw 48x48 image, bilinear resize to 32
+    dict(augs=["Af", "Pe", "Cr"], pool=True, pool_size=40),                     # pooled to 40, random 32-crop at the end
+    dict(augs=["Cc", "Ro", "Er2"], pool=False),                                 # centre crop of the raw image
+    dict(augs=["Re", "Ji2"], pool=True, pool_size=48),                          # resized crop from a larger pooled image
+    dict(augs=["Af", "Pe", "Ji", "Er"], pool=True, interpolate=True, interp_size=16),   # default set, then avg-pool 32 -> 16
+    dict(augs=["Af"], pool=True, pool_size=40, interpolate=True, interp_size=32),       # no resize in the chain: 40 -> 32 by pooling
+    dict(augs=["R"], pool=True, pool_size=24),                                  # upsampling resize 24 -> 32
+])
+def test_makecutouts_branches_match_oracle(cuda, kw):
+    B, H, cut, cutn = 2, 48, 32, 3
+    mc = fmain.MakeCutouts(cut, cutn, **kw)
+    mc.generator = torch.Generator().manual_seed(3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, 3, H, H, generator=g)
+    n = cutn * B
+    size = mc.batch_size_px(H)
+    facs = torch.rand(n, generator=g) * 0.1
+    noise = torch.randn(n, 3, size, size, generator=g)
+    prm = mc.draw_aug_params(n, "cpu", H)
+    assert prm is not None
+    xo = x.clone().requires_grad_(True)
+    ref = _cut_oracle(xo, mc, prm, facs, noise)
+    S = mc.out_size_px(H)
+    assert tuple(ref.shape) == (n, 3, S, S)
+    gw = torch.randn(ref.shape, generator=g)
+    (ref * gw).sum().backward()
+    xh = x.cuda().requires_grad_(True)
+    out = mc(xh, facs=facs.cuda(), noise=noise.cuda(), aug_params={k: v.cuda() for k, v in prm.items()})
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert _relmax(out, ref.detach()) < 1e-4
+    (out * gw.cuda()).sum().backward()
+    assert _relmax(xh.grad, xo.grad) < 1e-3
+
+
+def test_resize_only_cutouts_equal_torch_interpolate(cuda):
+    """augs=['R'], pool=False, noise off is literally `Resize(cut_size)(input.repeat(cutn,1,1,1))` (main.py:145-152,216-219):
+    pins the 'R' map of the fused resampler to torch's own bilinear interpolate (align_corners=False)."""
+    import torch.nn.functional as F
+    B, H, cut, cutn = 2, 48, 32, 2
+    mc = fmain.MakeCutouts(cut, cutn, augs=["R"], pool=False)
+    mc.noise_fac = 0
+    x = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(8))
+    ref = F.interpolate(x.repeat(cutn, 1, 1, 1), (cut, cut), mode="bilinear")
+    out = mc(x.cuda())
+    assert _relmax(out, ref) < 1e-5
+    up = fmain.MakeCutouts(64, 1, augs=["R"], pool=False)
+    up.noise_fac = 0
+    assert _relmax(up(x.cuda()), F.interpolate(x, (64, 64), mode="bilinear")) < 1e-5
+
+
+def test_unbuilt_augmentations_raise():
+    for a in ("Sh", "Et", "Ts"):
+        with pytest.raises(NotImplementedError):
+            fmain.MakeCutouts(32, 2, augs=[a])
