@@ -184,6 +184,8 @@ class DistributedOptimizer:
         self._seen = set()
         self._handles = {}
         self._wire = {}
+        self._order = {}                    # bucket -> launch position of the current step
+        self.overlap_update = os.environ.get("FFVC_DP_OVERLAP_UPDATE", "1") != "0"
         a.add_grad_callback(self._param_ready)
         for p in a.plist:
             if p.requires_grad:
@@ -236,6 +238,7 @@ class DistributedOptimizer:
             self._enqueue(b, g)
 
     def _enqueue(self, b, g):
+        self._order[b] = len(self._order)
         if self.wire_dtype is not None and self.wire_dtype != g.dtype:
             w = g.to(self.wire_dtype)
             self._wire[b] = w
@@ -243,22 +246,49 @@ class DistributedOptimizer:
         else:
             self._handles[b] = dist.all_reduce(g, async_op=True)
 
-    def synchronize(self):
-        """Flush buckets that never completed (unused params), wait for every exchange."""
-        if is_distributed():
-            for b in range(len(self.buckets)):
-                if b not in self._handles:
-                    self._launch(b)
-            for b, h in self._handles.items():
-                h.wait()
-                if b in self._wire:
-                    s, e, _ = self.buckets[b]
-                    if self._wire[b].is_cuda:
-                        self._wire[b].record_stream(torch.cuda.current_stream())
-                    self.arena.grads[s:e].copy_(self._wire[b])
+    def _flush_unlaunched(self):
+        for b in range(len(self.buckets)):
+            if b not in self._handles:
+                self._launch(b)
+
+    def _wait_bucket(self, b):
+        h = self._handles.pop(b, None)
+        if h is None:
+            return
+        h.wait()                              # stream-level for RCCL: the current stream waits, the host does not
+        if b in self._wire:
+            s, e, _ = self.buckets[b]
+            w = self._wire.pop(b)
+            if w.is_cuda:
+                w.record_stream(torch.cuda.current_stream())
+            self.arena.grads[s:e].copy_(w)
+
+    def _reset(self):
         self._handles, self._wire = {}, {}
         self._pending = [len(idxs) for _, _, idxs in self.buckets]
         self._seen = set()
+
+    def synchronize(self):
+        """Flush buckets that never completed (unused params), wait for every exchange."""
+        if is_distributed():
+            self._flush_unlaunched()
+            for b in list(self._handles):
+                self._wait_bucket(b)
+        self._reset()
+
+    def _ranges_as_reduced(self):
+        """(start, end) of every bucket in launch order, each yielded once its exchange is waited for (on the stream): the
+        optimizer updates slice k while the exchanges of slices k+1.. — the mapper's FIRST layers, whose gradients are the
+        last ones backward produces and therefore the ones nothing else could hide — are still in flight."""
+        order = sorted(self._handles, key=lambda b: self._order.get(b, 1 << 30))
+        done = set()
+        for b in order:
+            self._wait_bucket(b)
+            done.add(b)
+            yield self.buckets[b][0], self.buckets[b][1]
+        for b, (s, e, _) in enumerate(self.buckets):          # slices that had no exchange (not distributed): plain update
+            if b not in done:
+                yield s, e
 
     # -- optimizer surface --------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -284,9 +314,19 @@ class DistributedOptimizer:
         return False
 
     def step(self, closure=None):
+        fused = hasattr(self.opt, "arena") and hasattr(self.opt, "grad_scale")
+        if (is_distributed() and fused and self.overlap_update and not getattr(self, "_synced", False)):
+            # bucket-wise update as the exchanges complete (no global-norm clip pending: that needs every slice first)
+            self._flush_unlaunched()
+            self._set_scale()
+            out = self.opt.step(ranges=self._ranges_as_reduced())
+            self._reset()
+            self._order = {}
+            return out
         if not getattr(self, "_synced", False):
             self.synchronize()
         self._synced = False
+        self._order = {}
         if not self._set_scale() and not getattr(self, "_prescaled", False) and size() > 1:
             self.arena.grads.div_(size())
         self._prescaled = False

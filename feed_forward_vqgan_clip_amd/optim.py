@@ -79,7 +79,10 @@ class FusedAdam(torch.optim.Optimizer):
         return sd
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, ranges=None):
+        """One Adam update of the whole flat bucket — or, when `ranges` yields (start, end) element slices (each call of
+        the iterator may first wait for that slice's gradient exchange), one launch per slice in that order, so the update
+        of the slices already reduced runs while RCCL is still moving the last ones (distributed.py)."""
         a = self.arena
         g = self.param_groups[0]
         ops.join_side_stream()          # weight gradients are produced on the side stream
@@ -89,9 +92,12 @@ class FusedAdam(torch.optim.Optimizer):
         if self._ema is not None:       # torch_ema: decay = min(decay, (1 + n) / (10 + n)) with n counted from 1
             self._ema_updates += 1
             ema_w = 1.0 - min(self._ema_decay, (1 + self._ema_updates) / (10 + self._ema_updates))
-        K.adam(a.params, a.grads, self._m, self._v, None if a.cdt == torch.float32 else a.shadow, g["lr"],
-               g["betas"][0], g["betas"][1], g["eps"], self._step, self._eff_scale(), ema=self._ema, ema_weight=ema_w,
-               dev_scale=None if clip is None else clip[0:1])
+        shadow = None if a.cdt == torch.float32 else a.shadow
+        for s, e in (ranges if ranges is not None else ((0, a.total),)):
+            K.adam(a.params[s:e], a.grads[s:e], self._m[s:e], self._v[s:e], None if shadow is None else shadow[s:e], g["lr"],
+                   g["betas"][0], g["betas"][1], g["eps"], self._step, self._eff_scale(),
+                   ema=None if self._ema is None else self._ema[s:e], ema_weight=ema_w,
+                   dev_scale=None if clip is None else clip[0:1])
         a.refresh(cast=False)
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
