@@ -67,7 +67,7 @@ def build(args, device):
     arch, quick = fmain.clip_arch(args.clip_model)
     clip_sd = fclip.random_state_dict(arch, seed=1234)
     vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
-    perceptor = fclip.CLIP(clip_sd, cdt, quick_gelu=quick)
+    perceptor = fclip.CLIP(clip_sd, cdt, quick_gelu=quick, fp8=args.clip_fp8)
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
     opt.loss_scale = args.loss_scale if cdt == torch.float16 else 1.0
     if hvd.is_distributed():
@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--vq-image-size", type=int, default=16, help="latent grid S (image = 16*S)")
     ap.add_argument("--clip-model", default="ViT-B/32", help="perceptor (main.py:1308-1333 names): ViT-B/32 (headline), "
                     "ViT-B/16, ViT-L/14, openclip/<arch>/<pretrained> (cfg5: openclip/ViT-L-14/laion2b_s32b_b82k)")
+    ap.add_argument("--clip-fp8", action="store_true", help="image-tower linears (fwd + dgrad) on the fp8 MFMA path: e4m3 "
+                    "weights / activations, e5m2 gradients, per-tensor delayed scaling (cfg5); NOT the headline configuration")
     ap.add_argument("--augs", default="default", help="'default' = the reference's Af,Pe,Ji,Er (main.py:164-165), or a "
                     "comma list, e.g. 'R'")
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp32"],
@@ -337,7 +339,7 @@ def main():
         "metric": "train-step images/sec (whole node), ViT-B/32 + VQGAN-f16 256x256, bs=64, 1/2/4/8 GPU",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic seeded token batches, random-init weights (no network)",
+        "dtype": args.dtype + ("+fp8(clip image tower linears)" if args.clip_fp8 else ""), "data": "synthetic seeded token batches, random-init weights (no network)",
         "precision_recipe": {"bf16": "bf16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
                                      "fp32 text tower, VQ distances and loss",
                              "f16": "IEEE f16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "

@@ -74,9 +74,9 @@ def _f(t):
 
 
 class _Block:
-    def __init__(self, sd, p, cdt, need_dgrad, act=ACT_QUICKGELU):
+    def __init__(self, sd, p, cdt, need_dgrad, act=ACT_QUICKGELU, fp8=False):
         self.act = act
-        fz = lambda w, b: ops.Weights.frozen(sd[w], sd[b], cdt, need_dgrad)  # noqa: E731
+        fz = lambda w, b: ops.Weights.frozen(sd[w], sd[b], cdt, need_dgrad, fp8=fp8)  # noqa: E731
         self.ln1 = (_f(sd[p + ".ln_1.weight"]), _f(sd[p + ".ln_1.bias"]))
         self.ln2 = (_f(sd[p + ".ln_2.weight"]), _f(sd[p + ".ln_2.bias"]))
         self.in_proj = fz(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias")
@@ -115,13 +115,17 @@ class _TakeToken(torch.autograd.Function):
 
 
 class CLIP:
-    def __init__(self, state_dict, cdt=torch.bfloat16, vision_heads=None, text_heads=None, quick_gelu=True):
+    def __init__(self, state_dict, cdt=torch.bfloat16, vision_heads=None, text_heads=None, quick_gelu=True, fp8=False):
         """quick_gelu: OpenAI checkpoints and open_clip's `-quickgelu` architectures use x*sigmoid(1.702x) in the MLPs
         (cloob.py:179-181); the other open_clip architectures (ViT-B-32 / ViT-L-14 on LAION-2B, main.py:1323-1329) use
-        the exact erf GELU."""
+        the exact erf GELU.
+        fp8: the four Linear layers of every image-tower block (in_proj, out_proj, c_fc, c_proj; forward and dgrad) run on
+        the fp8 MFMA path (BASELINE.json configs[4]): e4m3 weights / activations, e5m2 gradients, per-tensor delayed
+        scaling, fp32 accumulation; LayerNorm, softmax, residual stream, patch embedding and projection keep `cdt` / fp32."""
         if not torch.cuda.is_available():
             raise RuntimeError("CLIP needs a HIP device; there is no CPU fallback")
         sd, self.cdt = state_dict, cdt
+        self.fp8 = bool(fp8)
         act = ACT_QUICKGELU if quick_gelu else ACT_GELU
         w = sd["visual.conv1.weight"]
         self.width, self.patch = w.shape[0], w.shape[-1]
@@ -137,7 +141,7 @@ class CLIP:
         n = 0
         self.vblocks = []
         while f"visual.transformer.resblocks.{n}.ln_1.weight" in sd:
-            self.vblocks.append(_Block(sd, f"visual.transformer.resblocks.{n}", cdt, True, act))
+            self.vblocks.append(_Block(sd, f"visual.transformer.resblocks.{n}", cdt, True, act, fp8=fp8))
             n += 1
         self.vproj = ops.Weights.frozen(sd["visual.proj"].t().contiguous(), None, cdt)
         self.embed_dim = sd["visual.proj"].shape[1]

@@ -522,6 +522,21 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero, int gm) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
   constexpr int NW = 2 * (BN / 64);                  // waves per workgroup
+  {
+    // Epilogue desynchronisation (FFVC_STAGGER_TICKS, 100 MHz ticks in gm's upper bits): equal tiles make every CU reach its
+    // store burst at the same moment, an HBM-write-bound phase with idle matrix pipes.  Half of the FIRST round's workgroups
+    // start late by about half a tile time, so afterwards the two halves of the chip alternate between K loop and epilogue.
+    const int ticks = gm >> 8;
+    gm &= 255;
+    // workgroups are dealt round-robin to the 8 XCDs and then to an XCD's 32 CUs: with two workgroups per CU the pair on
+    // a CU is (k, k + 32) of that XCD -> delay the second slot; with one per CU every other CU
+    const int k = blockIdx.x >> 3;
+    const bool late = (BM == 256 && BN == 256) ? (k < 32 && (k & 1)) : (k >= 32 && k < 64);
+    if (ticks > 0 && blockIdx.y == 0 && blockIdx.z == 0 && late) {
+      const uint64_t t0 = wall_clock64();
+      while ((int64_t)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   constexpr int XTILE = BM * 128, WTILE = BN * 128;  // bytes
   constexpr int STAGE = XTILE + WTILE;
   constexpr bool RING = !(BM == 256 && BN == 128);   // 2-stage ring except for the single-stage 256x128 variant
@@ -1119,6 +1134,15 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   // shapes (tiles_n <= 16) are neutral to slightly worse, so they keep the row-major order
   int gm = gm_opt >= 0 && getenv("FFVC_TILE_GM") ? gm_opt : (tiles_n > 16 ? 4 : 1);
   if (gm > tiles_m) gm = tiles_m;
+  {
+    static int stagger = -1;
+    if (stagger < 0) {
+      const char* e = getenv("FFVC_STAGGER_TICKS");
+      stagger = e ? atoi(e) : 0;
+    }
+    // only grids with several full rounds of equal tiles
+    if (stagger > 0 && (int64_t)n_tiles * d.batch * split >= 3 * n_cu) gm |= stagger << 8;
+  }
 #ifdef FFVC_BUILD_PERSIST
   constexpr bool ring = !(BM == 256 && BN == 128);
   if constexpr (ring) {

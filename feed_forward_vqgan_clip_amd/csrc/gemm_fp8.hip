@@ -1,0 +1,326 @@
+// gemm_fp8.hip — OCP fp8 GEMM for the FROZEN towers (BASELINE.json configs[4]: "OpenCLIP ViT-L/14 ... fp8 MFMA path"):
+//
+//     y[m,n] = act( s0*s1 * sum_k X8[m,k] * W8[n,k] + bias ) (+ residual)        X8: e4m3 | e5m2,  W8: e4m3,  fp32 accumulate
+//
+// gfx950 reaches its fp8 rate (2x bf16) only through v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per instruction, block
+// scales left at 1); the K=16 fp8 MFMAs of CDNA3 run at the bf16 rate.  The kernel is the LDS-DMA ring kernel of
+// gemm2_kernels.h with the operands viewed as 16-bit words: a K step of 128 fp8 values is the same 128-byte row as 64
+// halves, so the DMA, the XOR-swizzled LDS image and the fragment reads are reused unchanged; two consecutive 16-byte
+// fragment reads (k bytes [32s+16h, +16) for s = 2t, 2t+1) form the 32-byte A / B operand of ONE K=64 MFMA.  The
+// hardware pairs A and B bytes by (lane half, byte position), both operands are read through the same map, so every k
+// meets its partner exactly once.  Half the operand bytes per FLOP also halves the LDS-DMA issue stream that limits the
+// 16-bit kernel.  Epilogues (bias / GELU / QuickGELU / residual / pre-activation write / activation-gradient multiply,
+// row-store through the LDS pad) are the shared ones; per-tensor scales arrive as device scalars (delayed scaling).
+//
+// Quantisation helpers: ffvc_fp8_quant (x*scale -> saturating e4m3 / e5m2, accumulates max|x| for the NEXT step's scale),
+// ffvc_fp8_amax, ffvc_fp8_update (scale <- fmt_max / (amax * margin)).
+#include "gemm2_kernels.h"
+
+namespace {
+
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+// A = weight rows (always e4m3: cbsz 0), B = activation rows (e4m3: blgp 0, e5m2: blgp 1)
+template <int XFMT>
+__device__ __forceinline__ void mma_f8(f32x16_t& acc, const u32x4_t& a0, const u32x4_t& a1, const u32x4_t& b0,
+                                       const u32x4_t& b1) {
+  const v8i_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+  const v8i_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, XFMT, 0, 0, 0, 0);
+}
+
+template <typename L, int BM, int BN, int XFMT>
+__global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm_f8_kernel(const ffvc_gemm_desc p, int tiles_n,
+                                                                                          int n_tiles, int vec_ok,
+                                                                                          const float* __restrict__ s0,
+                                                                                          const float* __restrict__ s1) {
+  constexpr int MT = BM / 64;
+  constexpr int NW = 2 * (BN / 64);
+  constexpr int XTILE = BM * 128, WTILE = BN * 128;
+  constexpr int STAGE = XTILE + WTILE;
+  constexpr bool RING = !(BM == 256 && BN == 128);
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int K16 = p.K >> 1;                                   // the operands as 16-bit words
+  KMajorDmaB<BM, NW> sx;
+  KMajorDmaB<BN, NW> sw;
+  sx.init((const uint16_t*)p.x, p.ldx >> 1, m0, p.M, 0, 0, tid, 0, 0);
+  sw.init((const uint16_t*)p.w, p.ldw >> 1, n0, p.N, 0, 0, tid, 0, 0);
+
+  f32x16_t acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const int nk = (K16 + BK - 1) / BK;
+  auto compute = [&](const unsigned char* sX, const unsigned char* sW, auto&& between) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      u32x4_t fa0[2], fa1[2], fb0[MT], fb1[MT];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rw = wn * 64 + t * 32 + l31;
+        fa0[t] = frag_kmajor(sW, rw, 2 * t2, lane);
+        fa1[t] = frag_kmajor(sW, rw, 2 * t2 + 1, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int rx = wm * (32 * MT) + t * 32 + l31;
+        fb0[t] = frag_kmajor(sX, rx, 2 * t2, lane);
+        fb1[t] = frag_kmajor(sX, rx, 2 * t2 + 1, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) mma_f8<XFMT>(acc[a][b], fa0[a], fa1[a], fb0[b], fb1[b]);
+      between(t2);
+    }
+  };
+  if constexpr (!RING) {
+    for (int kt = 0; kt < nk; ++kt) {
+      sx.issue(smem, kt * BK, K16);
+      sw.issue(smem + XTILE, kt * BK, K16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(smem, smem + XTILE, [](int) {});
+      __syncthreads();
+    }
+  } else {
+    if (nk > 0) {
+      sx.issue(smem, 0, K16);
+      sw.issue(smem + XTILE, 0, K16);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      unsigned char* cur = smem + (kt & 1) * STAGE;
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      const bool more = kt + 1 < nk;
+      const int kn = (kt + 1) * BK;
+      compute(cur, cur + XTILE, [&](int t2) {
+        if (more && t2 == 0) sx.issue(nxt, kn, K16);
+        if (more && t2 == 1) sw.issue(nxt + XTILE, kn, K16);
+      });
+    }
+  }
+  if (s0) {      // product of the two per-tensor inverse scales (device scalars: delayed scaling never syncs the host)
+    const float s = s0[0] * (s1 ? s1[0] : 1.0f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] *= s;
+  }
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + (RING ? 2 : 1) * STAGE + wid * 4096, 0);
+  else
+    ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1, 0);
+}
+
+template <typename L, int BM, int BN>
+int launch_f8(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, const float* s1, hipStream_t st) {
+  const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
+  const int n_tiles = tiles_m * tiles_n;
+  constexpr int nthreads = 64 * 2 * (BN / 64);
+  constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128) + 2 * (BN / 64) * 4096;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_f8_kernel<L, BM, BN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_f8_kernel<L, BM, BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  if (x_fmt == 1)
+    hipLaunchKernelGGL((gemm_f8_kernel<L, BM, BN, 1>), dim3(n_tiles), dim3(nthreads), lds, st, d, tiles_n, n_tiles, vec_ok, s0, s1);
+  else
+    hipLaunchKernelGGL((gemm_f8_kernel<L, BM, BN, 0>), dim3(n_tiles), dim3(nthreads), lds, st, d, tiles_n, n_tiles, vec_ok, s0, s1);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename L>
+int launch_f8_cfg(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, const float* s1, hipStream_t st, int cfg) {
+  if (cfg == 512) return launch_f8<L, 256, 256>(d, x_fmt, vec_ok, s0, s1, st);
+  if (cfg == 256) return launch_f8<L, 256, 128>(d, x_fmt, vec_ok, s0, s1, st);
+  return launch_f8<L, 128, 128>(d, x_fmt, vec_ok, s0, s1, st);
+}
+
+// ---- quantisation ----------------------------------------------------------------------------------------------------
+// state[0] = scale applied before the conversion, state[1] = running max|x| (for the next update), state[2] = 1 / scale
+template <int FMT>
+__device__ __forceinline__ uint32_t cvt4_f8(float a, float b, float c, float d) {
+  constexpr float LIM = FMT == 0 ? 448.0f : 57344.0f;       // e4m3fn / e5m2 finite maxima: saturate instead of NaN / inf
+  a = fminf(fmaxf(a, -LIM), LIM);
+  b = fminf(fmaxf(b, -LIM), LIM);
+  c = fminf(fmaxf(c, -LIM), LIM);
+  d = fminf(fmaxf(d, -LIM), LIM);
+  int r = 0;
+  if constexpr (FMT == 0) {
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  } else {
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, r, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
+  }
+  return (uint32_t)r;
+}
+
+// ONE atomic per workgroup (every wave hitting the same address serialises in L2: 32k atomics cost 0.3 ms)
+__device__ __forceinline__ void block_amax(float m, float* __restrict__ state) {
+  __shared__ float part[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.0f) atomicMax((unsigned int*)(state + 1), __float_as_uint(m));   // m >= 0: uint order == float order
+  }
+}
+
+template <typename ST, int FMT>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(const ST* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        float* __restrict__ state, int64_t n) {
+  const float scale = state[0];
+  float m = 0.0f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
+    const f32x8 v = load8(src + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v.v[j]));
+    u32x2_t o;
+    o[0] = cvt4_f8<FMT>(v.v[0] * scale, v.v[1] * scale, v.v[2] * scale, v.v[3] * scale);
+    o[1] = cvt4_f8<FMT>(v.v[4] * scale, v.v[5] * scale, v.v[6] * scale, v.v[7] * scale);
+    *(u32x2_t*)(dst + i) = o;
+  }
+  block_amax(m, state);
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const ST* __restrict__ src, float* __restrict__ state, int64_t n) {
+  float m = 0.0f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
+    const f32x8 v = load8(src + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v.v[j]));
+  }
+  block_amax(m, state);
+}
+
+__global__ void fp8_update_kernel(float* __restrict__ state, float fmt_max, float margin) {
+  const float a = state[1];
+  if (a > 0.0f && isfinite(a)) {
+    const float s = fmt_max / (a * margin);
+    state[0] = s;
+    state[2] = 1.0f / s;
+  } else if (!(state[0] > 0.0f)) {
+    state[0] = 1.0f;
+    state[2] = 1.0f;
+  }
+  state[1] = 0.0f;
+}
+
+inline int f8_grid(int64_t n) {
+  const int64_t g = (n / 8 + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int ffvc_gemm_fp8(const ffvc_gemm_desc* dp, int x_fmt, int lo_dtype, const float* scale0, const float* scale1,
+                             void* stream) {
+  FFVC_CHECK_ARG(dp != nullptr, "ffvc_gemm_fp8: null descriptor");
+  const ffvc_gemm_desc& d = *dp;
+  FFVC_CHECK_ARG(d.x && d.w && d.y && d.M > 0 && d.N > 0 && d.K > 0, "ffvc_gemm_fp8: bad problem");
+  FFVC_CHECK_ARG(x_fmt == 0 || x_fmt == 1, "ffvc_gemm_fp8: x_fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG(lo_dtype == FFVC_BF16 || lo_dtype == FFVC_F16, "ffvc_gemm_fp8: lo_dtype must be a 16-bit storage type");
+  FFVC_CHECK_ARG(d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR && d.batch <= 1 && d.split_k <= 1 && d.kseg == 0 &&
+                     d.x_mi == 0 && d.slab_stride == 0,
+                 "ffvc_gemm_fp8: plain K-major x K-major problems only");
+  FFVC_CHECK_ARG((d.K % 16) == 0 && (d.ldx % 16) == 0 && (d.ldw % 16) == 0 && ((uintptr_t)d.x % 16) == 0 &&
+                     ((uintptr_t)d.w % 16) == 0,
+                 "ffvc_gemm_fp8: K / ldx / ldw must be multiples of 16 and the operands 16-byte aligned (K=%d)", d.K);
+  FFVC_CHECK_ARG(!(d.flags & (FFVC_F_GN_SUMS | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_TR_SAFE)),
+                 "ffvc_gemm_fp8: unsupported flags 0x%x", d.flags);
+  FFVC_CHECK_ARG((256 * (d.ldx / 2) + d.K / 2) * 2 < 0x7FFFFF00ll && (256 * (d.ldw / 2) + d.K / 2) * 2 < 0x7FFFFF00ll,
+                 "ffvc_gemm_fp8: operand rows too long for 32-bit DMA offsets");
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_COLSUM) || d.colsum, "ffvc_gemm_fp8: FFVC_F_COLSUM without a buffer");
+  // vectorised epilogue requirements (as ffvc_gemm); the row-store epilogue when everything is 8-aligned
+  auto mult = [](int64_t v, int64_t m) { return (v % m) == 0; };
+  const bool out32 = d.flags & FFVC_F_OUT_F32;
+  int vec_ok = mult(d.N, 4) && mult(d.y_sm, 4) && mult((int64_t)(uintptr_t)d.y, 16);
+  if (d.residual) vec_ok = vec_ok && mult(d.r_sm, 4) && mult((int64_t)(uintptr_t)d.residual, 16);
+  if (d.aux) vec_ok = vec_ok && mult(d.ldaux, 4) && mult((int64_t)(uintptr_t)d.aux, 16);
+  if (d.bias) vec_ok = vec_ok && mult((int64_t)(uintptr_t)d.bias, 16);
+  FFVC_CHECK_ARG(vec_ok && d.y_mi == 0 && d.r_mi == 0, "ffvc_gemm_fp8: needs N %% 4 == 0 and 16-byte aligned plain output rows");
+  {
+    bool ok = mult(d.N, 8) && (out32 ? mult(d.y_sm, 4) : mult(d.y_sm, 8));
+    if (d.residual) ok = ok && ((d.flags & FFVC_F_RES_F32) ? mult(d.r_sm, 4) : mult(d.r_sm, 8));
+    if (d.aux) ok = ok && mult(d.ldaux, 8);
+    if (ok) vec_ok = 2;
+  }
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_COLSUM) || vec_ok == 2, "ffvc_gemm_fp8: FFVC_F_COLSUM needs the row-store epilogue");
+  // tile choice as in ffvc_gemm2_try (every variant keeps 8 waves on a CU; pick the largest tile that fills whole rounds)
+  static int env_bm = -1;
+  if (env_bm < 0) {
+    const char* e = getenv("FFVC_FP8_BM");
+    env_bm = e ? atoi(e) : 0;
+  }
+  int cfg = (env_bm == 128 || env_bm == 256 || env_bm == 512) ? env_bm : 0;
+  if (!cfg) {
+    const int64_t t512 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 256);
+    const int64_t t256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 128);
+    const int64_t t128 = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128);
+    auto eff = [](int64_t t, int slots) { return (double)t / (double)(((t + slots - 1) / slots) * slots); };
+    const double e512 = (d.N >= 256 && t512 >= 192) ? eff(t512, 256) * 1.25 : 0.0;
+    const double e256 = t256 >= 256 ? eff(t256, 512) * 1.07 : 0.0;
+    const double e128 = eff(t128, 512);
+    cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (lo_dtype == FFVC_F16) return launch_f8_cfg<f16_t>(d, x_fmt, vec_ok, scale0, scale1, st, cfg);
+  return launch_f8_cfg<uint16_t>(d, x_fmt, vec_ok, scale0, scale1, st, cfg);
+}
+
+extern "C" int ffvc_fp8_quant(const void* src, int src_dtype, void* dst, int fmt, float* state, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(src && dst && state && n > 0 && (n % 8) == 0, "ffvc_fp8_quant: bad args (n must be a multiple of 8)");
+  FFVC_CHECK_ARG(fmt == 0 || fmt == 1, "ffvc_fp8_quant: fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "ffvc_fp8_quant: misaligned pointers");
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt == 0) {
+    DISPATCH_DT(src_dtype, ST, hipLaunchKernelGGL((fp8_quant_kernel<ST, 0>), dim3(f8_grid(n)), dim3(256), 0, st, (const ST*)src,
+                                                  (uint8_t*)dst, state, n));
+  } else {
+    DISPATCH_DT(src_dtype, ST, hipLaunchKernelGGL((fp8_quant_kernel<ST, 1>), dim3(f8_grid(n)), dim3(256), 0, st, (const ST*)src,
+                                                  (uint8_t*)dst, state, n));
+  }
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_fp8_amax(const void* src, int src_dtype, float* state, int64_t n, void* stream) {
+  FFVC_CHECK_ARG(src && state && n > 0 && (n % 8) == 0, "ffvc_fp8_amax: bad args (n must be a multiple of 8)");
+  FFVC_CHECK_ARG(((uintptr_t)src % 16) == 0, "ffvc_fp8_amax: misaligned pointer");
+  DISPATCH_DT(src_dtype, ST, hipLaunchKernelGGL((fp8_amax_kernel<ST>), dim3(f8_grid(n)), dim3(256), 0, (hipStream_t)stream,
+                                                (const ST*)src, state, n));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_fp8_update(float* state, int fmt, float margin, void* stream) {
+  FFVC_CHECK_ARG(state && (fmt == 0 || fmt == 1) && margin >= 1.0f, "ffvc_fp8_update: bad args");
+  hipLaunchKernelGGL(fp8_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, fmt == 0 ? 448.0f : 57344.0f, margin);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}

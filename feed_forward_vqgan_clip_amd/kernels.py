@@ -259,6 +259,93 @@ def layernorm_bwd_acc(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_l
     return dx
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# fp8 path of the frozen towers (cfg5): per-tensor delayed scaling + ffvc_gemm_fp8
+# ---------------------------------------------------------------------------------------------------------------
+E4M3, E5M2 = 0, 1
+FP8_MARGIN = 2.0          # headroom of the delayed scale: next step's values may exceed this step's amax by this factor
+
+
+class Fp8Scale:
+    """Device-resident scale of one tensor stream: state = [scale, running amax, 1/scale, -].  The first use measures the
+    tensor itself (current scaling); afterwards the amax seen while quantising step t sets the scale of step t+1
+    (delayed scaling: no extra pass over the tensor, no host synchronisation)."""
+
+    __slots__ = ("state", "fmt", "ready")
+
+    def __init__(self, fmt, device):
+        self.state = torch.zeros(4, dtype=torch.float32, device=device)
+        self.fmt, self.ready = fmt, False
+
+    @property
+    def inv(self):
+        return self.state[2:3]
+
+
+def fp8_quant(x, sc, frozen=False):
+    """x (16-bit or fp32, numel % 8 == 0) -> uint8 tensor of fp8 bytes in sc.fmt, scaled by sc's current scale.
+    frozen: a weight, quantised once with its own amax (margin 1)."""
+    _need_cuda(x)
+    x = x if x.is_contiguous() else x.contiguous()
+    n = x.numel()
+    st = stream_ptr()
+    if not sc.ready:
+        _call("ffvc_fp8_amax", x.data_ptr(), dtype_code(x.dtype), sc.state.data_ptr(), n, st)
+        _call("ffvc_fp8_update", sc.state.data_ptr(), sc.fmt, 1.0 if frozen else FP8_MARGIN, st)
+        sc.ready = True
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _call("ffvc_fp8_quant", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), sc.fmt, sc.state.data_ptr(), n, st)
+    return out
+
+
+def fp8_next_scale(sc):
+    """Fold the amax accumulated by the last fp8_quant into the scale the next step will use (after the GEMM that
+    consumed this step's scale has been enqueued)."""
+    _call("ffvc_fp8_update", sc.state.data_ptr(), sc.fmt, FP8_MARGIN, stream_ptr())
+
+
+def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0,
+             colsum=None):
+    """y[M,N] = act(sx.inv * sw.inv * X8 W8^T + bias) (+ residual): x8 [M,K], w8 [N,K] uint8 fp8 bytes (x in sx.fmt)."""
+    _need_cuda(x8, w8, y, bias, residual, aux)
+    if x8.dtype != torch.uint8 or w8.dtype != torch.uint8:
+        raise TypeError("gemm_fp8: operands must be uint8 tensors of fp8 bytes")
+    d = GemmDesc()
+    d.x, d.w, d.y = x8.data_ptr(), w8.data_ptr(), y.data_ptr()
+    d.bias, d.residual, d.aux = _ptr(bias), _ptr(residual), _ptr(aux)
+    d.M, d.N, d.K = M, N, K
+    d.x_mode, d.w_mode = OP_KMAJOR, OP_KMAJOR
+    if y.dtype == torch.float32:
+        flags |= F_OUT_F32
+    elif y.dtype != lo_dtype:
+        raise TypeError("gemm_fp8: y must be fp32 or lo_dtype")
+    if residual is not None:
+        if residual.dtype == torch.float32:
+            flags |= F_RES_F32
+        elif residual.dtype != lo_dtype:
+            raise TypeError("gemm_fp8: residual must be fp32 or lo_dtype")
+    if aux is not None and aux.dtype != lo_dtype:
+        raise TypeError("gemm_fp8: aux must be lo_dtype")
+    if colsum is not None:
+        d.colsum = colsum.data_ptr()
+        flags |= _lib.F_COLSUM
+    d.act, d.flags, d.split_k, d.alpha = act, flags, 1, 1.0
+    d.ldx, d.ldw, d.ldaux = K, K, ldaux
+    d.y_mi, d.y_so, d.y_sm = 0, 0, N
+    d.r_mi, d.r_so, d.r_sm = 0, 0, N
+    d.batch, d.batch_inner = 1, 1
+    lib = _lib.load()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.ffvc_gemm_fp8(byref(d), sx.fmt, dtype_code(lo_dtype), sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()),
+               "ffvc_gemm_fp8")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * K, e0, e1, (M, N, K, 1, 1)))
+    return y
+
+
 def _gn_ws(B, HW, G, dev):
     n = _lib.load().ffvc_groupnorm_ws_bytes(B, HW, G)
     return torch.empty((n + 7) // 8, dtype=torch.float64, device=dev)

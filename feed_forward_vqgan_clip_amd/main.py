@@ -210,8 +210,9 @@ def clip_arch(model_type):
     return arch, quick
 
 
-def load_clip_model(model_type, path=None, cdt=torch.bfloat16):
-    """main.py:1308-1333 for the OpenAI / OpenCLIP ViT families (state_dict in clip.model.CLIP layout)."""
+def load_clip_model(model_type, path=None, cdt=torch.bfloat16, fp8=False):
+    """main.py:1308-1333 for the OpenAI / OpenCLIP ViT families (state_dict in clip.model.CLIP layout).
+    fp8: image-tower linears on the fp8 MFMA path (config key `clip_fp8`, BASELINE.json configs[4])."""
     arch, quick = clip_arch(model_type)
     if path is None or str(path).startswith("random:"):
         seed = int(str(path).split(":", 1)[1]) if path else 1234
@@ -219,7 +220,7 @@ def load_clip_model(model_type, path=None, cdt=torch.bfloat16):
     else:
         obj = torch.load(path, map_location="cpu", weights_only=False)
         sd = obj.state_dict() if hasattr(obj, "state_dict") else obj.get("state_dict", obj)
-    return _clip.CLIP(sd, cdt, quick_gelu=quick)
+    return _clip.CLIP(sd, cdt, quick_gelu=quick, fp8=fp8)
 
 
 def synthetic_tokens(n, seed=0, context_length=77):

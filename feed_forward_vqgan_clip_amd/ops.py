@@ -33,21 +33,33 @@ from .kernels import ACT_GELU, ACT_NONE, ACT_QUICKGELU  # noqa: F401
 class Weights:
     """fp32 master weight [N, K] (+ bias [N]) with compute-dtype shadows."""
 
-    __slots__ = ("weight", "bias", "sh", "sht", "N", "K", "on_grad")
+    __slots__ = ("weight", "bias", "sh", "sht", "N", "K", "on_grad", "fp8")
 
     def __init__(self, weight, bias, sh, sht, on_grad=None):
         self.weight, self.bias, self.sh, self.sht = weight, bias, sh, sht
         self.N, self.K = sh.shape[0], sh.shape[1]
         self.on_grad = on_grad
+        self.fp8 = None
 
     @staticmethod
-    def frozen(weight, bias, cdt, need_dgrad=True):
-        """Build shadows once for a frozen layer; weight: fp32 [N, K] (any device -> cuda)."""
+    def frozen(weight, bias, cdt, need_dgrad=True, fp8=False):
+        """Build shadows once for a frozen layer; weight: fp32 [N, K] (any device -> cuda).
+        fp8: also keep OCP e4m3 copies of W and W^T (one per-tensor scale, quantised from the fp32 master) plus the delayed
+        scaling state of the layer's activation (e4m3) and gradient (e5m2) streams: Linear fwd / dgrad then run on the
+        fp8 MFMA path (ffvc_gemm_fp8).  Needs 16-element aligned N and K."""
         w = weight.detach().reshape(weight.shape[0], -1).float().cuda().contiguous()
         b = None if bias is None else bias.detach().float().cuda().contiguous()
         sh = K.cast(w, cdt) if cdt != torch.float32 else w
         sht = K.transpose(w, cdt) if need_dgrad else None
-        return Weights(None, b, sh, sht)
+        W = Weights(None, b, sh, sht)
+        if fp8:
+            if cdt not in K.LOWP or W.N % 16 or W.K % 16:
+                raise ValueError(f"fp8 weights need a 16-bit compute dtype and N, K multiples of 16 (N={W.N}, K={W.K})")
+            sw = K.Fp8Scale(K.E4M3, w.device)
+            W.fp8 = {"w": sw, "sh": K.fp8_quant(w, sw, frozen=True),
+                     "sht": K.fp8_quant(w.t().contiguous(), sw, frozen=True) if need_dgrad else None,
+                     "x": K.Fp8Scale(K.E4M3, w.device), "g": K.Fp8Scale(K.E5M2, w.device)}
+        return W
 
 
 # ---------------------------------------------------------------------------
@@ -212,6 +224,11 @@ class _LinearFn(Function):
             if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
                 raise TypeError("linear(drop>0) with a residual needs the fp32 residual stream")
             K.dropout(y, ctx.drop[0], ctx.drop[1], residual=residual, out=y)
+        elif W.fp8 is not None and not gn_hw and x.dtype in K.LOWP and rows % 8 == 0:
+            f = W.fp8                  # fp8 MFMA path of a frozen layer: quantise the activation, per-tensor delayed scale
+            x8 = K.fp8_quant(x, f["x"])
+            K.gemm_fp8(x8, f["sh"], y, rows, W.N, W.K, f["x"], f["w"], lo_dtype=cdt, bias=W.bias, residual=residual)
+            K.fp8_next_scale(f["x"])
         else:
             sums = _gn_request(gn_hw > 0, y, rows // gn_hw if gn_hw else 0, gn_hw, W.N)
             K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual,
@@ -232,7 +249,13 @@ class _LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
-            K.gemm(dyt, W.sht, dx, rows, W.K, W.N, ldx=W.N, ldw=W.N)
+            f = W.fp8
+            if f is not None and f["sht"] is not None and not ctx.drop and dyt.dtype in K.LOWP and rows % 8 == 0:
+                dy8 = K.fp8_quant(dyt, f["g"])                       # gradients travel as e5m2
+                K.gemm_fp8(dy8, f["sht"], dx, rows, W.K, W.N, f["g"], f["w"], lo_dtype=cdt)
+                K.fp8_next_scale(f["g"])
+            else:
+                K.gemm(dyt, W.sht, dx, rows, W.K, W.N, ldx=W.N, ldw=W.N)
         if ctx.train:
             (x,) = ctx.saved_tensors
             _wgrad(dyt, x, W, rows)
@@ -256,11 +279,24 @@ class _MLPFn(Function):
         rows = x.numel() // W1.K
         h_pre = torch.empty(*x.shape[:-1], W1.N, dtype=cdt, device=x.device)
         h = torch.empty_like(h_pre)
-        K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
-               flags=K.F_WRITE_PREACT)
+        ctx.fp8 = (W1.fp8 is not None and W2.fp8 is not None and not drop and x.dtype in K.LOWP and rows % 8 == 0)
+        if ctx.fp8:
+            f1 = W1.fp8
+            x8 = K.fp8_quant(x, f1["x"])
+            K.gemm_fp8(x8, f1["sh"], h, rows, W1.N, W1.K, f1["x"], f1["w"], lo_dtype=cdt, bias=W1.bias, act=act, aux=h_pre,
+                       ldaux=W1.N, flags=K.F_WRITE_PREACT)
+            K.fp8_next_scale(f1["x"])
+        else:
+            K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
+                   flags=K.F_WRITE_PREACT)
         y = torch.empty(*x.shape[:-1], W2.N, dtype=out_dtype or cdt, device=x.device)
         ctx.drop = (float(drop),) + tuple(_drop_seeds(2)) if drop else None
-        if ctx.drop:    # Linear, act, Dropout, Linear, Dropout (mlp_mixer_pytorch.py:16-23, vitgan.py:36-41), then + residual
+        if ctx.fp8:
+            f2 = W2.fp8
+            h8 = K.fp8_quant(h, f2["x"])
+            K.gemm_fp8(h8, f2["sh"], y, rows, W2.N, W2.K, f2["x"], f2["w"], lo_dtype=cdt, bias=W2.bias, residual=residual)
+            K.fp8_next_scale(f2["x"])
+        elif ctx.drop:    # Linear, act, Dropout, Linear, Dropout (mlp_mixer_pytorch.py:16-23, vitgan.py:36-41), then + residual
             if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
                 raise TypeError("mlp(drop>0) with a residual needs the fp32 residual stream")
             K.dropout(h, ctx.drop[0], ctx.drop[1], out=h)
@@ -286,6 +322,19 @@ class _MLPFn(Function):
         # the first Linear's bias gradient = column sums of dh: accumulated by the epilogue that writes dh
         b1_fused = (ctx.train and not ctx.drop and W1.bias is not None and W1.bias.requires_grad and
                     K.colsum_fusable(cdt, W2.K, W2.N))
+        if ctx.fp8 and W2.fp8["sht"] is not None and W1.fp8["sht"] is not None:
+            f1, f2 = W1.fp8, W2.fp8
+            dy8 = K.fp8_quant(dyt, f2["g"])
+            K.gemm_fp8(dy8, f2["sht"], dh, rows, W2.K, W2.N, f2["g"], f2["w"], lo_dtype=cdt, aux=h_pre, ldaux=W2.K,
+                       act=ctx.act, flags=K.F_MUL_ACT_GRAD)
+            K.fp8_next_scale(f2["g"])
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dh8 = K.fp8_quant(dh, f1["g"])
+                dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
+                K.gemm_fp8(dh8, f1["sht"], dx, rows, W1.K, W1.N, f1["g"], f1["w"], lo_dtype=cdt)
+                K.fp8_next_scale(f1["g"])
+            return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None, None, None
         K.gemm(dyt, W2.sht, dh, rows, W2.K, W2.N, ldx=W2.N, ldw=W2.N, aux=h_pre, ldaux=W2.K, act=ctx.act,
                flags=K.F_MUL_ACT_GRAD, colsum=_grad_buf(W1.bias) if b1_fused else None)
         if ctx.drop:        # the hidden mask commutes with the element-wise act' factor the epilogue just applied

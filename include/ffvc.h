@@ -134,6 +134,21 @@ typedef struct ffvc_gemm_desc {
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
 
+/* OCP fp8 GEMM for the frozen towers (BASELINE.json configs[4], "fp8 MFMA path"): x and w hold fp8 bytes (w: e4m3fn;
+ * x: e4m3fn for x_fmt 0, e5m2 for x_fmt 1 = gradients), K-major both, fp32 accumulation on
+ * v_mfma_f32_32x32x64_f8f6f4 (the only fp8 instruction of gfx950 that runs at twice the bf16 rate).  d->K, ldx, ldw
+ * count fp8 ELEMENTS and must be multiples of 16; y / aux / residual use `lo_dtype` (FFVC_BF16 | FFVC_F16) unless flagged
+ * fp32; d->in_dtype is ignored.  The accumulator is multiplied by d->alpha * scale0[0] * scale1[0] (device scalars, may be
+ * NULL): the inverse per-tensor quantisation scales.  Same fused epilogues as ffvc_gemm; no batch, no split-K.
+ * ffvc_fp8_quant: dst = saturate(src * state[0]) as fp8 (fmt 0 e4m3 | 1 e5m2), state[1] = max(state[1], max|src|).
+ * ffvc_fp8_amax: state[1] = max(state[1], max|src|).  ffvc_fp8_update: state[0] = fmt_max / (state[1] * margin),
+ * state[2] = 1 / state[0], state[1] = 0  (delayed scaling: the amax seen at step t sets the scale of step t+1).
+ * state: 4 floats on the device.  n must be a multiple of 8. */
+int ffvc_gemm_fp8(const ffvc_gemm_desc* d, int x_fmt, int lo_dtype, const float* scale0, const float* scale1, void* stream);
+int ffvc_fp8_quant(const void* src, int src_dtype, void* dst, int fmt, float* state, int64_t n, void* stream);
+int ffvc_fp8_amax(const void* src, int src_dtype, float* state, int64_t n, void* stream);
+int ffvc_fp8_update(float* state, int fmt, float margin, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Normalisation / softmax (HBM-bound; fp32 statistics; dtype codes per tensor)
  * ------------------------------------------------------------------------- */

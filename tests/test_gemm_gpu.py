@@ -355,3 +355,77 @@ def test_forced_tiles_nt_and_conv(cuda, tile, dt):
         K.set_option("gemm2_tile", 1)
         K.set_option("gemm8", 0)
         K.set_option("conv_row", 1)
+
+
+# ----------------------------------------------------------------------------- fp8 path (cfg5)
+def _f8_ref(t8, fmt):
+    """uint8 fp8 bytes -> fp32 values through torch's own OCP float8 dtypes (the independent decoder)."""
+    return t8.view(torch.float8_e4m3fn if fmt == K.E4M3 else torch.float8_e5m2).float()
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_fp8_quant_matches_torch_float8(cuda, fmt):
+    """ffvc_fp8_quant = saturating round-to-nearest-even to OCP e4m3fn / e5m2 of x * scale, scale = fmt_max / (amax * margin)."""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(64, 264, generator=g) * 3).to(torch.float16).cuda()
+    sc = K.Fp8Scale(fmt, x.device)
+    q = K.fp8_quant(x, sc)
+    st = sc.state.cpu()
+    fmax = 448.0 if fmt == 0 else 57344.0
+    assert abs(st[0].item() - fmax / (x.float().abs().max().item() * K.FP8_MARGIN)) < 1e-3 * st[0].item()
+    assert abs(st[0].item() * st[2].item() - 1) < 1e-6 and st[1].item() == x.float().abs().max().item()
+    ref = (x.float() * st[0]).clamp(-fmax, fmax).to(torch.float8_e4m3fn if fmt == 0 else torch.float8_e5m2)
+    assert torch.equal(q.cpu(), ref.view(torch.uint8).cpu())
+    sat = K.fp8_quant(x * 100, sc)                       # stale (delayed) scale -> saturates at the format maximum, no NaN / inf
+    assert torch.isfinite(_f8_ref(sat, fmt)).all() and _f8_ref(sat, fmt).abs().max().item() == fmax
+    K.fp8_next_scale(sc)
+    assert abs(sc.state[0].item() - fmax / ((x * 100).float().abs().max().item() * K.FP8_MARGIN)) < 1e-2 * sc.state[0].item()
+
+
+@pytest.mark.parametrize("ldt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("xfmt", [0, 1])
+@pytest.mark.parametrize("M,N,Kd,tile", [(512, 512, 1024, 0), (300, 264, 80, 0), (1024, 256, 256, 512), (520, 384, 272, 256),
+                                         (256, 128, 128, 128), (16448, 1024, 1024, 0)])
+def test_fp8_gemm_matches_dequantised_reference(cuda, M, N, Kd, tile, xfmt, ldt, monkeypatch):
+    """ffvc_gemm_fp8 (v_mfma_f32_32x32x64_f8f6f4, fp32 accumulate) against fp64 math on the SAME fp8 values decoded by
+    torch's float8 dtypes, for every tile configuration, ragged M / N, K tails, e4m3 and e5m2 activations."""
+    if tile:
+        monkeypatch.setenv("FFVC_FP8_BM", str(tile))      # read once per process: only the first forced value sticks,
+    g = torch.Generator().manual_seed(7)                  # the heuristic covers the rest
+    x = torch.randn(M, Kd, generator=g).to(ldt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.05).cuda()
+    sx, sw = K.Fp8Scale(xfmt, x.device), K.Fp8Scale(K.E4M3, x.device)
+    x8, w8 = K.fp8_quant(x, sx), K.fp8_quant(w, sw, frozen=True)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    K.gemm_fp8(x8, w8, y, M, N, Kd, sx, sw, lo_dtype=ldt, bias=bias, residual=res)
+    ref = (_f8_ref(x8, xfmt).double() @ _f8_ref(w8, K.E4M3).double().t()) * (sx.state[2].double() * sw.state[2].double()) + \
+        bias.double() + res.double()
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-4      # fp32 accumulation order / MFMA adder tree
+    # close to the unquantised product as well (3 mantissa bits on the activation, per-tensor scales)
+    full = x.double() @ w.double().t() + bias.double() + res.double()
+    assert ((y.double() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item() < (0.06 if xfmt == 0 else 0.12)
+    # 16-bit output + GELU + pre-activation write, then the activation-gradient epilogue on the stored pre-activation
+    h, pre = torch.empty(M, N, dtype=ldt, device=x.device), torch.empty(M, N, dtype=ldt, device=x.device)
+    K.gemm_fp8(x8, w8, h, M, N, Kd, sx, sw, lo_dtype=ldt, bias=bias, act=K.ACT_GELU, aux=pre, ldaux=N, flags=K.F_WRITE_PREACT)
+    pref = ref - res.double()
+    tol = 2e-3 if ldt == torch.float16 else 1.6e-2
+    assert ((pre.double() - pref).abs().max() / pref.abs().max()).item() < tol
+    assert ((h.double() - torch.nn.functional.gelu(pref)).abs().max() / pref.abs().max()).item() < tol
+    dh = torch.empty(M, N, dtype=ldt, device=x.device)
+    K.gemm_fp8(x8, w8, dh, M, N, Kd, sx, sw, lo_dtype=ldt, act=K.ACT_GELU, aux=pre, ldaux=N, flags=K.F_MUL_ACT_GRAD)
+    p = pre.double()
+    gg = 0.5 * (1 + torch.erf(p / 2 ** 0.5)) + p * torch.exp(-0.5 * p * p) / (2 * torch.pi) ** 0.5
+    want = (ref - res.double() - bias.double()) * gg
+    assert ((dh.double() - want).abs().max() / want.abs().max()).item() < tol
+
+
+def test_fp8_gemm_rejects_bad_shapes(cuda):
+    from feed_forward_vqgan_clip_amd._lib import FFVCError
+    x8 = torch.zeros(64, 72, dtype=torch.uint8, device=cuda)
+    w8 = torch.zeros(64, 72, dtype=torch.uint8, device=cuda)
+    y = torch.empty(64, 64, device=cuda)
+    sc = K.Fp8Scale(K.E4M3, x8.device)
+    with pytest.raises(FFVCError, match="multiples of 16"):
+        K.gemm_fp8(x8, w8, y, 64, 64, 72, sc, sc, lo_dtype=torch.float16)

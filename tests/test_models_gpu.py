@@ -121,6 +121,34 @@ def test_clip_patch14_long_sequence_matches_oracle(cuda, cdt, tol, quick):
     assert _relrms(model.encode_text(tok.cuda()), oclip.encode_text(sd, tok, quick_gelu=quick)) < 2e-4
 
 
+@pytest.mark.parametrize("cdt", [F16, BF16])
+def test_clip_fp8_tower_close_to_16bit_tower(cuda, cdt):
+    """cfg5's fp8 MFMA path: the image tower with its four per-block linears in e4m3 (gradients e5m2, per-tensor delayed
+    scaling) stays within fp8's error budget of the SAME tower in 16-bit storage, forward and image gradient, and keeps doing
+    so on a second call (delayed scales now come from the first call's amax)."""
+    cfg = dict(embed_dim=64, image_resolution=112, vision_layers=3, vision_width=256, vision_patch_size=16,
+               context_length=16, vocab_size=96, transformer_width=64, transformer_heads=1, transformer_layers=1)
+    sd = fclip.random_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(6)
+    for k in list(sd):
+        if k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    ref_model = fclip.CLIP(sd, cdt, quick_gelu=False)
+    f8_model = fclip.CLIP(sd, cdt, quick_gelu=False, fp8=True)
+    assert all(b.c_fc.fp8 is not None and b.in_proj.fp8 is not None for b in f8_model.vblocks)
+    gw = torch.randn(8, 64, generator=g).cuda()
+    for it in range(2):
+        img = torch.randn(8, 3, 112, 112, generator=g).cuda()
+        a, b = img.clone().requires_grad_(True), img.clone().requires_grad_(True)
+        ea, eb = ref_model.encode_image(a), f8_model.encode_image(b)
+        (ea * gw).sum().backward()
+        (eb * gw).sum().backward()
+        assert _relrms(eb, ea.detach()) < 0.08, it
+        assert _relrms(b.grad, a.grad) < 0.25, it
+        cos = torch.nn.functional.cosine_similarity(ea.detach().float(), eb.detach().float(), dim=1)
+        assert cos.min().item() > 0.995
+
+
 def test_clip_arch_names():
     """main.py:1308-1333: OpenAI names and openclip/<arch>/<pretrained> spellings -> architecture + activation."""
     from feed_forward_vqgan_clip_amd import main as fmain
