@@ -12,6 +12,8 @@
 //
 // Numerics match the GEMM + softmax path it replaces: fp32 scores and statistics, probabilities rounded to bf16
 // before the second product and before the softmax gradient, fp32 accumulation everywhere.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -580,6 +582,359 @@ __global__ __launch_bounds__(64) void attn_flash_bwd_dkv_kernel(const uint16_t* 
   store_transposed<L, 2>(dKp, ld, dKT, k0, T, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Flash attention, second generation: NWV waves per workgroup (64 queries each) share every 64-key block through LDS —
+// K as rows (A operand of S^T = K Q^T, 16-byte fragment reads), V transposed (A operand of O^T += V^T P^T) — loaded
+// cooperatively (each 16-byte chunk once per workgroup instead of once per wave) and prefetched into registers one block
+// ahead of the MFMAs that consume it.  The per-wave math is that of attn_flash_fwd_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KS = 72;                 // row stride (halves) of the K-rows panel: 144 B keeps 16-byte fragment reads aligned
+constexpr int KPANEL = 64 * KS;
+
+// 16-byte fragment of row `row` of a rows panel: features 16 s + 8 h ..
+__device__ __forceinline__ u32x4_t ldsfrag(const uint16_t* panel, int row, int s, int h) {
+  return *(const u32x4_t*)(panel + row * KS + 16 * s + 8 * h);
+}
+
+template <int NWV>
+struct BlockLoader {                   // 64 rows x 64 features of a [T, ld] matrix = 512 chunks of 16 B over 64*NWV threads
+  static constexpr int NCH = 512 / (64 * NWV);
+  u32x4_t r[NCH];
+  __device__ __forceinline__ void load(const uint16_t* base, int64_t ld, int row0, int T, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 64 * NWV;
+      const int row = row0 + (c >> 3);
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      r[i] = row < T ? *(const u32x4_t*)(base + (int64_t)row * ld + 8 * (c & 7)) : z;
+    }
+  }
+  __device__ __forceinline__ void store_rows(uint16_t* panel, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 64 * NWV;
+      *(u32x4_t*)(panel + (c >> 3) * KS + 8 * (c & 7)) = r[i];
+    }
+  }
+  __device__ __forceinline__ void store_transposed(uint16_t* Xt, int tid) const {      // Xt[d][row], stride TS
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 64 * NWV;
+      const int row = c >> 3, d0 = 8 * (c & 7);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Xt[(d0 + 2 * e) * TS + row] = (uint16_t)(r[i][e] & 0xffffu);
+        Xt[(d0 + 2 * e + 1) * TS + row] = (uint16_t)(r[i][e] >> 16);
+      }
+    }
+  }
+};
+
+template <typename L, bool CAUSAL, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void attn_flash2_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
+                                                                   float* __restrict__ lse, int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KPANEL];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[PANEL];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const int q0 = 64 * (NWV * blockIdx.x + wv);                 // this wave's queries
+  const float c = scale * LOG2E;
+
+  u32x4_t fq[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fq[qt][s] = rowfrag(Q, ld, q0 + 32 * qt + l31, T, s, h);
+  f32x16_t OT[2][2];
+  zero_tiles(OT);
+  float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.0f, 0.0f};
+  const int qend = min(T, 64 * NWV * ((int)blockIdx.x + 1));    // one past the workgroup's last query
+  const int nkb = CAUSAL ? (qend + 63) / 64 : (T + 63) / 64;
+  const int my_last = CAUSAL ? q0 / 64 : nkb - 1;              // last key block this wave needs
+  BlockLoader<NWV> lk, lv;
+  lk.load(Kp, ld, 0, T, tid);
+  lv.load(V, ld, 0, T, tid);
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = 64 * kb;
+    __syncthreads();                                           // everyone is done with the previous block's panels
+    lk.store_rows(Ks, tid);
+    lv.store_transposed(Vt, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) {                                        // next block's chunks fly under this block's MFMAs
+      lk.load(Kp, ld, k0 + 64, T, tid);
+      lv.load(V, ld, k0 + 64, T, tid);
+    }
+    if (kb > my_last || q0 >= T) continue;
+    f32x16_t ST[2][2];
+    zero_tiles(ST);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4_t fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = ldsfrag(Ks, 32 * a + l31, s, h);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) mma(ST[a][qt], fa[a], fq[qt][s]);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = q0 + 32 * qt + l31;
+      const int klim = CAUSAL ? min(T, q + 1) : T;
+      float mloc = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + 32 * kt + reg_index(r, h) < klim) mloc = fmaxf(mloc, ST[kt][qt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(m[qt], mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m[qt] - mnew) * c);
+      float sum = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p =
+              (k0 + 32 * kt + reg_index(r, h) < klim) ? __builtin_amdgcn_exp2f((ST[kt][qt][r] - mnew) * c) : 0.0f;
+          ST[kt][qt][r] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      l[qt] = l[qt] * alpha + sum;
+      m[qt] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) OT[dt][qt][r] *= alpha;
+    }
+    lds_product<L, 2, 2>(OT, Vt, ST, 0, lane);
+  }
+  if (q0 >= T) return;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float inv = l[qt] > 0.0f ? 1.0f / l[qt] : 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) OT[dt][qt][r] *= inv;
+    const int q = q0 + 32 * qt + l31;
+    if (h == 0 && q < T) lse[(int64_t)bh * T + q] = m[qt] * c + __builtin_amdgcn_logf(l[qt]);
+  }
+  store_transposed<L, 2>(o + (int64_t)b * T * D + hd * 64, D, OT, q0, T, lane);
+}
+
+
+// dQ, second generation: NWV waves (64 queries each) share the K / V key blocks through LDS (K rows, V rows, K^T).
+template <typename L, bool CAUSAL, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void attn_flash2_bwd_dq_kernel(const uint16_t* __restrict__ qkv,
+                                                                         const uint16_t* __restrict__ out,
+                                                                         const uint16_t* __restrict__ dout,
+                                                                         const float* __restrict__ lse,
+                                                                         float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                                         int T, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KPANEL];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[KPANEL];
+  __shared__ __attribute__((aligned(16))) uint16_t Kt[PANEL];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const uint16_t* O = out + (int64_t)b * T * D + hd * 64;
+  const uint16_t* dO = dout + (int64_t)b * T * D + hd * 64;
+  const int q0 = 64 * (NWV * blockIdx.x + wv);
+  const float c = scale * LOG2E;
+
+  u32x4_t fq[2][4], fdo[2][4];
+  float dl[2], ls[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + 32 * qt + l31;
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fq[qt][s] = rowfrag(Q, ld, q, T, s, h);
+      fdo[qt][s] = rowfrag(dO, D, q, T, s, h);
+      const u32x4_t fo = rowfrag(O, D, q, T, s, h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += lo_unpack<L>((uint16_t)(fo[e] & 0xffffu)) * lo_unpack<L>((uint16_t)(fdo[qt][s][e] & 0xffffu));
+        acc += lo_unpack<L>((uint16_t)(fo[e] >> 16)) * lo_unpack<L>((uint16_t)(fdo[qt][s][e] >> 16));
+      }
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    dl[qt] = acc;
+    ls[qt] = q < T ? lse[(int64_t)bh * T + q] : 0.0f;
+    if (h == 0 && q < T) delta[(int64_t)bh * T + q] = acc;
+  }
+  f32x16_t dQT[2][2];
+  zero_tiles(dQT);
+  const int qend = min(T, 64 * NWV * ((int)blockIdx.x + 1));
+  const int nkb = CAUSAL ? (qend + 63) / 64 : (T + 63) / 64;
+  const int my_last = CAUSAL ? q0 / 64 : nkb - 1;
+  BlockLoader<NWV> lk, lv;
+  lk.load(Kp, ld, 0, T, tid);
+  lv.load(V, ld, 0, T, tid);
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = 64 * kb;
+    __syncthreads();
+    lk.store_rows(Ks, tid);
+    lk.store_transposed(Kt, tid);
+    lv.store_rows(Vs, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) {
+      lk.load(Kp, ld, k0 + 64, T, tid);
+      lv.load(V, ld, k0 + 64, T, tid);
+    }
+    if (kb > my_last || q0 >= T) continue;
+#pragma unroll 1
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16_t PT[1][2], dPT[1][2];
+      zero_tiles(PT);
+      zero_tiles(dPT);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4_t fk = ldsfrag(Ks, 32 * kt + l31, s, h);
+        const u32x4_t fv = ldsfrag(Vs, 32 * kt + l31, s, h);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          mma(PT[0][qt], fk, fq[qt][s]);
+          mma(dPT[0][qt], fv, fdo[qt][s]);
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 32 * qt + l31;
+        const int klim = q < T ? (CAUSAL ? min(T, q + 1) : T) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p =
+              (k0 + 32 * kt + reg_index(r, h) < klim) ? __builtin_amdgcn_exp2f(PT[0][qt][r] * c - ls[qt]) : 0.0f;
+          dPT[0][qt][r] = p * (dPT[0][qt][r] - dl[qt]) * scale;
+        }
+      }
+      lds_product<L, 1, 2>(dQT, Kt, dPT, 32 * kt, lane);
+    }
+  }
+  if (q0 < T) store_transposed<L, 2>(dqkv + (int64_t)b * T * ld + hd * 64, ld, dQT, q0, T, lane);
+}
+
+// dK, dV, second generation: NWV waves (64 keys each) share the Q / dO query blocks through LDS (rows and transposed).
+template <typename L, bool CAUSAL, int NWV>
+__global__ __launch_bounds__(64 * NWV) void attn_flash2_bwd_dkv_kernel(const uint16_t* __restrict__ qkv,
+                                                                          const uint16_t* __restrict__ dout,
+                                                                          const float* __restrict__ lse,
+                                                                          const float* __restrict__ delta,
+                                                                          uint16_t* __restrict__ dqkv, int T, int heads,
+                                                                          float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t Qs[KPANEL];
+  __shared__ __attribute__((aligned(16))) uint16_t dOs[KPANEL];
+  __shared__ __attribute__((aligned(16))) uint16_t Qt[PANEL];
+  __shared__ __attribute__((aligned(16))) uint16_t dOt[PANEL];
+  __shared__ __attribute__((aligned(16))) float stat[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int D = heads * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const uint16_t* Q = qkv + (int64_t)b * T * ld + hd * 64;
+  const uint16_t* Kp = Q + D;
+  const uint16_t* V = Q + 2 * D;
+  const uint16_t* dO = dout + (int64_t)b * T * D + hd * 64;
+  const int k0 = 64 * (NWV * blockIdx.x + wv);                 // this wave's keys
+  const float c = scale * LOG2E;
+
+  u32x4_t fk[2][4], fv[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fk[kt][s] = rowfrag(Kp, ld, k0 + 32 * kt + l31, T, s, h);
+      fv[kt][s] = rowfrag(V, ld, k0 + 32 * kt + l31, T, s, h);
+    }
+  f32x16_t dVT[2][2], dKT[2][2];
+  zero_tiles(dVT);
+  zero_tiles(dKT);
+  const int nqb = (T + 63) / 64;
+  const int qb0 = CAUSAL ? NWV * (int)blockIdx.x : 0;          // first query block that sees any key of this workgroup
+  const int my_first = CAUSAL ? k0 / 64 : 0;
+  BlockLoader<NWV> lq, ldo;
+  lq.load(Q, ld, 64 * qb0, T, tid);
+  ldo.load(dO, D, 64 * qb0, T, tid);
+#pragma unroll 1
+  for (int qb = qb0; qb < nqb; ++qb) {
+    const int q0 = 64 * qb;
+    __syncthreads();
+    lq.store_rows(Qs, tid);
+    lq.store_transposed(Qt, tid);
+    ldo.store_rows(dOs, tid);
+    ldo.store_transposed(dOt, tid);
+    if (tid < 64) {
+      const int q = q0 + tid;
+      stat[0][tid] = q < T ? lse[(int64_t)bh * T + q] : 0.0f;
+      stat[1][tid] = q < T ? delta[(int64_t)bh * T + q] : 0.0f;
+    }
+    __syncthreads();
+    if (qb + 1 < nqb) {
+      lq.load(Q, ld, q0 + 64, T, tid);
+      ldo.load(dO, D, q0 + 64, T, tid);
+    }
+    if (qb < my_first || k0 >= T) continue;
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
+      if (q0 + 32 * qt >= T) break;
+      f32x16_t S[1][2], dP[1][2];
+      zero_tiles(S);
+      zero_tiles(dP);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4_t fa = ldsfrag(Qs, 32 * qt + l31, s, h);
+        const u32x4_t fb = ldsfrag(dOs, 32 * qt + l31, s, h);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          mma(S[0][kt], fa, fk[kt][s]);
+          mma(dP[0][kt], fb, fv[kt][s]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qi = 32 * qt + 8 * g + 4 * h;
+        const f32x4_t l4 = *(const f32x4_t*)&stat[0][qi];
+        const f32x4_t d4 = *(const f32x4_t*)&stat[1][qi];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const int key = k0 + 32 * kt + l31;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const int q = q0 + qi + j;
+            const bool ok = key < T && q < T && (!CAUSAL || key <= q);
+            const float p = ok ? __builtin_amdgcn_exp2f(S[0][kt][r] * c - l4[j]) : 0.0f;
+            S[0][kt][r] = p;
+            dP[0][kt][r] = p * (dP[0][kt][r] - d4[j]) * scale;
+          }
+        }
+      }
+      lds_product<L, 1, 2>(dVT, dOt, S, 32 * qt, lane);
+      lds_product<L, 1, 2>(dKT, Qt, dP, 32 * qt, lane);
+    }
+  }
+  if (k0 >= T) return;
+  uint16_t* dKp = dqkv + (int64_t)b * T * ld + hd * 64 + D;
+  store_transposed<L, 2>(dKp + D, ld, dVT, k0, T, lane);
+  store_transposed<L, 2>(dKp, ld, dKT, k0, T, lane);
+}
+
 #undef mma
 
 }  // namespace
@@ -619,9 +974,38 @@ extern "C" int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv
   return 0;
 }
 
+static int flash_gen() {               // FFVC_FLASH_GEN=1: the one-wave first-generation kernels (A/B runs)
+  static int g = -1;
+  if (g < 0) {
+    const char* e = getenv("FFVC_FLASH_GEN");
+    g = e ? atoi(e) : 2;
+  }
+  return g;
+}
+
 template <typename L>
 static void flash_fwd_launch(const void* qkv, void* out, float* lse, int B, int T, int heads, float scale, int causal,
                              hipStream_t st) {
+  if (flash_gen() >= 2) {
+    if (T > 320) {         // 4 waves share every key block; short sequences (257 tokens) waste fewer query slots with 2
+      const dim3 g4((T + 255) / 256, B * heads);
+      if (causal)
+        hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, true, 4>), g4, dim3(256), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
+                           T, heads, scale);
+      else
+        hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, false, 4>), g4, dim3(256), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
+                           T, heads, scale);
+    } else {
+      const dim3 g2((T + 127) / 128, B * heads);
+      if (causal)
+        hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, true, 2>), g2, dim3(128), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
+                           T, heads, scale);
+      else
+        hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, false, 2>), g2, dim3(128), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
+                           T, heads, scale);
+    }
+    return;
+  }
   const dim3 grid((T + 63) / 64, B * heads);
   if (causal)
     hipLaunchKernelGGL((attn_flash_fwd_kernel<L, true>), grid, dim3(64), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse, T,
@@ -634,6 +1018,23 @@ static void flash_fwd_launch(const void* qkv, void* out, float* lse, int B, int 
 template <typename L>
 static void flash_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                              int B, int T, int heads, float scale, int causal, hipStream_t st) {
+  if (flash_gen() >= 2) {
+#define FFVC_FLASH2_BWD(CAUS, NWV)                                                                                          \
+  {                                                                                                                         \
+    const dim3 g((T + 64 * NWV - 1) / (64 * NWV), B * heads);                                                               \
+    hipLaunchKernelGGL((attn_flash2_bwd_dq_kernel<L, CAUS, NWV>), g, dim3(64 * NWV), 0, st, (const uint16_t*)qkv,            \
+                       (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, T, heads, scale);          \
+    hipLaunchKernelGGL((attn_flash2_bwd_dkv_kernel<L, CAUS, NWV>), g, dim3(64 * NWV), 0, st, (const uint16_t*)qkv,           \
+                       (const uint16_t*)dout, lse, (const float*)delta, (uint16_t*)dqkv, T, heads, scale);                  \
+  }
+    if (T > 320) {
+      if (causal) FFVC_FLASH2_BWD(true, 4) else FFVC_FLASH2_BWD(false, 4)
+    } else {
+      if (causal) FFVC_FLASH2_BWD(true, 2) else FFVC_FLASH2_BWD(false, 2)
+    }
+#undef FFVC_FLASH2_BWD
+    return;
+  }
   const dim3 grid((T + 63) / 64, B * heads);
   if (causal) {
     hipLaunchKernelGGL((attn_flash_bwd_dq_kernel<L, true>), grid, dim3(64), 0, st, (const uint16_t*)qkv, (const uint16_t*)out,
