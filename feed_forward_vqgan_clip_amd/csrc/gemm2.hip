@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
     }
   }
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, ffvc_gemm_detail::EPI_GN>(p, acc, m0, n0, wm, wn, lane, 0, 0,
+                                                                                    smem + XTILE + WTILE + wid * 4096);
   else
     ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
 }
@@ -220,7 +221,8 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     const int env_row = opt_value(g_opt_conv_row, "FFVC_CONV_ROW", 1);
     const int W = d.conv_W;
     const bool geom_ok = (W == 64 || W == 128 || (W >= 256 && W % 256 == 0)) && ((int64_t)d.conv_H * W) % 256 == 0 && d.batch == 1 &&
-                         d.split_k <= 1 && (d.N % 128) == 0 && (d.M % 256) == 0;
+                         d.split_k <= 1 && (d.N % 128) == 0 && (d.M % 256) == 0 && d.act == FFVC_ACT_NONE &&
+                         !(d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM));   // its epilogue class is GN-only
     const bool fills = (int64_t)(d.M / 256) * (d.N / 128) >= 256;
     if (geom_ok && (env_row == 2 || (env_row == 1 && fills && cfg != 512))) {
       const int tiles_n = d.N / 128, n_tiles = (d.M / 256) * tiles_n;

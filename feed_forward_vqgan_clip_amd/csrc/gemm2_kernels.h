@@ -517,7 +517,9 @@ constexpr bool EXP_SKIP = false;
 #endif
 // BUF: K-major / implicit-im2col operands go through buffer-descriptor DMA (buffer_load ... lds, scalar K offset) instead of
 // global_load_lds with 64-bit per-lane addresses; plain operands only (no K segments, no split row map, offsets < 2 GiB).
-template <typename L, int XMODE, int WMODE, int BM, int BN, bool BUF = false>
+// EPI: epilogue class of the instantiation (gemm_common.h): the launcher picks the lean kernel for launches that use neither
+// an activation nor the column / GroupNorm sums.
+template <typename L, int XMODE, int WMODE, int BM, int BN, bool BUF = false, int EPI = ffvc_gemm_detail::EPI_ALL>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2_kernel(
     const ffvc_gemm_desc p, int tiles_n, int n_tiles, int ksplit_len, int vec_ok, const uint16_t* zero, int gm) {
   constexpr int MT = BM / 64;                        // 32-row MFMA tiles per wave along M (wave tile (32*MT) x 64)
@@ -703,8 +705,8 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     }
   }
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, m0, n0, wm, wn, lane, zo, zi,
-                                                       smem + (RING ? 2 : 1) * STAGE + wid * 4096);
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi,
+                                                                   smem + (RING ? 2 : 1) * STAGE + wid * 4096);
   else
     ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
 }
@@ -1206,19 +1208,43 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
       use_buf = e ? atoi(e) : 1;
     }
     if (use_buf && dma_operand_ok<XMODE>(d, true) && dma_operand_ok<WMODE>(d, false)) {
-      static bool attr_b = false;
-      if (!attr_b) {
-        (void)hipFuncSetAttribute((const void*)gemm2_kernel<L, XMODE, WMODE, BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_b = true;
+      using namespace ffvc_gemm_detail;
+      // epilogue class: convolutions never carry an activation (GroupNorm moments only), weight gradients (TRANS x TRANS)
+      // neither; the K-major x K-major / K-major x TRANS kernels exist lean and complete
+      static int lean_opt = -1;
+      if (lean_opt < 0) {
+        const char* e = getenv("FFVC_EPI_LEAN");
+        lean_opt = e ? atoi(e) : 1;
       }
-      hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN, true>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles,
-                         ksplit_len, vec_ok, zero, gm);
-      hipError_t eb = hipGetLastError();
-      if (eb != hipSuccess) {
-        ffvc_set_error("gemm2 (buffer DMA) launch failed: %s", hipGetErrorString(eb));
-        return -(int)eb - 1000;
+      const bool wants_act = d.act != FFVC_ACT_NONE || (d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM));
+      const bool wants_gn = d.flags & FFVC_F_GN_SUMS;
+      auto go = [&](auto epi_tag) -> int {
+        constexpr int EPI = decltype(epi_tag)::value;
+        static bool attr_b = false;
+        if (!attr_b) {
+          (void)hipFuncSetAttribute((const void*)gemm2_kernel<L, XMODE, WMODE, BM, BN, true, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          attr_b = true;
+        }
+        hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN, true, EPI>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles,
+                           ksplit_len, vec_ok, zero, gm);
+        hipError_t eb = hipGetLastError();
+        if (eb != hipSuccess) {
+          ffvc_set_error("gemm2 (buffer DMA) launch failed: %s", hipGetErrorString(eb));
+          return -(int)eb - 1000;
+        }
+        return 1;
+      };
+      if constexpr (XMODE == FFVC_OP_CONV3X3) {
+        if (!wants_act) return go(std::integral_constant<int, EPI_GN>{});
+      } else if constexpr (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS) {
+        if (!wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
+      } else if constexpr (XMODE == FFVC_OP_KMAJOR) {
+        if (lean_opt && !wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
+        return go(std::integral_constant<int, EPI_ALL>{});
+      } else {
+        return go(std::integral_constant<int, EPI_ALL>{});
       }
-      return 1;
+      // a convolution / weight gradient that does ask for an activation falls through to the global-address kernel below
     }
   }
   hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,

@@ -140,8 +140,7 @@ __device__ __forceinline__ f32x2_t apply_act2(int act, f32x2_t v) {
   if constexpr (sizeof(T) == 2) {
     if (act == FFVC_ACT_GELU) return act_gelu_fast2(v);
     if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_fast2(v);
-    if (act == FFVC_ACT_LRELU || act == FFVC_ACT_TANH) return f32x2_t{apply_act<T>(act, v[0]), apply_act<T>(act, v[1])};
-    return v;
+    return v;         // LeakyReLU / tanh exist only on the fp32 path (the Net2Net prior): 16 unrolled tanhf copies are bloat
   } else {
     f32x2_t r;
     r[0] = apply_act<T>(act, v[0]);
@@ -154,8 +153,6 @@ __device__ __forceinline__ f32x2_t apply_act_grad2(int act, f32x2_t pre) {
   if constexpr (sizeof(T) == 2) {
     if (act == FFVC_ACT_GELU) return act_gelu_grad_fast2(pre);
     if (act == FFVC_ACT_QUICKGELU) return act_quickgelu_grad_fast2(pre);
-    if (act == FFVC_ACT_LRELU || act == FFVC_ACT_TANH)
-      return f32x2_t{apply_act_grad<T>(act, pre[0]), apply_act_grad<T>(act, pre[1])};
     f32x2_t one = {1.0f, 1.0f};
     return one;
   } else {
@@ -166,7 +163,14 @@ __device__ __forceinline__ f32x2_t apply_act_grad2(int act, f32x2_t pre) {
   }
 }
 
-template <typename T>
+// EPI: which optional epilogue code a kernel instantiation carries (the row-store epilogue is unrolled 4 * MT times per
+// kernel, and its size is not free: adding an activation variant to every copy cost the whole step 10 %, removing the
+// activation code from kernels that never use it bought 7 % on plain GEMMs — profiles/r02_epilogue_code_size.txt).
+//   EPI_ACT   activation / activation-gradient / pre-activation write / bias-gradient column sums
+//   EPI_GN    GroupNorm moment accumulation
+constexpr int EPI_ACT = 1, EPI_GN = 2, EPI_ALL = 3, EPI_LEAN = 0;
+
+template <typename T, int EPI = EPI_ALL>
 __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,
                                              int64_t arow, int flags) {
   if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
@@ -174,7 +178,9 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v.v[j] += b.v[j];
   }
-  if (flags & FFVC_F_MUL_ACT_GRAD) {
+  if constexpr (!(EPI & EPI_ACT)) {
+    // lean instantiation: no activation code at all
+  } else if (flags & FFVC_F_MUL_ACT_GRAD) {
     const f32x8 pre = load8((const T*)p.aux + arow + n);
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
@@ -214,7 +220,7 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
 }
 
 // pad: this wave's 4 KiB of LDS.  Requires N % 8 == 0 and 16-byte aligned rows of y / aux / residual (host-checked).
-template <typename T, int MT, bool NSPLIT = false>
+template <typename T, int MT, bool NSPLIT = false, int EPI = EPI_ALL>
 __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0,
                                                    int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
                                                    int zs = -1) {
@@ -227,9 +233,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
   const int64_t abz = zo * p.abo + zi * p.abi;
   unsigned char* wr = pad + l31 * 128;
   const int wsw = l31 & 7;
-  const bool gn = flags & FFVC_F_GN_SUMS;
+  const bool gn = (EPI & EPI_GN) && (flags & FFVC_F_GN_SUMS);
   float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [nt][4-channel half]
-  const bool cs_on = flags & FFVC_F_COLSUM;
+  const bool cs_on = (EPI & EPI_ACT) && (flags & FFVC_F_COLSUM);
   float cs[2][8];                                                                      // [nt][column of this lane]
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -277,7 +283,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
           v.v[4 + j] = b[j];
         }
         if (mok[i] && n < p.N) {
-          epilogue_oct<T>(p, v, n, yrow[i], rrow[i], arow[i], flags);
+          epilogue_oct<T, EPI>(p, v, n, yrow[i], rrow[i], arow[i], flags);
           if (gn) {   // moments of the fp32 values before the bf16 store (the rounding noise adds ~1e-6 of E[x^2])
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
