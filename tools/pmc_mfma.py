@@ -18,7 +18,8 @@ agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for f in files:
     seen = set()
     for row in csv.DictReader(open(f)):
-        name = re.sub(r"\(.*", "", row["Kernel_Name"])[:90]
+        name = re.sub(r"^void ", "", row["Kernel_Name"])
+        name = re.sub(r"\(ffvc_gemm_desc.*|\(float const.*|\(unsigned short.*", "", name)[:90]
         a = agg[name]
         key = (row.get("Dispatch_Id"), name)
         if key not in seen:
