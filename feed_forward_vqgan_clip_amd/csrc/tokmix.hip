@@ -321,17 +321,25 @@ __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_
     // hipcc drain the LDS-DMA ring with vmcnt(0) at its first use
     const const_f32p bc = (const_f32p)(b1 + __builtin_amdgcn_readfirstlane(c) * TM_OC);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ol = 8 * (r >> 2) + 4 * hh + (r & 3);
-      const float blo = bc[8 * (r >> 2) + (r & 3)], bhi = bc[8 * (r >> 2) + 4 + (r & 3)];
-      const float pre = a1[r] + (hh ? bhi : blo);
-      float cdf, e;
-      gelu_parts_fast(pre, cdf, e);
-      const float hv = pre * cdf;
-      const float dv = a2[r] * (cdf + pre * 0.39894228040143267794f * e);
-      const uint32_t pk = lo_pack2<L>(hv, dv);
-      *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk & 0xffffu);
-      *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk >> 16);
+    for (int r = 0; r < 16; r += 2) {          // two hidden rows at a time: the erf / pdf polynomial runs on v_pk_*_f32
+      f32x2_t pre, cdf, e;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ru = r + u;
+        const float blo = bc[8 * (ru >> 2) + (ru & 3)], bhi = bc[8 * (ru >> 2) + 4 + (ru & 3)];
+        pre[u] = a1[ru] + (hh ? bhi : blo);
+      }
+      gelu_parts_fast2(pre, cdf, e);
+      const f32x2_t hv = pre * cdf;
+      const f32x2_t dv = f32x2_t{a2[r], a2[r + 1]} * (cdf + pre * 0.39894228040143267794f * e);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ru = r + u;
+        const int ol = 8 * (ru >> 2) + 4 * hh + (ru & 3);
+        const uint32_t pk = lo_pack2<L>(hv[u], dv[u]);
+        *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk & 0xffffu);
+        *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk >> 16);
+      }
     }
   }
   __syncthreads();
