@@ -460,6 +460,18 @@ inline bool mult(int64_t v, int64_t m) { return (v % m) == 0; }
 
 }  // namespace
 
+namespace {
+// aux[m, n] <- act'(aux[m, n]) in place (FFVC_F_AUX_ACTGRAD forward on kernels without the specialised epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void actgrad_inplace_kernel(T* __restrict__ aux, int act, int M, int N, int64_t ld) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    T* p = aux + (i / N) * ld + (i % N);
+    ElemTraits<T>::store(p, ffvc_gemm_detail::apply_act_grad<T>(act, ElemTraits<T>::load(p)));
+  }
+}
+}  // namespace
+
 extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   FFVC_CHECK_ARG(dp != nullptr, "ffvc_gemm: null descriptor");
   ffvc_gemm_desc d = *dp;
@@ -525,14 +537,36 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
              mult((int64_t)(uintptr_t)d.aux, 16);
   if (d.bias && !(d.flags & FFVC_F_BIAS_ALONG_M)) vec_ok = vec_ok && mult((int64_t)(uintptr_t)d.bias, 16);
   hipStream_t st = (hipStream_t)stream;
+  // FFVC_F_AUX_ACTGRAD forward: kernels without the specialised epilogue store the pre-activation; one extra pass turns it
+  // into the derivative so that the backward's plain multiply sees the same thing on every path
+  const bool actgrad_fwd = (d.flags & FFVC_F_AUX_ACTGRAD) && (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & FFVC_F_MUL_ACT_GRAD);
+  if (d.flags & FFVC_F_AUX_ACTGRAD) {
+    FFVC_CHECK_ARG(d.in_dtype != FFVC_F32 && d.aux && d.batch <= 1 && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU),
+                   "ffvc_gemm: FFVC_F_AUX_ACTGRAD needs a 16-bit dtype, aux, batch 1 and GELU / QuickGELU");
+  }
+  auto fixup = [&]() -> int {
+    if (!actgrad_fwd) return 0;
+    const int64_t n = (int64_t)d.M * d.N;
+    const int grid = (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256);
+    if (d.in_dtype == FFVC_F16)
+      hipLaunchKernelGGL((actgrad_inplace_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (f16_t*)d.aux, d.act, d.M, d.N, d.ldaux);
+    else
+      hipLaunchKernelGGL((actgrad_inplace_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, (uint16_t*)d.aux, d.act, d.M, d.N,
+                         d.ldaux);
+    FFVC_LAUNCH_CHECK();
+    return 0;
+  };
   {
     const int r2 = ffvc_gemm2_try(d, st, vec_ok);   // LDS-DMA fast path (bf16, 16-byte aligned operands)
-    if (r2 == 1) return 0;
+    if (r2 == 2) return 0;                          // specialised epilogue: aux already holds act'(pre)
+    if (r2 == 1) return fixup();
     if (r2 < 0) return r2;
   }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_GN_SUMS), "ffvc_gemm: FFVC_F_GN_SUMS is only available on the bf16 LDS-DMA path");
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_COLSUM), "ffvc_gemm: FFVC_F_COLSUM is only available on the 16-bit LDS-DMA path");
-  if (d.in_dtype == FFVC_BF16) return dispatch<uint16_t>(d, st, vec_ok);
-  if (d.in_dtype == FFVC_F16) return dispatch<f16_t>(d, st, vec_ok);
-  return dispatch<float>(d, st, vec_ok);
+  int rc;
+  if (d.in_dtype == FFVC_BF16) rc = dispatch<uint16_t>(d, st, vec_ok);
+  else if (d.in_dtype == FFVC_F16) rc = dispatch<f16_t>(d, st, vec_ok);
+  else rc = dispatch<float>(d, st, vec_ok);
+  return rc ? rc : fixup();
 }

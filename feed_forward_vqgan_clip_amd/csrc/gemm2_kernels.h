@@ -1240,6 +1240,28 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
         if (!wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
       } else if constexpr (XMODE == FFVC_OP_KMAJOR) {
         if (lean_opt && !wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
+        if constexpr (WMODE == FFVC_OP_KMAJOR && BM == 256 && BN == 256) {
+          // the MLP launches of the Mixer / ViT blocks: one activation, fixed at compile time
+          if (lean_opt >= 1 && !wants_gn && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU)) {
+            const bool bwd = d.flags & FFVC_F_MUL_ACT_GRAD;
+            if (d.flags & FFVC_F_AUX_ACTGRAD) {        // aux carries act'(pre): specialised store / plain multiply
+              if (bwd && !(d.flags & FFVC_F_WRITE_PREACT)) return go(std::integral_constant<int, EPI_K_MULAUX>{});
+              if (!bwd && (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & FFVC_F_COLSUM)) {
+                const int r = d.act == FFVC_ACT_GELU ? go(std::integral_constant<int, EPI_K_GELU_FWDG>{})
+                                                     : go(std::integral_constant<int, EPI_K_QGELU_FWDG>{});
+                return r == 1 ? 2 : r;                 // 2 = aux already holds the derivative (no conversion pass needed)
+              }
+            }
+            if (!bwd && !(d.flags & (FFVC_F_COLSUM | FFVC_F_AUX_ACTGRAD))) {
+              if (d.act == FFVC_ACT_GELU) return go(std::integral_constant<int, EPI_K_GELU_FWD>{});
+              return go(std::integral_constant<int, EPI_K_QGELU_FWD>{});
+            }
+            if (bwd && !(d.flags & (FFVC_F_WRITE_PREACT | FFVC_F_AUX_ACTGRAD))) {
+              if (d.act == FFVC_ACT_GELU) return go(std::integral_constant<int, EPI_K_GELU_BWD>{});
+              return go(std::integral_constant<int, EPI_K_QGELU_BWD>{});
+            }
+          }
+        }
         return go(std::integral_constant<int, EPI_ALL>{});
       } else {
         return go(std::integral_constant<int, EPI_ALL>{});

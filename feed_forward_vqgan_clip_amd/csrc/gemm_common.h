@@ -42,7 +42,7 @@ __device__ __forceinline__ void epilogue_quad(const ffvc_gemm_desc& p, f32x4_t v
     if (flags & FFVC_F_MUL_ACT_GRAD) {
       const f32x4_t pre = load4((const T*)p.aux + arow + n);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] *= apply_act_grad<T>(p.act, pre[j]);
+      for (int j = 0; j < 4; ++j) v[j] *= (flags & FFVC_F_AUX_ACTGRAD) ? pre[j] : apply_act_grad<T>(p.act, pre[j]);
     } else if (p.act != FFVC_ACT_NONE) {
       if (flags & FFVC_F_WRITE_PREACT) store4((T*)p.aux + arow + n, v);
 #pragma unroll
@@ -69,7 +69,8 @@ __device__ __forceinline__ void epilogue_quad(const ffvc_gemm_desc& p, f32x4_t v
       float u = v[j];
       if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) u += p.bias[n + j];
       if (flags & FFVC_F_MUL_ACT_GRAD) {
-        u *= apply_act_grad<T>(p.act, ElemTraits<T>::load((const T*)p.aux + arow + n + j));
+        const float av = ElemTraits<T>::load((const T*)p.aux + arow + n + j);
+        u *= (flags & FFVC_F_AUX_ACTGRAD) ? av : apply_act_grad<T>(p.act, av);
       } else if (p.act != FFVC_ACT_NONE) {
         if (flags & FFVC_F_WRITE_PREACT) ElemTraits<T>::store((T*)p.aux + arow + n + j, u);
         u = apply_act<T>(p.act, u);
@@ -163,12 +164,34 @@ __device__ __forceinline__ f32x2_t apply_act_grad2(int act, f32x2_t pre) {
   }
 }
 
+// activation a and derivative d of the pre-activation x in one go (shared erf / exp / sigmoid); 16-bit kernels only
+template <typename T>
+__device__ __forceinline__ void apply_act_both2(int act, f32x2_t x, f32x2_t& a, f32x2_t& d) {
+  if (act == FFVC_ACT_GELU) {
+    f32x2_t cdf, e;
+    gelu_parts_fast2(x, cdf, e);
+    a = x * cdf;
+    d = cdf + x * 0.39894228040143267794f * e;
+  } else {
+    const f32x2_t s = sigmoid_fast2(x * 1.702f);
+    a = x * s;
+    d = s * (1.0f + 1.702f * x * (1.0f - s));
+  }
+}
+
 // EPI: which optional epilogue code a kernel instantiation carries (the row-store epilogue is unrolled 4 * MT times per
 // kernel, and its size is not free: adding an activation variant to every copy cost the whole step 10 %, removing the
 // activation code from kernels that never use it bought 7 % on plain GEMMs — profiles/r02_epilogue_code_size.txt).
 //   EPI_ACT   activation / activation-gradient / pre-activation write / bias-gradient column sums
 //   EPI_GN    GroupNorm moment accumulation
+//   EPI_K_*   ONE activation fixed at compile time (no dynamic switch, no other activation's code): the Mixer / ViT MLP
+//             launches (GELU or QuickGELU, forward with optional pre-activation write, or activation-gradient + column sums)
 constexpr int EPI_ACT = 1, EPI_GN = 2, EPI_ALL = 3, EPI_LEAN = 0;
+constexpr int EPI_K_GELU_FWD = 4, EPI_K_QGELU_FWD = 8, EPI_K_GELU_BWD = 16, EPI_K_QGELU_BWD = 32;
+constexpr int EPI_K_GELU_FWDG = 64, EPI_K_QGELU_FWDG = 128;   // forward that stores act'(pre) (FFVC_F_AUX_ACTGRAD)
+constexpr int EPI_K_MULAUX = 256;                              // backward: acc *= aux (aux already holds act'(pre))
+constexpr int EPI_K_FWD = EPI_K_GELU_FWD | EPI_K_QGELU_FWD, EPI_K_BWD = EPI_K_GELU_BWD | EPI_K_QGELU_BWD;
+constexpr int EPI_K_FWDG = EPI_K_GELU_FWDG | EPI_K_QGELU_FWDG;
 
 template <typename T, int EPI = EPI_ALL>
 __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,
@@ -178,15 +201,55 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v.v[j] += b.v[j];
   }
-  if constexpr (!(EPI & EPI_ACT)) {
-    // lean instantiation: no activation code at all
-  } else if (flags & FFVC_F_MUL_ACT_GRAD) {
+  if constexpr ((EPI & EPI_K_FWDG) != 0) {
+    constexpr int A = (EPI & EPI_K_GELU_FWDG) ? FFVC_ACT_GELU : FFVC_ACT_QUICKGELU;
+    f32x8 g;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      f32x2_t a, dv;
+      apply_act_both2<T>(A, f32x2_t{v.v[j], v.v[j + 1]}, a, dv);
+      v.v[j] = a[0];
+      v.v[j + 1] = a[1];
+      g.v[j] = dv[0];
+      g.v[j + 1] = dv[1];
+    }
+    store8((T*)p.aux + arow + n, g);
+  } else if constexpr ((EPI & EPI_K_MULAUX) != 0) {
+    const f32x8 pre = load8((const T*)p.aux + arow + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] *= pre.v[j];
+  } else if constexpr ((EPI & EPI_K_FWD) != 0) {
+    constexpr int A = (EPI & EPI_K_GELU_FWD) ? FFVC_ACT_GELU : FFVC_ACT_QUICKGELU;
+    if (flags & FFVC_F_WRITE_PREACT) store8((T*)p.aux + arow + n, v);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2_t a = apply_act2<T>(A, f32x2_t{v.v[j], v.v[j + 1]});
+      v.v[j] = a[0];
+      v.v[j + 1] = a[1];
+    }
+  } else if constexpr ((EPI & EPI_K_BWD) != 0) {
+    constexpr int A = (EPI & EPI_K_GELU_BWD) ? FFVC_ACT_GELU : FFVC_ACT_QUICKGELU;
     const f32x8 pre = load8((const T*)p.aux + arow + n);
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-      const f32x2_t g = apply_act_grad2<T>(p.act, f32x2_t{pre.v[j], pre.v[j + 1]});
+      const f32x2_t g = apply_act_grad2<T>(A, f32x2_t{pre.v[j], pre.v[j + 1]});
       v.v[j] *= g[0];
       v.v[j + 1] *= g[1];
+    }
+  } else if constexpr (!(EPI & EPI_ACT)) {
+    // lean instantiation: no activation code at all
+  } else if (flags & FFVC_F_MUL_ACT_GRAD) {
+    const f32x8 pre = load8((const T*)p.aux + arow + n);
+    if (flags & FFVC_F_AUX_ACTGRAD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v.v[j] *= pre.v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2_t g = apply_act_grad2<T>(p.act, f32x2_t{pre.v[j], pre.v[j + 1]});
+        v.v[j] *= g[0];
+        v.v[j + 1] *= g[1];
+      }
     }
   } else if (p.act != FFVC_ACT_NONE) {
     if (flags & FFVC_F_WRITE_PREACT) store8((T*)p.aux + arow + n, v);
@@ -235,7 +298,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
   const int wsw = l31 & 7;
   const bool gn = (EPI & EPI_GN) && (flags & FFVC_F_GN_SUMS);
   float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [nt][4-channel half]
-  const bool cs_on = (EPI & EPI_ACT) && (flags & FFVC_F_COLSUM);
+  const bool cs_on = (EPI & (EPI_ACT | EPI_K_BWD | EPI_K_MULAUX)) && (flags & FFVC_F_COLSUM);
   float cs[2][8];                                                                      // [nt][column of this lane]
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)

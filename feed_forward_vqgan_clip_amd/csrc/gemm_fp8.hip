@@ -251,7 +251,7 @@ extern "C" int ffvc_gemm_fp8(const ffvc_gemm_desc* dp, int x_fmt, int lo_dtype, 
   FFVC_CHECK_ARG((d.K % 16) == 0 && (d.ldx % 16) == 0 && (d.ldw % 16) == 0 && ((uintptr_t)d.x % 16) == 0 &&
                      ((uintptr_t)d.w % 16) == 0,
                  "ffvc_gemm_fp8: K / ldx / ldw must be multiples of 16 and the operands 16-byte aligned (K=%d)", d.K);
-  FFVC_CHECK_ARG(!(d.flags & (FFVC_F_GN_SUMS | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_TR_SAFE)),
+  FFVC_CHECK_ARG(!(d.flags & (FFVC_F_GN_SUMS | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_TR_SAFE | FFVC_F_AUX_ACTGRAD)),
                  "ffvc_gemm_fp8: unsupported flags 0x%x", d.flags);
   FFVC_CHECK_ARG((256 * (d.ldx / 2) + d.K / 2) * 2 < 0x7FFFFF00ll && (256 * (d.ldw / 2) + d.K / 2) * 2 < 0x7FFFFF00ll,
                  "ffvc_gemm_fp8: operand rows too long for 32-bit DMA offsets");

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_QUICKGELU, ACT_TANH, BF16, F16, F32, F_ACCUM_OUT, F_ATOMIC_OUT, F_BIAS_ALONG_M,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_QUICKGELU, ACT_TANH, BF16, F_AUX_ACTGRAD, F16, F32, F_ACCUM_OUT, F_ATOMIC_OUT, F_BIAS_ALONG_M,  # noqa: F401
                    F_MUL_ACT_GRAD, F_OUT_F32, F_RES_F32, F_TR_SAFE, F_UPSAMPLE2X, F_WRITE_PREACT,
                    OP_CONV3X3, OP_KMAJOR, OP_TRANS, GemmDesc)
 

@@ -176,6 +176,7 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
 
 
 _LN_LO = os.environ.get("FFVC_LN_LO", "1") != "0"      # A/B switch for the fused bf16 gradient copy
+_ACTGRAD = os.environ.get("FFVC_ACTGRAD", "1") != "0"  # A/B switch: MLPs keep act'(pre) instead of pre (16-bit modes)
 
 
 def _gn_request(gn, y, images, hw, C):
@@ -280,6 +281,10 @@ class _MLPFn(Function):
         h_pre = torch.empty(*x.shape[:-1], W1.N, dtype=cdt, device=x.device)
         h = torch.empty_like(h_pre)
         ctx.fp8 = (W1.fp8 is not None and W2.fp8 is not None and not drop and x.dtype in K.LOWP and rows % 8 == 0)
+        # 16-bit modes keep act'(pre) instead of pre (`h_pre` then IS the derivative): the forward forms it from the erf / exp it
+        # evaluates anyway and the backward epilogue becomes a plain multiply (FFVC_F_AUX_ACTGRAD; fp32 parity mode and the fp8
+        # path keep the textbook form)
+        ctx.ag = K.F_AUX_ACTGRAD if (cdt in K.LOWP and _ACTGRAD and not ctx.fp8 and act in (ACT_GELU, ACT_QUICKGELU)) else 0
         if ctx.fp8:
             f1 = W1.fp8
             x8 = K.fp8_quant(x, f1["x"])
@@ -288,7 +293,7 @@ class _MLPFn(Function):
             K.fp8_next_scale(f1["x"])
         else:
             K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
-                   flags=K.F_WRITE_PREACT)
+                   flags=K.F_WRITE_PREACT | ctx.ag)
         y = torch.empty(*x.shape[:-1], W2.N, dtype=out_dtype or cdt, device=x.device)
         ctx.drop = (float(drop),) + tuple(_drop_seeds(2)) if drop else None
         if ctx.fp8:
@@ -336,7 +341,7 @@ class _MLPFn(Function):
                 K.fp8_next_scale(f1["g"])
             return dx, None, None, None, None, (dy if ctx.has_res else None), None, None, None, None, None
         K.gemm(dyt, W2.sht, dh, rows, W2.K, W2.N, ldx=W2.N, ldw=W2.N, aux=h_pre, ldaux=W2.K, act=ctx.act,
-               flags=K.F_MUL_ACT_GRAD, colsum=_grad_buf(W1.bias) if b1_fused else None)
+               flags=K.F_MUL_ACT_GRAD | ctx.ag, colsum=_grad_buf(W1.bias) if b1_fused else None)
         if ctx.drop:        # the hidden mask commutes with the element-wise act' factor the epilogue just applied
             K.dropout(dh, ctx.drop[0], ctx.drop[1], out=dh)
         if ctx.train:

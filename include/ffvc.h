@@ -59,6 +59,11 @@ extern "C" {
 #define FFVC_F_UPSAMPLE2X 128   /* conv: input is nearest-2x upsampled on the fly */
 #define FFVC_F_GN_SUMS 512      /* also accumulate GroupNorm moments of the stored output (see gn_sums below) */
 #define FFVC_F_COLSUM 1024      /* also accumulate the column sums of the stored output into colsum[N] (see below) */
+#define FFVC_F_AUX_ACTGRAD 2048 /* aux holds act'(pre-activation) instead of the pre-activation.  With FFVC_F_WRITE_PREACT the
+                                 * forward stores the derivative (formed from the same erf / exp as the activation; launches
+                                 * that cannot take the specialised kernel store the pre-activation and convert it in a second
+                                 * pass), with FFVC_F_MUL_ACT_GRAD the backward epilogue is a plain multiply.  16-bit dtypes,
+                                 * batch 1. */
 #define FFVC_F_ACCUM_OUT 256    /* y += acc with plain read-modify-write (fp32 y, split_k == 1: one owner per element) */
 
 /*

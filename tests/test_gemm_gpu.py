@@ -429,3 +429,39 @@ def test_fp8_gemm_rejects_bad_shapes(cuda):
     sc = K.Fp8Scale(K.E4M3, x8.device)
     with pytest.raises(FFVCError, match="multiples of 16"):
         K.gemm_fp8(x8, w8, y, 64, 64, 72, sc, sc, lo_dtype=torch.float16)
+
+
+@pytest.mark.parametrize("ldt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "quickgelu"])
+@pytest.mark.parametrize("M,N,Kd", [(1024, 1024, 256), (200, 72, 40), (512, 256, 128)])
+def test_gemm_actgrad_storage(cuda, M, N, Kd, act, ldt):
+    """FFVC_F_AUX_ACTGRAD: the forward leaves act'(pre) in aux (specialised epilogue on 256x256 tiles, pre-activation +
+    conversion pass elsewhere) and the backward epilogue multiplies by it — same numbers as the textbook pair
+    (pre-activation stored, derivative evaluated in the backward epilogue)."""
+    code = K.ACT_GELU if act == "gelu" else K.ACT_QUICKGELU
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, Kd, generator=g).to(ldt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).to(ldt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    dy = torch.randn(M, Kd, generator=g).to(ldt).cuda()
+    wt = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).to(ldt).cuda()
+    h0, pre = torch.empty(M, N, dtype=ldt, device=cuda), torch.empty(M, N, dtype=ldt, device=cuda)
+    h1, gd = torch.empty_like(h0), torch.empty_like(h0)
+    K.gemm(x, w, h0, M, N, Kd, ldx=Kd, ldw=Kd, bias=b, act=code, aux=pre, ldaux=N, flags=K.F_WRITE_PREACT)
+    K.gemm(x, w, h1, M, N, Kd, ldx=Kd, ldw=Kd, bias=b, act=code, aux=gd, ldaux=N, flags=K.F_WRITE_PREACT | K.F_AUX_ACTGRAD)
+    assert torch.equal(h0, h1)
+    p = (x.double() @ w.double().t() + b.double())
+    if act == "gelu":
+        want = 0.5 * (1 + torch.erf(p / 2 ** 0.5)) + p * torch.exp(-0.5 * p * p) / (2 * torch.pi) ** 0.5
+    else:
+        s = torch.sigmoid(1.702 * p)
+        want = s * (1 + 1.702 * p * (1 - s))
+    tol = 2e-3 if ldt == torch.float16 else 1.6e-2
+    assert (gd.double() - want).abs().max().item() < tol * max(1.0, want.abs().max().item()) + \
+        (2e-2 if ldt == torch.bfloat16 else 3e-3)          # conversion-pass path differentiates the ROUNDED pre-activation
+    d0, d1 = torch.empty_like(h0), torch.empty_like(h0)
+    K.gemm(dy, wt, d0, M, N, Kd, ldx=Kd, ldw=Kd, act=code, aux=pre, ldaux=N, flags=K.F_MUL_ACT_GRAD)
+    K.gemm(dy, wt, d1, M, N, Kd, ldx=Kd, ldw=Kd, act=code, aux=gd, ldaux=N, flags=K.F_MUL_ACT_GRAD | K.F_AUX_ACTGRAD)
+    ref = (dy.double() @ wt.double().t()) * want
+    scale = ref.abs().max().item()
+    assert (d1.double() - ref).abs().max().item() < 3 * tol * scale and (d0.double() - ref).abs().max().item() < 3 * tol * scale
