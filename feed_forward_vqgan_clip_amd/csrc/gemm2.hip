@@ -36,7 +36,7 @@ namespace {
 // 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
 // (X 33 KiB + W 16 KiB) so that two workgroups share a CU and alternate DMA / MFMA phases.
 // K order: kh (3) x 64-channel block (Cin/64) x kw (3); the X tile is (re)loaded only when (kh, block) changes.
-template <typename L, bool BUF>
+template <typename L, bool BUF, int EPI = ffvc_gemm_detail::EPI_GN>
 __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
                                                           const uint16_t* zero) {
   constexpr int MT = 4, BM = 256, BN = 128;
@@ -106,8 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
     }
   }
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, ffvc_gemm_detail::EPI_GN>(p, acc, m0, n0, wm, wn, lane, 0, 0,
-                                                                                    smem + XTILE + WTILE + wid * 4096);
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
   else
     ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
 }
@@ -239,12 +238,23 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
         attr = true;
       }
       const bool buf = use_buf && g8_offsets_ok<FFVC_OP_CONV3X3>(d);
+      // epilogue class: forward convolutions accumulate the next GroupNorm's moments, dgrad convolutions do not -> lean
+      const bool gnv = (d.flags & FFVC_F_GN_SUMS) != 0;
+      constexpr int EG = ffvc_gemm_detail::EPI_GN, EL = ffvc_gemm_detail::EPI_LEAN;
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t, true, EL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, true, EL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr2 = true;
+      }
       if (d.in_dtype == FFVC_F16) {
-        if (buf) hipLaunchKernelGGL((conv_row_kernel<f16_t, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
-        else hipLaunchKernelGGL((conv_row_kernel<f16_t, false>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        if (buf && !gnv) hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EL>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        else if (buf) hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EG>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        else hipLaunchKernelGGL((conv_row_kernel<f16_t, false, EG>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
       } else {
-        if (buf) hipLaunchKernelGGL((conv_row_kernel<uint16_t, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
-        else hipLaunchKernelGGL((conv_row_kernel<uint16_t, false>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        if (buf && !gnv) hipLaunchKernelGGL((conv_row_kernel<uint16_t, true, EL>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        else if (buf) hipLaunchKernelGGL((conv_row_kernel<uint16_t, true, EG>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        else hipLaunchKernelGGL((conv_row_kernel<uint16_t, false, EG>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
       }
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) {

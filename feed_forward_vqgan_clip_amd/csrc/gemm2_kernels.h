@@ -1235,6 +1235,7 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
         return 1;
       };
       if constexpr (XMODE == FFVC_OP_CONV3X3) {
+        if (!wants_act && !wants_gn && lean_opt) return go(std::integral_constant<int, EPI_LEAN>{});   // dgrad convolutions
         if (!wants_act) return go(std::integral_constant<int, EPI_GN>{});
       } else if constexpr (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS) {
         if (!wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
