@@ -97,8 +97,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
 // (part_g/part_b: [gridDim.x, dim], reduced afterwards by ffvc_colsum); NULL skips them.
 // MAXE = elements cached per lane (16: dim <= 1024, 32: dim <= 2048): the kernel is latency-bound on its row loads, so
 // register count (= waves in flight per SIMD) is what sets its bandwidth.
-template <int VEC, typename DYT, typename XT, int MAXE = LN_MAXE>
-__global__ __launch_bounds__(256, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(const DYT* __restrict__ dy, const XT* __restrict__ x,
+// NWB = waves per workgroup.  The parameter gradients leave the workgroup as one fp32 atomic per column, and same-address
+// atomics serialise in L2 (~75 ns each): their cost is proportional to the NUMBER OF WORKGROUPS, so large launches use 16
+// waves per workgroup (a quarter of the workgroups at the same number of waves in flight) — an experiment (FFVC_LN_WIDE=1):
+// the 16-way LDS combine costs more than the atomics it saves, so the 4-wave form stays the default.
+template <int VEC, typename DYT, typename XT, int MAXE = LN_MAXE, int NWB = 4>
+__global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(const DYT* __restrict__ dy, const XT* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const XT* __restrict__ dres,
@@ -113,12 +117,12 @@ __global__ __launch_bounds__(256, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(const
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) ag[i] = ab[i] = 0.f;
   if (want_p) {
-    for (int i = threadIdx.x; i < 2 * dim; i += 256) ln_smem[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * dim; i += 64 * NWB) ln_smem[i] = 0.f;
     __syncthreads();
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
-  for (int64_t row = r0 + wave; row < r1; row += 4) {
+  for (int64_t row = r0 + wave; row < r1; row += NWB) {
     const float mu = mean[row], rs = rstd[row];
     float g[MAXE], xh[MAXE], rsd[MAXE];
     float s1 = 0.f, s2 = 0.f;
@@ -175,12 +179,12 @@ __global__ __launch_bounds__(256, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(const
     }
     __syncthreads();
     if (acc_mode) {   // part_g / part_b are the [dim] gradients themselves: one fp32 atomic per column and workgroup
-      for (int i = threadIdx.x; i < dim; i += 256) {
+      for (int i = threadIdx.x; i < dim; i += 64 * NWB) {
         atomicAdd(part_g + i, ln_smem[i]);
         atomicAdd(part_b + i, ln_smem[dim + i]);
       }
     } else {
-      for (int i = threadIdx.x; i < dim; i += 256) {
+      for (int i = threadIdx.x; i < dim; i += 64 * NWB) {
         part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
         part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
       }
@@ -784,6 +788,23 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
   const bool v4 = (dim % 4) == 0;
+  static int wide = -1;
+  if (wide < 0) {
+    const char* e = getenv("FFVC_LN_WIDE");
+    wide = e ? atoi(e) : 0;     // measured: 16384x1024 74.8 us (4 waves) vs 89.9 us (16 waves) isolated, step 141.6 vs 142-143 ms: off
+  }
+  if (wide && acc_mode && part_g && v4 && dim <= 1024 && rows >= 8192) {
+    // accumulate-into-the-bucket mode on a large launch: 16-wave workgroups, 64 rows each (see ln_bwd_kernel)
+    const int rpb16 = 64;
+    const int grid16 = (int)((rows + rpb16 - 1) / rpb16);
+    DISPATCH_DT(dy_dtype, DYT, DISPATCH_DT(x_dtype, XT, {
+                  hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16, 16>), dim3(grid16), dim3(1024), smem, st, (const DYT*)dy,
+                                     (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows, dim,
+                                     rpb16, acc_mode, (DYT*)dx_lo);
+                }));
+    FFVC_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_DT(dy_dtype, DYT, DISPATCH_DT(x_dtype, XT, {
                 if (v4 && dim <= 1024)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,

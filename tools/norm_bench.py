@@ -26,6 +26,9 @@ for rows, dim, tag in ((16384, 1024, "mixer"), (25600, 768, "vit")):
     dres = torch.randn(rows, dim, device=dev)
     report(f"ln_bwd {tag} +dres +param grads", timeit(lambda: K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=True)),
            rows * dim * 14)
+    dg, db = torch.zeros(dim, device=dev), torch.zeros(dim, device=dev)
+    report(f"ln_bwd_acc {tag} +dres +param grads (bucket atomics) +lo copy",
+           timeit(lambda: K.layernorm_bwd_acc(dy, x, g, mean, rstd, dg, db, dres=dres, want_lo=True)), rows * dim * 16)
     report(f"ln_bwd {tag} +dres", timeit(lambda: K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)), rows * dim * 14)
     report(f"ln_bwd {tag} plain", timeit(lambda: K.layernorm_bwd(dy, x, g, mean, rstd)), rows * dim * 10)
 
