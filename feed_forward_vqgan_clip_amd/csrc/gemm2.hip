@@ -25,6 +25,7 @@
 #include "gemm2_kernels.h"
 
 // the other operand-mode pairs are instantiated in gemm2_modes.hip / gemm2_conv.hip (parallel compilation)
+int ffvc_gemm2_launch_kk(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
 int ffvc_gemm2_launch_conv(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
 int ffvc_gemm2_launch_nn(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
 int ffvc_gemm2_launch_tn(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
@@ -131,7 +132,8 @@ const uint16_t* zero_page() {
   if (!g_zero_page[dev]) {
     void* p = nullptr;
     if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
+    // one-time: the null-stream memset is not ordered against torch's non-blocking streams -> wait for it here
+    if (hipMemset(p, 0, 4096) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
     g_zero_page[dev] = (uint16_t*)p;
   }
   return g_zero_page[dev];
@@ -215,7 +217,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     }
     if (d.K <= shortk && cfg != 128) cfg = 128;
   }
-  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return launch2_cfg<FFVC_OP_KMAJOR, FFVC_OP_KMAJOR>(d, st, vec_ok, zero, cfg);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return ffvc_gemm2_launch_kk(d, st, vec_ok, zero, cfg);
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) {
     const int env_row = opt_value(g_opt_conv_row, "FFVC_CONV_ROW", 1);
     const int W = d.conv_W;

@@ -1135,6 +1135,9 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
   // measured (profiles/r01_gemm_micro.txt): grouping only pays for very wide outputs (8192^3: +7 %); the step's own
   // shapes (tiles_n <= 16) are neutral to slightly worse, so they keep the row-major order
   int gm = gm_opt >= 0 && getenv("FFVC_TILE_GM") ? gm_opt : (tiles_n > 16 ? 4 : 1);
+  // weight gradients whose output is wider than tall (dW2 of the channel MLP: 1024 x 4096 from a 16384-long reduction):
+  // pairs of tile rows share the wide operand's panel, 774 -> 847 TFLOP/s isolated (tools/tt_gm_ab.py)
+  if (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS && !getenv("FFVC_TILE_GM") && tiles_n > tiles_m) gm = 2;
   if (gm > tiles_m) gm = tiles_m;
   {
     static int stagger = -1;
