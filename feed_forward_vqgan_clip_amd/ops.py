@@ -225,7 +225,7 @@ class _LinearFn(Function):
             if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
                 raise TypeError("linear(drop>0) with a residual needs the fp32 residual stream")
             K.dropout(y, ctx.drop[0], ctx.drop[1], residual=residual, out=y)
-        elif W.fp8 is not None and not gn_hw and x.dtype in K.LOWP and rows % 8 == 0:
+        elif W.fp8 is not None and not gn_hw and x.dtype in K.LOWP:
             f = W.fp8                  # fp8 MFMA path of a frozen layer: quantise the activation, per-tensor delayed scale
             x8 = K.fp8_quant(x, f["x"])
             K.gemm_fp8(x8, f["sh"], y, rows, W.N, W.K, f["x"], f["w"], lo_dtype=cdt, bias=W.bias, residual=residual)
@@ -251,7 +251,7 @@ class _LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
             f = W.fp8
-            if f is not None and f["sht"] is not None and not ctx.drop and dyt.dtype in K.LOWP and rows % 8 == 0:
+            if f is not None and f["sht"] is not None and not ctx.drop and dyt.dtype in K.LOWP:
                 dy8 = K.fp8_quant(dyt, f["g"])                       # gradients travel as e5m2
                 K.gemm_fp8(dy8, f["sht"], dx, rows, W.K, W.N, f["g"], f["w"], lo_dtype=cdt)
                 K.fp8_next_scale(f["g"])
@@ -280,7 +280,7 @@ class _MLPFn(Function):
         rows = x.numel() // W1.K
         h_pre = torch.empty(*x.shape[:-1], W1.N, dtype=cdt, device=x.device)
         h = torch.empty_like(h_pre)
-        ctx.fp8 = (W1.fp8 is not None and W2.fp8 is not None and not drop and x.dtype in K.LOWP and rows % 8 == 0)
+        ctx.fp8 = (W1.fp8 is not None and W2.fp8 is not None and not drop and x.dtype in K.LOWP)
         # 16-bit modes keep act'(pre) instead of pre (`h_pre` then IS the derivative): the forward forms it from the erf / exp it
         # evaluates anyway and the backward epilogue becomes a plain multiply (FFVC_F_AUX_ACTGRAD; fp32 parity mode and the fp8
         # path keep the textbook form)

@@ -175,3 +175,55 @@ def test_cfg3_cfg4_throughput_mode_properties(cuda, kind):
         losses.append(loss.item())
     final, _ = stepper.forward_loss(tok, **kw)
     assert min(losses[1:] + [final.item()]) < losses[0], losses     # Adam on a fixed batch finds a lower loss within 4 steps
+
+
+def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
+    """BASELINE.json configs[4] at full size (Mixer 1x1024 on a 32x32 latent grid, 512x512 decode, OpenCLIP ViT-L/14 LAION-2B
+    tower: erf-GELU, 257 tokens -> flash-style attention, 588-wide patch rows), two prompts x two cutouts: the throughput
+    modes (f16 storage; f16 + fp8 MFMA linears in the tower with delayed scaling) against the exact-fp32 HIP mode on the same
+    weights and draws (that mode is pinned to the oracle per component: Mixer / decoder / patch-14 tower tests), and a
+    training step in the fp8 mode."""
+    Bn, cutn = 2, 2
+    name = "openclip/ViT-L-14/laion2b_s32b_b82k"
+    cfg = fmain.Config(lr=1e-4, epochs=1, noise_dim=0, dropout=0, cutn=cutn, batch_size=Bn, repeat=1, nb_noise=None,
+                       diversity_coef=0, clip_model=name, model_type="mlp_mixer", dim=1024, depth=1, vq_image_size=32)
+    arch, quick = fmain.clip_arch(name)
+    assert arch is fclip.VIT_L14 and quick is False and fmain.clip_dim_size(cfg) == (768, 224)
+    vq_sd, clip_sd = fvq.random_state_dict(fvq.F16_16384, seed=3), fclip.random_state_dict(arch, seed=3)
+    tok = fmain.synthetic_tokens(Bn, seed=5).cuda()
+    g = torch.Generator().manual_seed(9)
+    facs, noise = (torch.rand(cutn * Bn, generator=g) * 0.1).cuda(), torch.randn(cutn * Bn, 3, 224, 224, generator=g).cuda()
+    prm = None
+    out = {}
+    for mode, cdt, fp8 in (("fp32", torch.float32, False), ("f16", torch.float16, False), ("fp8", torch.float16, True)):
+        torch.manual_seed(3)
+        net = fmain.build_model(cfg, 256).cuda().prepare(cdt)
+        vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
+        perceptor = fclip.CLIP(clip_sd, cdt, quick_gelu=quick, fp8=fp8)
+        assert perceptor.grid == 16 and len(perceptor.vblocks) == 24 and perceptor.embed_dim == 768
+        opt = FusedAdam(net.parameters(), lr=cfg.lr)
+        opt.loss_scale = 4096.0 if cdt == torch.float16 else 1.0
+        stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+        if prm is None:
+            prm = stepper.make_cutouts.draw_aug_params(cutn * Bn, "cuda")
+        idx = out["fp32"]["indices"] if "fp32" in out else None          # same codes as the fp32 run: compares arithmetic
+        with torch.no_grad():
+            loss, mid = stepper.forward_loss(tok, facs=facs, noise=noise, aug_params=prm, force_idx=idx)
+        assert tuple(mid["xr"].shape) == (Bn, 512, 512, 3) and tuple(mid["embed"].shape) == (cutn * Bn, 768)
+        out[mode] = dict(loss=loss.item(), indices=mid["indices"], embed=mid["embed"].float(), xr=mid["xr"].float())
+        if mode == "fp8":
+            l1, _ = stepper(tok, facs=facs, noise=noise, aug_params=prm)   # a full training step in the fp8 mode
+            gr = net._ffvc_arena.grads
+            assert math.isfinite(l1.item()) and torch.isfinite(gr).all() and gr.abs().max().item() > 0
+        del stepper, net, vq, perceptor, opt
+        torch.cuda.empty_cache()
+    ref = out["fp32"]
+
+    def rr(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+    e16, e8 = rr(out["f16"]["embed"], ref["embed"]), rr(out["fp8"]["embed"], ref["embed"])
+    r16, r8 = abs(out["f16"]["loss"] - ref["loss"]) / ref["loss"], abs(out["fp8"]["loss"] - ref["loss"]) / ref["loss"]
+    print(f"[cfg5] loss fp32 {ref['loss']:.7f} | f16 rel {r16:.2e} embed {e16:.2e} | fp8 rel {r8:.2e} embed {e8:.2e}")
+    assert rr(out["f16"]["xr"], ref["xr"]) < 3e-3 and e16 < 3e-3 and r16 < 1e-4        # the north_star tolerance in f16 mode
+    assert e8 < 6e-2 and r8 < 3e-3                                                      # fp8 tower: its own budget
