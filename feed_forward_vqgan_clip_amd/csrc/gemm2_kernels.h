@@ -1241,12 +1241,28 @@ int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t*
         if (!wants_act && !wants_gn && lean_opt) return go(std::integral_constant<int, EPI_LEAN>{});   // dgrad convolutions
         if (!wants_act) return go(std::integral_constant<int, EPI_GN>{});
       } else if constexpr (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS) {
+        if (!wants_act && !wants_gn && lean_opt >= 1 && (d.flags & FFVC_F_OUT_F32) && !d.residual && !d.bias &&
+            !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)))
+          return go(std::integral_constant<int, EPI_LEAN | EPI_O_F32>{});          // weight-gradient slabs
         if (!wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
       } else if constexpr (XMODE == FFVC_OP_KMAJOR) {
+        if constexpr (WMODE == FFVC_OP_KMAJOR) {
+          if (lean_opt >= 1 && !wants_act && !wants_gn && !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_BIAS_ALONG_M)) &&
+              d.slab_stride == 0) {
+            if (!d.residual && !(d.flags & FFVC_F_OUT_F32)) return go(std::integral_constant<int, EPI_LEAN | EPI_O_T>{});
+            if (d.residual && (d.flags & FFVC_F_RES_F32) && (d.flags & FFVC_F_OUT_F32))
+              return go(std::integral_constant<int, EPI_LEAN | EPI_O_F32R>{});
+          }
+        }
         if (lean_opt && !wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
         if constexpr (WMODE == FFVC_OP_KMAJOR && BM == 256 && BN == 256) {
           // the MLP launches of the Mixer / ViT blocks: one activation, fixed at compile time
-          if (lean_opt >= 1 && !wants_gn && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU)) {
+          // the kinds fix the rest of the epilogue too: 16-bit plain output, no residual, column bias (forward) / none (backward)
+          const bool plain_out = !d.residual && !(d.flags & (FFVC_F_OUT_F32 | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) &&
+                                 d.slab_stride == 0 && d.alpha == 1.0f;
+          const bool bwd_k = d.flags & FFVC_F_MUL_ACT_GRAD;
+          const bool bias_ok = bwd_k ? d.bias == nullptr : (d.bias != nullptr && !(d.flags & FFVC_F_BIAS_ALONG_M));
+          if (lean_opt >= 1 && !wants_gn && plain_out && bias_ok && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU)) {
             const bool bwd = d.flags & FFVC_F_MUL_ACT_GRAD;
             if (d.flags & FFVC_F_AUX_ACTGRAD) {        // aux carries act'(pre): specialised store / plain multiply
               if (bwd && !(d.flags & FFVC_F_WRITE_PREACT)) return go(std::integral_constant<int, EPI_K_MULAUX>{});

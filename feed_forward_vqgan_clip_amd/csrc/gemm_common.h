@@ -192,11 +192,24 @@ constexpr int EPI_K_GELU_FWDG = 64, EPI_K_QGELU_FWDG = 128;   // forward that st
 constexpr int EPI_K_MULAUX = 256;                              // backward: acc *= aux (aux already holds act'(pre))
 constexpr int EPI_K_FWD = EPI_K_GELU_FWD | EPI_K_QGELU_FWD, EPI_K_BWD = EPI_K_GELU_BWD | EPI_K_QGELU_BWD;
 constexpr int EPI_K_FWDG = EPI_K_GELU_FWDG | EPI_K_QGELU_FWDG;
+// The kinds also fix the REST of the epilogue (the launcher checks it): forward kinds = column bias, no residual, output in the
+// 16-bit storage type; backward kinds = no bias, no residual, 16-bit output.  No flag tests are left in their unrolled copies.
+constexpr int EPI_K_ANY_FWD = EPI_K_FWD | EPI_K_FWDG, EPI_K_ANY_BWD = EPI_K_BWD | EPI_K_MULAUX;
+constexpr int EPI_K_ANY = EPI_K_ANY_FWD | EPI_K_ANY_BWD;
+// Output classes of the lean kernels (again launcher-checked): 16-bit plain store without residual (dgrads, qkv), fp32 store
+// with an fp32 residual (the projections back into the fp32 residual stream), plain fp32 store (weight-gradient slabs).
+constexpr int EPI_O_T = 512, EPI_O_F32R = 1024, EPI_O_F32 = 2048;
 
 template <typename T, int EPI = EPI_ALL>
 __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,
                                              int64_t arow, int flags) {
-  if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
+  if constexpr ((EPI & EPI_K_ANY_FWD) != 0) {
+    const f32x8 b = load8(p.bias + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] += b.v[j];
+  } else if constexpr ((EPI & EPI_K_ANY_BWD) != 0) {
+    // no bias
+  } else if (p.bias && !(flags & FFVC_F_BIAS_ALONG_M)) {
     const f32x8 b = load8(p.bias + n);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v.v[j] += b.v[j];
@@ -260,6 +273,19 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
       v.v[j + 1] = a[1];
     }
   }
+  if constexpr ((EPI & (EPI_K_ANY | EPI_O_T)) != 0) {
+    store8((T*)p.y + yrow + n, v);
+    return;
+  } else if constexpr ((EPI & EPI_O_F32R) != 0) {
+    const f32x8 r = load8((const float*)p.residual + rrow + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] += r.v[j];
+    store8((float*)p.y + yrow + n, v);
+    return;
+  } else if constexpr ((EPI & EPI_O_F32) != 0) {
+    store8((float*)p.y + yrow + n, v);
+    return;
+  }
   if (p.residual) {
     const f32x8 r = (flags & FFVC_F_RES_F32) ? load8((const float*)p.residual + rrow + n) : load8((const T*)p.residual + rrow + n);
 #pragma unroll
@@ -308,7 +334,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
   for (int mt = 0; mt < MT; ++mt) {
     const int mbase = m0 + wm * (32 * MT) + mt * 32;
     float bias_m = 0.0f;
-    if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mbase + l31, p.M - 1)];
+    if constexpr ((EPI & EPI_K_ANY) == 0)
+      if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mbase + l31, p.M - 1)];
     int64_t yrow[2], rrow[2], arow[2];
     bool mok[2];
 #pragma unroll
