@@ -91,6 +91,7 @@ _lib = None
 # include/ffvc.h appears here and is exported by the shared object.
 _SIGNATURES = {
     "ffvc_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ffvc_actgrad_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "ffvc_gemm_fp8": (c_int, [POINTER(GemmDesc), c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ffvc_fp8_quant": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "ffvc_fp8_amax": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),

@@ -472,6 +472,18 @@ __global__ __launch_bounds__(256) void actgrad_inplace_kernel(T* __restrict__ au
 }
 }  // namespace
 
+extern "C" int ffvc_actgrad_inplace(void* aux, int dtype, int act, int M, int N, int64_t ld, void* stream) {
+  FFVC_CHECK_ARG(aux && (dtype == FFVC_BF16 || dtype == FFVC_F16) && M > 0 && N > 0 && ld >= N, "ffvc_actgrad_inplace: bad args");
+  const int64_t n = (int64_t)M * N;
+  const int grid = (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256);
+  if (dtype == FFVC_F16)
+    hipLaunchKernelGGL((actgrad_inplace_kernel<f16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (f16_t*)aux, act, M, N, ld);
+  else
+    hipLaunchKernelGGL((actgrad_inplace_kernel<uint16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint16_t*)aux, act, M, N, ld);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   FFVC_CHECK_ARG(dp != nullptr, "ffvc_gemm: null descriptor");
   ffvc_gemm_desc d = *dp;
@@ -546,15 +558,7 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   }
   auto fixup = [&]() -> int {
     if (!actgrad_fwd) return 0;
-    const int64_t n = (int64_t)d.M * d.N;
-    const int grid = (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256);
-    if (d.in_dtype == FFVC_F16)
-      hipLaunchKernelGGL((actgrad_inplace_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (f16_t*)d.aux, d.act, d.M, d.N, d.ldaux);
-    else
-      hipLaunchKernelGGL((actgrad_inplace_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, (uint16_t*)d.aux, d.act, d.M, d.N,
-                         d.ldaux);
-    FFVC_LAUNCH_CHECK();
-    return 0;
+    return ffvc_actgrad_inplace(d.aux, d.in_dtype, d.act, d.M, d.N, d.ldaux, stream);
   };
   {
     const int r2 = ffvc_gemm2_try(d, st, vec_ok);   // LDS-DMA fast path (bf16, 16-byte aligned operands)

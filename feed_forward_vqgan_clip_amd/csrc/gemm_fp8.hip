@@ -16,6 +16,8 @@
 // ffvc_fp8_amax, ffvc_fp8_update (scale <- fmt_max / (amax * margin)).
 #include "gemm2_kernels.h"
 
+extern "C" int ffvc_actgrad_inplace(void* aux, int dtype, int act, int M, int N, int64_t ld, void* stream);
+
 namespace {
 
 typedef int v8i_t __attribute__((ext_vector_type(8)));
@@ -29,7 +31,7 @@ __device__ __forceinline__ void mma_f8(f32x16_t& acc, const u32x4_t& a0, const u
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, XFMT, 0, 0, 0, 0);
 }
 
-template <typename L, int BM, int BN, int XFMT>
+template <typename L, int BM, int BN, int XFMT, int EPI = ffvc_gemm_detail::EPI_ALL>
 __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm_f8_kernel(const ffvc_gemm_desc p, int tiles_n,
                                                                                           int n_tiles, int vec_ok,
                                                                                           const float* __restrict__ s0,
@@ -126,29 +128,57 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm_
         for (int i = 0; i < 16; ++i) acc[a][b][i] *= s;
   }
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<L, MT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + (RING ? 2 : 1) * STAGE + wid * 4096, 0);
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0,
+                                                                   smem + (RING ? 2 : 1) * STAGE + wid * 4096, 0);
   else
     ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1, 0);
 }
 
+// returns 0 (launched), 2 (launched, aux already holds act'(pre)) or an error code
 template <typename L, int BM, int BN>
 int launch_f8(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, const float* s1, hipStream_t st) {
+  using namespace ffvc_gemm_detail;
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
   const int n_tiles = tiles_m * tiles_n;
   constexpr int nthreads = 64 * 2 * (BN / 64);
   constexpr int lds = ((BM == 256 && BN == 128) ? 1 : 2) * (BM * 128 + BN * 128) + 2 * (BN / 64) * 4096;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_f8_kernel<L, BM, BN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)gemm_f8_kernel<L, BM, BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
+  auto go = [&](auto xf, auto epi_tag) -> int {
+    constexpr int XF = decltype(xf)::value, EPI = decltype(epi_tag)::value;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_f8_kernel<L, BM, BN, XF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm_f8_kernel<L, BM, BN, XF, EPI>), dim3(n_tiles), dim3(nthreads), lds, st, d, tiles_n, n_tiles, vec_ok, s0, s1);
+    FFVC_LAUNCH_CHECK();
+    return 0;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if constexpr (BM == 256 && BN == 256) {
+    // epilogue classes as in gemm2_kernels.h::launch2 (profiles/r02_epilogue_code_size.txt): the tower's launches are
+    // forward (e4m3 activations): qkv (16-bit plain), out_proj / c_proj (fp32 + fp32 residual), c_fc (activation + act'(pre));
+    // backward (e5m2 gradients): plain 16-bit dgrads and the aux-multiply
+    const bool wants_act = d.act != FFVC_ACT_NONE || (d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM));
+    const bool plain_store = !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_BIAS_ALONG_M)) && vec_ok == 2;
+    if (plain_store && !wants_act) {
+      if (!d.residual && !(d.flags & FFVC_F_OUT_F32))
+        return x_fmt ? go(I1{}, std::integral_constant<int, EPI_LEAN | EPI_O_T>{}) : go(I0{}, std::integral_constant<int, EPI_LEAN | EPI_O_T>{});
+      if (!x_fmt && d.residual && (d.flags & FFVC_F_RES_F32) && (d.flags & FFVC_F_OUT_F32))
+        return go(I0{}, std::integral_constant<int, EPI_LEAN | EPI_O_F32R>{});
+    }
+    const bool plain_out = plain_store && !d.residual && !(d.flags & FFVC_F_OUT_F32);
+    if (plain_out && (d.flags & FFVC_F_AUX_ACTGRAD) && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU)) {
+      const bool bwd = d.flags & FFVC_F_MUL_ACT_GRAD;
+      if (x_fmt && bwd && !d.bias && !(d.flags & FFVC_F_WRITE_PREACT)) return go(I1{}, std::integral_constant<int, EPI_K_MULAUX>{});
+      if (!x_fmt && !bwd && d.bias && (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & FFVC_F_COLSUM)) {
+        const int r = d.act == FFVC_ACT_GELU ? go(I0{}, std::integral_constant<int, EPI_K_GELU_FWDG>{})
+                                             : go(I0{}, std::integral_constant<int, EPI_K_QGELU_FWDG>{});
+        return r == 0 ? 2 : r;
+      }
+    }
   }
-  if (x_fmt == 1)
-    hipLaunchKernelGGL((gemm_f8_kernel<L, BM, BN, 1>), dim3(n_tiles), dim3(nthreads), lds, st, d, tiles_n, n_tiles, vec_ok, s0, s1);
-  else
-    hipLaunchKernelGGL((gemm_f8_kernel<L, BM, BN, 0>), dim3(n_tiles), dim3(nthreads), lds, st, d, tiles_n, n_tiles, vec_ok, s0, s1);
-  FFVC_LAUNCH_CHECK();
-  return 0;
+  return x_fmt ? go(I1{}, std::integral_constant<int, EPI_ALL>{}) : go(I0{}, std::integral_constant<int, EPI_ALL>{});
 }
 
 template <typename L>
@@ -251,7 +281,7 @@ extern "C" int ffvc_gemm_fp8(const ffvc_gemm_desc* dp, int x_fmt, int lo_dtype, 
   FFVC_CHECK_ARG((d.K % 16) == 0 && (d.ldx % 16) == 0 && (d.ldw % 16) == 0 && ((uintptr_t)d.x % 16) == 0 &&
                      ((uintptr_t)d.w % 16) == 0,
                  "ffvc_gemm_fp8: K / ldx / ldw must be multiples of 16 and the operands 16-byte aligned (K=%d)", d.K);
-  FFVC_CHECK_ARG(!(d.flags & (FFVC_F_GN_SUMS | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_TR_SAFE | FFVC_F_AUX_ACTGRAD)),
+  FFVC_CHECK_ARG(!(d.flags & (FFVC_F_GN_SUMS | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_TR_SAFE)),
                  "ffvc_gemm_fp8: unsupported flags 0x%x", d.flags);
   FFVC_CHECK_ARG((256 * (d.ldx / 2) + d.K / 2) * 2 < 0x7FFFFF00ll && (256 * (d.ldw / 2) + d.K / 2) * 2 < 0x7FFFFF00ll,
                  "ffvc_gemm_fp8: operand rows too long for 32-bit DMA offsets");
@@ -289,8 +319,17 @@ extern "C" int ffvc_gemm_fp8(const ffvc_gemm_desc* dp, int x_fmt, int lo_dtype, 
     cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (lo_dtype == FFVC_F16) return launch_f8_cfg<f16_t>(d, x_fmt, vec_ok, scale0, scale1, st, cfg);
-  return launch_f8_cfg<uint16_t>(d, x_fmt, vec_ok, scale0, scale1, st, cfg);
+  if (d.flags & FFVC_F_AUX_ACTGRAD)
+    FFVC_CHECK_ARG(d.aux && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU),
+                   "ffvc_gemm_fp8: FFVC_F_AUX_ACTGRAD needs aux and GELU / QuickGELU");
+  const int rc = lo_dtype == FFVC_F16 ? launch_f8_cfg<f16_t>(d, x_fmt, vec_ok, scale0, scale1, st, cfg)
+                                      : launch_f8_cfg<uint16_t>(d, x_fmt, vec_ok, scale0, scale1, st, cfg);
+  if (rc == 2) return 0;
+  if (rc) return rc;
+  // FFVC_F_AUX_ACTGRAD forward on a kernel without the specialised epilogue: aux holds the pre-activation -> convert it
+  if ((d.flags & FFVC_F_AUX_ACTGRAD) && (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & FFVC_F_MUL_ACT_GRAD))
+    return ffvc_actgrad_inplace(d.aux, lo_dtype, d.act, d.M, d.N, d.ldaux, stream);
+  return 0;
 }
 
 extern "C" int ffvc_fp8_quant(const void* src, int src_dtype, void* dst, int fmt, float* state, int64_t n, void* stream) {

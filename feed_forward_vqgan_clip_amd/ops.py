@@ -282,14 +282,14 @@ class _MLPFn(Function):
         h = torch.empty_like(h_pre)
         ctx.fp8 = (W1.fp8 is not None and W2.fp8 is not None and not drop and x.dtype in K.LOWP)
         # 16-bit modes keep act'(pre) instead of pre (`h_pre` then IS the derivative): the forward forms it from the erf / exp it
-        # evaluates anyway and the backward epilogue becomes a plain multiply (FFVC_F_AUX_ACTGRAD; fp32 parity mode and the fp8
-        # path keep the textbook form)
-        ctx.ag = K.F_AUX_ACTGRAD if (cdt in K.LOWP and _ACTGRAD and not ctx.fp8 and act in (ACT_GELU, ACT_QUICKGELU)) else 0
+        # evaluates anyway and the backward epilogue becomes a plain multiply (FFVC_F_AUX_ACTGRAD; the fp32 parity mode keeps
+        # the textbook form)
+        ctx.ag = K.F_AUX_ACTGRAD if (cdt in K.LOWP and _ACTGRAD and act in (ACT_GELU, ACT_QUICKGELU)) else 0
         if ctx.fp8:
             f1 = W1.fp8
             x8 = K.fp8_quant(x, f1["x"])
             K.gemm_fp8(x8, f1["sh"], h, rows, W1.N, W1.K, f1["x"], f1["w"], lo_dtype=cdt, bias=W1.bias, act=act, aux=h_pre,
-                       ldaux=W1.N, flags=K.F_WRITE_PREACT)
+                       ldaux=W1.N, flags=K.F_WRITE_PREACT | ctx.ag)
             K.fp8_next_scale(f1["x"])
         else:
             K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
@@ -331,7 +331,7 @@ class _MLPFn(Function):
             f1, f2 = W1.fp8, W2.fp8
             dy8 = K.fp8_quant(dyt, f2["g"])
             K.gemm_fp8(dy8, f2["sht"], dh, rows, W2.K, W2.N, f2["g"], f2["w"], lo_dtype=cdt, aux=h_pre, ldaux=W2.K,
-                       act=ctx.act, flags=K.F_MUL_ACT_GRAD)
+                       act=ctx.act, flags=K.F_MUL_ACT_GRAD | ctx.ag)
             K.fp8_next_scale(f2["g"])
             dx = None
             if ctx.needs_input_grad[0]:

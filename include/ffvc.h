@@ -138,6 +138,9 @@ typedef struct ffvc_gemm_desc {
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
+/* aux[m, n] <- act'(aux[m, n]) in place, 16-bit storage (the conversion pass behind FFVC_F_AUX_ACTGRAD on kernels without
+ * the specialised epilogue). */
+int ffvc_actgrad_inplace(void* aux, int dtype, int act, int M, int N, int64_t ld, void* stream);
 
 /* OCP fp8 GEMM for the frozen towers (BASELINE.json configs[4], "fp8 MFMA path"): x and w hold fp8 bytes (w: e4m3fn;
  * x: e4m3fn for x_fmt 0, e5m2 for x_fmt 1 = gradients), K-major both, fp32 accumulation on
