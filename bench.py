@@ -431,7 +431,14 @@ def main():
         out["parity_full_size"] = full_size_parity(args, sds, ref)
         out["parity_full_size"]["loss_oracle_fp32_batch1"] = ref["loss"]
     if rank == 0:
-        print(json.dumps(out))
+        # libraries that write to C stdio (RCCL's NCCL_DEBUG=VERSION banner) flush at exit, i.e. AFTER Python's own buffer:
+        # push their text out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if hvd.is_distributed():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
