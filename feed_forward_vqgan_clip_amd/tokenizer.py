@@ -7,16 +7,57 @@ position to EOT.  Output is int64 because main.py:733 only treats `torch.long` i
 
 No vocabulary ships with this repo (no network): pass `bpe_path` or set `FFVC_BPE_VOCAB` to CLIP's
 `bpe_simple_vocab_16e6.txt.gz` (plain `.txt` also accepted).  Without it `tokenize` raises.
+
+Pre-token pattern: CLIP's own, with the unicode classes `\\p{L}` (letters) and `\\p{N}` (numbers) through the `regex` module,
+so accented / Cyrillic / CJK text splits exactly as upstream (ids are integer work: bit-exact or wrong).
+Cleaning: upstream runs `ftfy.fix_text` first.  `ftfy` is used when it is importable; otherwise `_fix_text_basic` applies the
+deterministic, text-local part of ftfy's default configuration (NFC normalisation, curly quotes -> straight, Latin ligatures,
+full-width -> half-width characters, line-break and control-character clean-up, C1 controls -> their Windows-1252 characters).
+NOT reproduced without ftfy: its heuristic mojibake repair (`fix_encoding`, e.g. "Ã©" -> "é") and lossy-sequence
+restoration — prompts that contain encoding damage tokenise as written.
 """
 import gzip
 import html
 import os
 import re
+import unicodedata
 from functools import lru_cache
 
+import regex
 import torch
 
-_PAT = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\sa-zA-Z0-9]+", re.IGNORECASE)
+try:                                   # not in the offline image; used when present so the ids match upstream on damaged text too
+    import ftfy as _ftfy
+except ImportError:                    # pragma: no cover - depends on the environment
+    _ftfy = None
+
+_PAT = regex.compile(r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""",
+                     regex.IGNORECASE)
+
+_QUOTES = {0x2018: "'", 0x2019: "'", 0x201a: "'", 0x201b: "'", 0x02bc: "'", 0x201c: '"', 0x201d: '"', 0x201e: '"', 0x201f: '"'}
+_LIGATURES = {0x0132: "IJ", 0x0133: "ij", 0x0149: "\u02bcn", 0x01f1: "DZ", 0x01f2: "Dz", 0x01f3: "dz", 0x01c4: "D\u017d",
+              0x01c5: "D\u017e", 0x01c6: "d\u017e", 0x01c7: "LJ", 0x01c8: "Lj", 0x01c9: "lj", 0x01ca: "NJ", 0x01cb: "Nj",
+              0x01cc: "nj", 0xfb00: "ff", 0xfb01: "fi", 0xfb02: "fl", 0xfb03: "ffi", 0xfb04: "ffl", 0xfb05: "\u017ft",
+              0xfb06: "st"}
+_WIDTH = {0x3000: " "}
+_WIDTH.update({c: chr(c - 0xfee0) for c in range(0xff01, 0xff5f)})          # full-width ASCII block -> ASCII
+_CONTROL = {c: None for c in list(range(0x00, 0x09)) + [0x0b] + list(range(0x0e, 0x20)) + [0x7f, 0xfeff] +
+            list(range(0x206a, 0x2070)) + list(range(0xfff9, 0xfffd))}
+_C1 = {c: bytes([c]).decode("cp1252", errors="ignore") or None for c in range(0x80, 0xa0)}
+_TABLE = {**_CONTROL, **_WIDTH, **_LIGATURES, **_QUOTES}
+
+
+def _fix_text_basic(text):
+    """The deterministic subset of ftfy.fix_text's default configuration (see the module docstring)."""
+    text = text.replace("\r\n", "\n").replace("\r", "\n").replace("\u2028", "\n").replace("\u2029", "\n").replace("\u0085", "\n")
+    text = text.translate(_C1).translate(_TABLE)     # C1 controls first: \x93 -> a curly quote -> straight
+    return unicodedata.normalize("NFC", text)
+
+
+def basic_clean(text):
+    """clip.simple_tokenizer.basic_clean: ftfy.fix_text, two html.unescape passes, strip."""
+    text = _ftfy.fix_text(text) if _ftfy is not None else _fix_text_basic(text)
+    return html.unescape(html.unescape(text)).strip()
 
 
 @lru_cache()
@@ -82,7 +123,7 @@ class SimpleTokenizer:
         return res
 
     def encode(self, text):
-        text = re.sub(r"\s+", " ", html.unescape(html.unescape(text)).strip()).strip().lower()
+        text = re.sub(r"\s+", " ", basic_clean(text)).strip().lower()
         ids = []
         for tok in _PAT.findall(text):
             tok = "".join(self.byte_encoder[b] for b in tok.encode("utf-8"))

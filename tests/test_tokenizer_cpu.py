@@ -63,3 +63,32 @@ def test_load_dataset_tokenises_text_files(tk, tmp_path, monkeypatch):
     out = tmp_path / "tok.pkl"
     fmain.tokenize(str(p), out=str(out), bpe_path=str(vocab))
     assert torch.equal(fmain.load_dataset(str(out)), toks)
+
+
+def test_unicode_letters_and_numbers_follow_clip_pattern(tk):
+    """clip.simple_tokenizer's pre-token pattern uses \p{L} / \p{N}: an accented or non-Latin word is ONE pre-token (its
+    UTF-8 bytes then go through the byte alphabet and BPE), every unicode digit is its own pre-token."""
+    text = "café naïve 東京2024 привет's ½ x²"
+    assert T._PAT.findall(text) == ["café", "naïve", "東京", "2", "0", "2", "4",
+                                    "привет", "'s", "½", "x", "²"]
+    be = tk.byte_encoder
+    e_acute = [be[b] for b in "é".encode("utf-8")]                    # two byte symbols
+    ids = tk.encode("Café")
+    # one word: 'c a' merges (rank 0), then f and the two bytes of e-acute, the LAST carrying the end-of-word marker
+    assert ids == [tk.encoder["ca"], tk.encoder["f"], tk.encoder[e_acute[0]], tk.encoder[e_acute[1] + "</w>"]]
+    # the ASCII-only pattern of round 2 split it into 'caf' + the accent (f would have carried the marker)
+    assert tk.encoder["f</w>"] not in ids
+    assert tk.decode(ids).strip() == "café"
+    # CJK and Cyrillic round-trip through the byte alphabet
+    for t in ("東京", "привет мир", "x² + ½"):
+        assert tk.decode(tk.encode(t)).replace(" ", "") == t.replace(" ", "")
+
+
+def test_basic_clean_subset_of_ftfy():
+    """Without ftfy the deterministic part of its default configuration is applied (documented gap: mojibake repair)."""
+    if T._ftfy is not None:
+        pytest.skip("ftfy present: upstream's own cleaner is used")
+    assert T.basic_clean("  “Quoted” ‘x’ ﬁne ＡＢＣ　ok\x07 &amp;amp; ") == "\"Quoted\" 'x' fine ABC ok &"
+    assert T.basic_clean("a\r\nb c") == "a\nb\nc"
+    assert T.basic_clean("é") == "é"                       # NFC
+    assert T.basic_clean("\x93x\x94") == "\"x\""                      # C1 controls -> cp1252 curly quotes -> straight
