@@ -5,8 +5,10 @@ reference's main.py (`train`, `build_model`, `load_model`, `load_dataset`, `load
 
     python -m feed_forward_vqgan_clip_amd.main train configs/example.yaml
 
-Only the `train` path is built; `test`, `evaluate`, `tokenize`,
-`encode_text_and_images*`, `train_prior` are out of scope for this round.
+Built: `train`, `test` / `load_model` / the PIL image grids (inference and checkpoint compatibility, incl. legacy
+pickled-module `model.th` files and pytorch-lightning VQGAN checkpoints through checkpoint_io), `tokenize`, `encode_text`,
+`encode_text_and_images` (feature cache) and the Net2Net prior's `load_prior_model` / sampling.  Not built (SURVEY.md §2 "—"):
+`evaluate`, `encode_text_and_images_webdataset`, `train_prior`.
 No weights / BPE vocabulary ship with this repo: `vqgan_checkpoint: "random:<seed>"`,
 `clip_model_path: "random:<seed>"` and `path: "synthetic:<n>"` select seeded synthetic
 weights / token batches.
@@ -355,13 +357,24 @@ def build_model(config, vq_channels=None):
 
 
 def load_model(path, cdt=torch.bfloat16, vq_channels=256):
-    """main.py:1273-1290 for dict checkpoints {"state_dict","config","step","epoch"}."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    if not isinstance(ckpt, dict):
-        raise NotImplementedError("legacy pickled-module checkpoints (model.th) are not supported")
-    config = Config(ckpt["config"])
+    """main.py:1273-1290: dict checkpoints {"state_dict","config","step","epoch"} and the legacy form, a pickled module
+    instance (`model.th`).  The legacy object graph is read with stand-in classes (checkpoint_io), its parameters are
+    flattened into a state_dict and loaded into a freshly built mapper, so neither the reference's classes nor its
+    `_fix_*_gelu_issue` patches are needed."""
+    from . import checkpoint_io
+
+    ckpt = checkpoint_io.tolerant_load(path)
+    if isinstance(ckpt, dict):
+        config, sd = Config(checkpoint_io.plain_config(ckpt["config"])), ckpt["state_dict"]
+    elif checkpoint_io.is_module_like(ckpt):
+        config = Config(checkpoint_io.plain_config(getattr(ckpt, "config", None) or {}))
+        if "model_type" not in config:
+            raise ValueError(f"{path}: pickled module without a usable `config` attribute")
+        sd = checkpoint_io.module_state_dict(ckpt)
+    else:
+        raise ValueError(f"{path}: neither a checkpoint dict nor a pickled module")
     net = build_model(config, vq_channels)
-    net.load_state_dict(ckpt["state_dict"])
+    net.load_state_dict(sd)
     net.config = config
     return net.cuda().prepare(cdt)
 

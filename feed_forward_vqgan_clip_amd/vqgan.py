@@ -195,16 +195,26 @@ def synth(model, z):
 
 
 def load_vqgan_model(config_path, checkpoint_path, cdt=torch.bfloat16):
-    """main.py:84-103 for `taming.models.vqgan.VQModel` configs (yaml read with PyYAML, lightning ckpt
-    `state_dict` entry, strict=False semantics: only decoder / post_quant / codebook keys are used)."""
+    """main.py:84-103: yaml read with PyYAML; the three targets the reference accepts —
+      taming.models.vqgan.VQModel                        decoder / post_quant_conv / quantize.embedding
+      taming.models.vqgan.GumbelVQ                       same decoder; the codebook is `quantize.embed` (main.py:95 aliases it)
+      taming.models.cond_transformer.Net2NetTransformer  its `first_stage_model` (a VQModel) is the model (main.py:96-100)
+    The checkpoint is a pytorch-lightning file: read through `checkpoint_io.tolerant_load` (lightning / omegaconf / taming are
+    not installed), `state_dict` entry, strict=False semantics: only decoder / post_quant / codebook keys are used."""
     import yaml
+
+    from . import checkpoint_io
 
     with open(config_path) as f:
         conf = yaml.safe_load(f)
     target = conf["model"]["target"]
-    if target != "taming.models.vqgan.VQModel":
-        raise ValueError(f"unknown model type: {target}")
     params = conf["model"]["params"]
+    prefix = ""
+    if target == "taming.models.cond_transformer.Net2NetTransformer":
+        params = params["first_stage_config"]["params"]
+        prefix = "first_stage_model."
+    elif target not in ("taming.models.vqgan.VQModel", "taming.models.vqgan.GumbelVQ"):
+        raise ValueError(f"unknown model type: {target}")
     dd = params["ddconfig"]
     cfg = dict(ch=dd["ch"], ch_mult=tuple(dd["ch_mult"]), num_res_blocks=dd["num_res_blocks"],
                attn_resolutions=tuple(dd["attn_resolutions"]), resolution=dd["resolution"], z_channels=dd["z_channels"],
@@ -212,5 +222,11 @@ def load_vqgan_model(config_path, checkpoint_path, cdt=torch.bfloat16):
     if str(checkpoint_path).startswith("random:"):
         sd = random_state_dict(cfg, seed=int(str(checkpoint_path).split(":", 1)[1]))
     else:
-        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=False)["state_dict"]
+        ckpt = checkpoint_io.tolerant_load(checkpoint_path)
+        sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        if "quantize.embedding.weight" not in sd and "quantize.embed.weight" in sd:      # GumbelVQ
+            sd = dict(sd)
+            sd["quantize.embedding.weight"] = sd["quantize.embed.weight"]
     return VQGAN(sd, cfg, cdt)

@@ -1,0 +1,83 @@
+"""checkpoint_io: reading pytorch-lightning VQGAN checkpoints and legacy pickled-module mapper checkpoints without the packages /
+classes that wrote them (reference main.py:84-103, 568-575, 1273-1290)."""
+import collections
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+from feed_forward_vqgan_clip_amd import checkpoint_io as C
+
+WRITER = textwrap.dedent('''
+    import sys, types, collections, torch
+    from torch import nn
+    out = sys.argv[1]
+    # --- a "pytorch_lightning"-like package and an "omegaconf"-like container that exist ONLY in this writer process
+    pl = types.ModuleType("pytorch_lightning_fake"); cb = types.ModuleType("pytorch_lightning_fake.callbacks")
+    sys.modules["pytorch_lightning_fake"] = pl; sys.modules["pytorch_lightning_fake.callbacks"] = cb
+    class ModelCheckpoint:
+        def __init__(self): self.best = 0.25; self.monitor = "val/loss"
+    ModelCheckpoint.__module__ = "pytorch_lightning_fake.callbacks"; cb.ModelCheckpoint = ModelCheckpoint
+    class AttrDict(dict): pass
+    AttrDict.__module__ = "pytorch_lightning_fake"; pl.AttrDict = AttrDict
+    g = torch.Generator().manual_seed(0)
+    sd = collections.OrderedDict(("decoder.w%d" % i, torch.randn(3, 4, generator=g)) for i in range(3))
+    torch.save({"state_dict": sd, "callbacks": {ModelCheckpoint: ModelCheckpoint()}, "hyper_parameters": AttrDict(lr=1e-3),
+                "epoch": 7}, out + "/lightning.ckpt")
+    # --- a legacy whole-module pickle of classes defined in a module that will not exist for the reader
+    ref = types.ModuleType("reference_fake_models"); sys.modules["reference_fake_models"] = ref
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__(); self.fc = nn.Linear(4, 4); self.act = nn.GELU(); self.register_buffer("scale", torch.ones(1))
+            self.register_buffer("tmp", torch.zeros(2), persistent=False)
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__(); self.inp = nn.Linear(3, 4); self.blocks = nn.ModuleList([Block(), Block()]); self.config = AttrDict(model_type="mlp_mixer", dim=4)
+    for c in (Block, Net): c.__module__ = "reference_fake_models"; setattr(ref, c.__name__, c)
+    torch.manual_seed(1); net = Net()
+    torch.save(net, out + "/model.th"); torch.save(net.state_dict(), out + "/expected_sd.th")
+''')
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ckpt")
+    subprocess.run([sys.executable, "-c", WRITER, str(d)], check=True)
+    return d
+
+
+def test_plain_torch_load_fails_and_tolerant_load_survives(files):
+    with pytest.raises(Exception):
+        torch.load(files / "lightning.ckpt", map_location="cpu", weights_only=False)
+    ckpt, stubbed = C.tolerant_load(files / "lightning.ckpt", return_stubbed=True)
+    assert "pytorch_lightning_fake.callbacks.ModelCheckpoint" in stubbed
+    assert ckpt["epoch"] == 7 and list(ckpt["state_dict"]) == ["decoder.w0", "decoder.w1", "decoder.w2"]
+    g = torch.Generator().manual_seed(0)
+    for i in range(3):
+        assert torch.equal(ckpt["state_dict"]["decoder.w%d" % i], torch.randn(3, 4, generator=g))
+    # state of the stand-ins is kept, behaviour is not
+    (cb,) = ckpt["callbacks"].values()
+    assert cb.best == 0.25 and cb.monitor == "val/loss"
+
+
+def test_legacy_pickled_module_flattens_to_its_state_dict(files):
+    with pytest.raises(Exception):
+        torch.load(files / "model.th", map_location="cpu", weights_only=False)
+    net = C.tolerant_load(files / "model.th")
+    assert C.is_module_like(net)
+    sd = C.module_state_dict(net)
+    want = torch.load(files / "expected_sd.th", map_location="cpu")
+    assert list(sd) == list(want)                      # same names, same order, non-persistent buffer left out
+    for k in want:
+        assert torch.equal(sd[k], want[k])
+    assert C.plain_config(net.config) == {"model_type": "mlp_mixer", "dim": 4}
+
+
+def test_module_state_dict_matches_torch_on_a_real_module():
+    m = torch.nn.Sequential(collections.OrderedDict(a=torch.nn.Linear(2, 3), b=torch.nn.BatchNorm1d(3)))
+    sd = C.module_state_dict(m)
+    assert list(sd) == list(m.state_dict())
+    for k, v in m.state_dict().items():
+        assert torch.equal(sd[k], v)

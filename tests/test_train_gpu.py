@@ -19,6 +19,7 @@ from feed_forward_vqgan_clip_amd import vqgan as fvq  # noqa: E402
 from feed_forward_vqgan_clip_amd.optim import CosineAnnealingLR, FusedAdam  # noqa: E402
 
 F32 = torch.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TINY_VQ = dict(ch=64, ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64, out_ch=3,
                embed_dim=64, n_embed=128)
 TINY_CLIP = dict(embed_dim=32, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8,
@@ -394,3 +395,97 @@ def test_mapper_dropout_train_eval_and_gradient(cuda, kind):
     an = (xg.grad * v).sum().item()
     assert abs(fd - an) / (abs(fd) + 1e-6) < 2e-2, (fd, an)
     assert all(torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in net.parameters())
+
+
+# ----------------------------------------------------------------------------- checkpoint compatibility (checkpoint_io)
+_LEGACY_WRITER = '''
+import sys, types, torch
+sys.path.insert(0, sys.argv[2])
+out = sys.argv[1]
+# a pytorch-lightning-like VQGAN checkpoint: state_dict next to objects of a package the reader does not have
+pl = types.ModuleType("pl_fake"); sys.modules["pl_fake"] = pl
+class Callback:
+    def __init__(self): self.best = 1.0
+Callback.__module__ = "pl_fake"; pl.Callback = Callback
+from feed_forward_vqgan_clip_amd import vqgan as fvq
+cfg = dict(ch=64, ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64, out_ch=3, embed_dim=64, n_embed=128)
+sd = fvq.random_state_dict(cfg, 5)
+torch.save({"state_dict": sd, "callbacks": [Callback()]}, out + "/vq.ckpt")
+gsd = {("quantize.embed.weight" if k == "quantize.embedding.weight" else k): v for k, v in sd.items()}
+torch.save({"state_dict": gsd, "callbacks": [Callback()]}, out + "/gumbel.ckpt")
+torch.save({"state_dict": {"first_stage_model." + k: v for k, v in sd.items()}, "callbacks": [Callback()]}, out + "/n2n.ckpt")
+'''
+
+
+def _vq_yaml(path, target, nested=False):
+    import yaml
+    params = dict(embed_dim=64, n_embed=128, ddconfig=dict(ch=64, ch_mult=[1, 1, 2], num_res_blocks=1, attn_resolutions=[8],
+                                                            resolution=32, z_channels=64, out_ch=3))
+    if nested:
+        params = dict(first_stage_config=dict(target="taming.models.vqgan.VQModel", params=params))
+    with open(path, "w") as f:
+        yaml.safe_dump(dict(model=dict(target=target, params=params)), f)
+    return str(path)
+
+
+def test_load_vqgan_model_reads_lightning_gumbel_and_net2net_checkpoints(cuda, tmp_path):
+    """reference main.py:84-103: the three targets, from pytorch-lightning files whose extra objects cannot be unpickled here."""
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, "-c", _LEGACY_WRITER, str(tmp_path), ROOT], check=True)
+    with pytest.raises(Exception):
+        torch.load(tmp_path / "vq.ckpt", map_location="cpu", weights_only=False)
+    ref = fvq.VQGAN(fvq.random_state_dict(TINY_VQ, 5), TINY_VQ, F32)
+    z = torch.randn(2, 2, 2, 64, device="cuda")
+    want, widx = fvq.synth_nhwc(ref, z)
+    for ck, target, nested in (("vq.ckpt", "taming.models.vqgan.VQModel", False), ("gumbel.ckpt", "taming.models.vqgan.GumbelVQ", False),
+                               ("n2n.ckpt", "taming.models.cond_transformer.Net2NetTransformer", True)):
+        m = fvq.load_vqgan_model(_vq_yaml(tmp_path / "c.yaml", target, nested), str(tmp_path / ck), F32)
+        got, gidx = fvq.synth_nhwc(m, z)
+        assert torch.equal(gidx, widx) and torch.equal(got, want), target
+    with pytest.raises(ValueError):
+        fvq.load_vqgan_model(_vq_yaml(tmp_path / "c.yaml", "taming.models.other.Thing"), "random:1", F32)
+
+
+def test_load_model_reads_a_legacy_pickled_module(cuda, tmp_path):
+    """reference main.py:568-575, 1281-1289: `model.th` is a pickled module instance of classes this package does not have."""
+    import subprocess
+    import sys
+    cfg = fmain.Config(noise_dim=0, dim=64, depth=2, dropout=0, clip_model="ViT-B/32", clip_dim=32, model_type="mlp_mixer",
+                       vq_image_size=12)
+    torch.manual_seed(3)
+    net = fmain.build_model(cfg, 64)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    torch.save(sd, tmp_path / "sd.th")
+    writer = '''
+import sys, types, torch
+from torch import nn
+sd = torch.load(sys.argv[1] + "/sd.th")
+ref = types.ModuleType("mlp_mixer_pytorch_fake"); sys.modules["mlp_mixer_pytorch_fake"] = ref
+class Holder(nn.Module):
+    pass
+Holder.__module__ = "mlp_mixer_pytorch_fake"; ref.Holder = Holder
+class Cfg(dict):
+    pass
+Cfg.__module__ = "mlp_mixer_pytorch_fake"; ref.Cfg = Cfg
+def build(prefix_tree):
+    m = Holder()
+    for name, sub in prefix_tree.items():
+        if isinstance(sub, dict): m.add_module(name, build(sub))
+        else: m.register_parameter(name, nn.Parameter(sub))
+    return m
+tree = {}
+for k, v in sd.items():
+    d = tree
+    parts = k.split(".")
+    for p in parts[:-1]: d = d.setdefault(p, {})
+    d[parts[-1]] = v
+root = build(tree)
+root.config = Cfg(noise_dim=0, dim=64, depth=2, dropout=0, clip_model="ViT-B/32", clip_dim=32, model_type="mlp_mixer", vq_image_size=12)
+torch.save(root, sys.argv[1] + "/model.th")
+'''
+    subprocess.run([sys.executable, "-c", writer, str(tmp_path)], check=True)
+    got = fmain.load_model(str(tmp_path / "model.th"), F32, vq_channels=64)
+    assert got.config.model_type == "mlp_mixer" and got.config.depth == 2
+    for k, v in sd.items():
+        assert torch.equal(got.state_dict()[k].cpu(), v), k
