@@ -120,6 +120,7 @@ _SIGNATURES = {
                                  c_void_p]),
     "ffvc_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "ffvc_split3": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
     "ffvc_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
     "ffvc_copy2d": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
     "ffvc_sln_fwd": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
@@ -146,7 +147,8 @@ _SIGNATURES = {
     "ffvc_spherical_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                     c_void_p]),
     "ffvc_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float,
-                          c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+                          c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "ffvc_clock_sample": (c_int, [c_void_p, c_void_p]),
     "ffvc_clip_coef": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "ffvc_dropout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_float, ctypes.c_uint32, c_void_p]),
     "ffvc_mean_sq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -6,9 +6,11 @@ clip.model.CLIP, whose math is restated in the reference at cloob.py:170-255,412
 
 Precision plan: the image tower runs in the compute dtype (bf16 MFMA, fp32
 accumulate, fp32 LayerNorm / softmax statistics, fp32 residual stream); the text tower (0.5 % of
-the step's FLOPs, no backward) always runs on the exact fp32 MFMA path.
+the step's FLOPs, no backward) is evaluated at fp32 grade: on the exact fp32 MFMA in parity mode, as split-precision
+f16 GEMMs (`_SplitLinear`) otherwise.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -95,6 +97,49 @@ class _Block:
         return ops.mlp(xn, self.c_fc, self.c_proj, self.act, residual=xid, out_dtype=f32)
 
 
+class _SplitLinear:
+    """Frozen fp32 Linear evaluated on the 16-bit matrix pipes at fp32 grade (ffvc_split3): the weight is stored once as
+    f16 [N, 3K] = [hi | hi | lo], the activation is split per call into [hi | lo | hi]; one f16 GEMM of depth 3K with fp32
+    accumulation then sums x_hi w_hi + x_lo w_hi + x_hi w_lo — every product but lo x lo (~2^-22 relative).  Bias, activation
+    and the fp32 residual ride in the GEMM epilogue.  ~5x the speed of the exact fp32 MFMA (1/16 of the 16-bit rate)."""
+
+    def __init__(self, weight, bias):
+        w = weight.detach().reshape(weight.shape[0], -1).float().cuda().contiguous()
+        self.N, self.K = w.shape
+        self.w3 = K.split3(w, torch.float16, weight_order=True)
+        self.bias = None if bias is None else bias.detach().float().cuda().contiguous()
+
+    def __call__(self, x, act=K.ACT_NONE, residual=None):
+        rows = x.numel() // self.K
+        x3 = K.split3(x.reshape(rows, self.K))
+        y = torch.empty(*x.shape[:-1], self.N, dtype=torch.float32, device=x.device)
+        K.gemm(x3, self.w3, y, rows, self.N, 3 * self.K, ldx=3 * self.K, ldw=3 * self.K, bias=self.bias, residual=residual,
+               act=act)
+        return y
+
+
+class _TextBlock:
+    """ResidualAttentionBlock of the (frozen, forward-only) text tower, cloob.py:202-205, with the four Linear layers as
+    split-precision GEMMs; LayerNorm, the causal attention (77 tokens) and the residual stream stay fp32."""
+
+    def __init__(self, sd, p, act):
+        self.act = act
+        self.ln1 = (_f(sd[p + ".ln_1.weight"]), _f(sd[p + ".ln_1.bias"]))
+        self.ln2 = (_f(sd[p + ".ln_2.weight"]), _f(sd[p + ".ln_2.bias"]))
+        self.in_proj = _SplitLinear(sd[p + ".attn.in_proj_weight"], sd[p + ".attn.in_proj_bias"])
+        self.out_proj = _SplitLinear(sd[p + ".attn.out_proj.weight"], sd[p + ".attn.out_proj.bias"])
+        self.c_fc = _SplitLinear(sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"])
+        self.c_proj = _SplitLinear(sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
+
+    def __call__(self, x, heads):
+        f32 = torch.float32
+        dh = x.shape[-1] // heads
+        o = ops.attention(self.in_proj(ops.layernorm(x, *self.ln1, f32)), heads, dh ** -0.5, True)
+        x = self.out_proj(o, residual=x)
+        h = self.c_fc(ops.layernorm(x, *self.ln2, f32), act=self.act)
+        return self.c_proj(h, residual=x)
+
+
 class _TakeToken(torch.autograd.Function):
     """x[:, idx, :] of a contiguous fp32 (N, L, D) tensor (class token, cloob.py:251)."""
 
@@ -115,13 +160,18 @@ class _TakeToken(torch.autograd.Function):
 
 
 class CLIP:
-    def __init__(self, state_dict, cdt=torch.bfloat16, vision_heads=None, text_heads=None, quick_gelu=True, fp8=False):
+    def __init__(self, state_dict, cdt=torch.float16, vision_heads=None, text_heads=None, quick_gelu=True, fp8=False,
+                 text_exact=None):
         """quick_gelu: OpenAI checkpoints and open_clip's `-quickgelu` architectures use x*sigmoid(1.702x) in the MLPs
         (cloob.py:179-181); the other open_clip architectures (ViT-B-32 / ViT-L-14 on LAION-2B, main.py:1323-1329) use
         the exact erf GELU.
         fp8: the four Linear layers of every image-tower block (in_proj, out_proj, c_fc, c_proj; forward and dgrad) run on
         the fp8 MFMA path (BASELINE.json configs[4]): e4m3 weights / activations, e5m2 gradients, per-tensor delayed
-        scaling, fp32 accumulation; LayerNorm, softmax, residual stream, patch embedding and projection keep `cdt` / fp32."""
+        scaling, fp32 accumulation; LayerNorm, softmax, residual stream, patch embedding and projection keep `cdt` / fp32.
+        text_exact: True = the text tower's Linear layers on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the 16-bit
+        rate; what round 2 shipped); False = split-precision f16 GEMMs (`_SplitLinear`, fp32-grade: features agree with the exact
+        path to ~1e-6 relative, 7.4 -> ~2 ms per step at cfg2).  Default: exact in fp32 parity mode, split otherwise
+        (FFVC_TEXT_EXACT=1 forces the exact path)."""
         if not torch.cuda.is_available():
             raise RuntimeError("CLIP needs a HIP device; there is no CPU fallback")
         sd, self.cdt = state_dict, cdt
@@ -152,10 +202,14 @@ class CLIP:
         self.context_length = self.tpos.shape[0]
         self.twidth = self.tpos.shape[1]
         self.text_heads = text_heads or self.twidth // 64
+        if text_exact is None:
+            text_exact = cdt == f32 or os.environ.get("FFVC_TEXT_EXACT", "0") == "1"
+        self.text_exact = bool(text_exact) or (self.twidth % 8 != 0)
         self.tblocks = []
         n = 0
         while f"transformer.resblocks.{n}.ln_1.weight" in sd:
-            self.tblocks.append(_Block(sd, f"transformer.resblocks.{n}", f32, False, act))
+            p = f"transformer.resblocks.{n}"
+            self.tblocks.append(_Block(sd, p, f32, False, act) if self.text_exact else _TextBlock(sd, p, act))
             n += 1
         self.ln_final = (_f(sd["ln_final.weight"]), _f(sd["ln_final.bias"]))
         self.tproj = ops.Weights.frozen(sd["text_projection"].t().contiguous(), None, f32, False)
@@ -193,8 +247,8 @@ class CLIP:
         text = text.cuda().contiguous()
         B, L = text.shape
         x = K.gather_rows(self.tok_emb, text, f32, pos=self.tpos, period=L)         # :526-528
-        for blk in self.tblocks:
-            x = blk(x, self.text_heads, f32, True)                                  # causal mask :510-516
+        for blk in self.tblocks:                                                    # causal mask :510-516
+            x = blk(x, self.text_heads, f32, True) if self.text_exact else blk(x, self.text_heads)
         xn = ops.layernorm(x, *self.ln_final, f32)                                  # :532
         eot = K.eot_gather(xn, text)                                                # :536
         return ops.linear(eot, self.tproj, out_dtype=f32)

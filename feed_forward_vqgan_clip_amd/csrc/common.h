@@ -404,6 +404,20 @@ __device__ __forceinline__ void mma_lo<f16_t>(f32x16_t& acc, const u32x4_t& a, c
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 
+// One 16x16x32 MFMA (same FLOP rate; measured ~8 % less energy per FLOP than 32x32x16 under the power cap: the chip holds
+// ~1.9 GHz instead of ~1.7 GHz, profiles/r03_power_ceiling.txt).  A / B fragment: lane (r = lane & 15, k = 8 * (lane >> 4) .. + 7);
+// C: lane owns column (lane & 15) of the B side and rows 4 * (lane >> 4) .. + 3 of the A side.
+template <typename T>
+__device__ __forceinline__ void mma16_lo(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b);
+template <>
+__device__ __forceinline__ void mma16_lo<uint16_t>(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16_lo<f16_t>(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+
 // Run a statement with `T` bound to the storage type of a dtype code.
 #define DISPATCH_DT(code, T, ...)          \
   do {                                     \

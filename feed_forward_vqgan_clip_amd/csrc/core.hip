@@ -36,6 +36,21 @@ extern "C" int ffvc_device_info(int32_t* n_cu, int32_t* clock_khz, int64_t* hbm_
   return 0;
 }
 
+// out[0] = shader-clock counter (s_memtime, ticks at the CURRENT engine clock), out[1] = the constant 100 MHz counter
+// (s_memrealtime) of whichever CU runs the sample: two samples bracketing a region give its average effective clock,
+// (d out[0]) / (d out[1] * 10 ns) — the chip clocks to its power budget under MFMA load (profiles/r03_power_ceiling.txt).
+__global__ void clock_sample_kernel(unsigned long long* out) {
+  out[0] = __builtin_amdgcn_s_memtime();
+  out[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+extern "C" int ffvc_clock_sample(uint64_t* out, void* stream) {
+  FFVC_CHECK_ARG(out, "ffvc_clock_sample: null pointer");
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
 // Each lane supplies the address of 4 consecutive shorts (lane l -> lds[4l..4l+3], lds[i] = i);
 // the dump shows which source element lands in (lane, j).
 __global__ void probe_tr16_kernel(int16_t* out) {

@@ -26,6 +26,33 @@ __global__ __launch_bounds__(256) void cast_kernel(const ST* __restrict__ s, DT*
   }
 }
 
+// ---------------------- fp32 -> three 16-bit segments ----------------------
+// Split-precision operand of an fp32-grade GEMM on the 16-bit matrix pipes: x = hi + lo (+ ~2^-22 |x|) with hi = rn16(x),
+// lo = rn16(x - hi).  With the activation written as [hi | lo | hi] and the weight as [hi | hi | lo] along K, ONE 16-bit GEMM
+// of depth 3K accumulates x_hi w_hi + x_lo w_hi + x_hi w_lo in fp32: everything but the lo x lo term.  SEG selects the layout:
+// 0 = activation order [hi | lo | hi], 1 = weight order [hi | hi | lo].
+template <typename DT>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s, DT* __restrict__ d, int64_t rows, int K,
+                                                     int64_t lds, int seg) {
+  const int k4 = K >> 2;
+  const int64_t n4 = rows * k4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / k4;
+    const int c = (int)(i - r * k4) * 4;
+    const f32x4_t v = load4(s + r * lds + c);
+    f32x4_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = lo_round<DT>(v[j]);
+      lo[j] = v[j] - hi[j];
+    }
+    DT* o = d + r * (3 * (int64_t)K) + c;
+    store4(o, hi);
+    store4(o + K, seg ? hi : lo);
+    store4(o + 2 * (int64_t)K, seg ? lo : hi);
+  }
+}
+
 // ------------------------- batched 2-D transpose ---------------------------
 // dst[b][c][r] = src[b][r][c] with dtype conversion (weight shadows W^T, mixer rearrange).
 template <typename ST, typename DT>
@@ -421,18 +448,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, ST* __restrict__ shadow,
                                                    int64_t n, float lr, float b1, float b2, float eps, float bc1,
                                                    float bc2_sqrt, float gscale, float* __restrict__ ema, float ema_w,
-                                                   const float* __restrict__ dev_scale) {
+                                                   const float* __restrict__ dev_scale, unsigned int* __restrict__ bad_count) {
   if (dev_scale) gscale *= dev_scale[0];      // global-norm clip coefficient computed on the device (no host sync)
+  // Non-finite gradients (an overflowing f16 backward, or inf x the clip coefficient 0 = NaN) must never reach p / m / v / ema:
+  // such an element keeps its state (no update), and the launch counts the waves that saw one in bad_count, which the host
+  // reads at its next logging synchronisation to back the loss scale off (optim.FusedAdam.check_overflow).
+  bool bad = false;
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4_t pv = load4(p + i * 4), gv = load4(g + i * 4), mv = load4(m + i * 4), vv = load4(v + i * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gg = gv[j] * gscale;
-      mv[j] = b1 * mv[j] + (1.0f - b1) * gg;
-      vv[j] = b2 * vv[j] + (1.0f - b2) * gg * gg;
-      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
-      pv[j] -= (lr / bc1) * (mv[j] / denom);
+      const bool ok = fabsf(gg) <= 3.0e38f;      // false for inf and NaN
+      bad |= !ok;
+      const float m2 = b1 * mv[j] + (1.0f - b1) * gg;
+      const float v2 = b2 * vv[j] + (1.0f - b2) * gg * gg;
+      const float denom = sqrtf(v2) / bc2_sqrt + eps;
+      const float p2 = pv[j] - (lr / bc1) * (m2 / denom);
+      mv[j] = ok ? m2 : mv[j];
+      vv[j] = ok ? v2 : vv[j];
+      pv[j] = ok ? p2 : pv[j];
     }
     store4(p + i * 4, pv);
     store4(m + i * 4, mv);
@@ -447,15 +483,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
     const float gg = g[i] * gscale;
-    const float mm = b1 * m[i] + (1.0f - b1) * gg;
-    const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
-    const float pp = p[i] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    const bool ok = fabsf(gg) <= 3.0e38f;
+    bad |= !ok;
+    const float mm = ok ? b1 * m[i] + (1.0f - b1) * gg : m[i];
+    const float vv = ok ? b2 * v[i] + (1.0f - b2) * gg * gg : v[i];
+    const float pp = ok ? p[i] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps)) : p[i];
     m[i] = mm;
     v[i] = vv;
     p[i] = pp;
     if (shadow) ElemTraits<ST>::store(shadow + i, pp);
     if (ema) ema[i] -= ema_w * (ema[i] - pp);
   }
+  if (bad_count && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(bad_count, 1u);
 }
 
 // ---- dropout (mlp_mixer_pytorch.py:20-22, vitgan.py:34-41,105,114,133: nn.Dropout inside the mapper MLPs / after attention) ----
@@ -816,6 +855,22 @@ extern "C" int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtyp
   return 0;
 }
 
+extern "C" int ffvc_split3(const float* src, void* dst, int dst_dtype, int64_t rows, int K, int64_t ld_src, int weight_order,
+                           void* stream) {
+  FFVC_CHECK_ARG(src && dst && rows > 0 && K > 0 && (K % 4) == 0 && ld_src >= K && (ld_src % 4) == 0,
+                 "ffvc_split3: bad args (K and ld_src must be multiples of 4)");
+  FFVC_CHECK_ARG(dst_dtype == FFVC_F16 || dst_dtype == FFVC_BF16, "ffvc_split3: dst must be a 16-bit dtype");
+  FFVC_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "ffvc_split3: misaligned pointers");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n4 = rows * (K / 4);
+  if (dst_dtype == FFVC_F16)
+    hipLaunchKernelGGL((split3_kernel<f16_t>), dim3(ew_grid(n4, 256)), dim3(256), 0, st, src, (f16_t*)dst, rows, K, ld_src, weight_order);
+  else
+    hipLaunchKernelGGL((split3_kernel<uint16_t>), dim3(ew_grid(n4, 256)), dim3(256), 0, st, src, (uint16_t*)dst, rows, K, ld_src, weight_order);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ffvc_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int batch, int rows, int cols,
                               int64_t src_batch_stride, int64_t dst_batch_stride, int dst_ld, void* stream) {
   FFVC_CHECK_ARG(src && dst && batch > 0 && rows > 0 && cols > 0, "ffvc_transpose: bad args");
@@ -992,7 +1047,7 @@ extern "C" int ffvc_spherical_loss(const float* embed, const float* feats, float
 
 extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n,
                          float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* ema,
-                         float ema_weight, const float* dev_scale, void* stream) {
+                         float ema_weight, const float* dev_scale, uint32_t* nonfinite_count, void* stream) {
   FFVC_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "ffvc_adam: bad args");
   FFVC_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0 && ((uintptr_t)shadow % 16) == 0 && ((uintptr_t)ema % 16) == 0,
@@ -1003,13 +1058,13 @@ extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* sha
   const int grid = ew_grid(n / 4 + 1, 256);
   if (shadow && shadow_dtype == FFVC_BF16)
     hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (uint16_t*)shadow, n, lr, beta1,
-                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
+                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count);
   else if (shadow && shadow_dtype == FFVC_F16)
     hipLaunchKernelGGL((adam_kernel<f16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (f16_t*)shadow, n, lr, beta1,
-                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
+                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count);
   else
     hipLaunchKernelGGL((adam_kernel<float>), dim3(grid), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2,
-                       eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale);
+                       eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -63,19 +63,30 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
   else
     sw.init((const uint16_t*)p.w, p.ldw, n0, p.N, 0, 0, tid, 0, 0);
 
-  f32x16_t acc[2][MT];
+  constexpr bool M16 = FFVC_MFMA16_CONVROW;         // v_mfma_f32_16x16x32 (see gemm2_kernel)
+  f32x16_t acc[M16 ? 1 : 2][M16 ? 1 : MT];
+  f32x4_t acc16[M16 ? 4 : 1][M16 ? 2 * MT : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < MT; ++b)
+      for (int b = 0; b < 2 * MT; ++b) acc16[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  }
 
-  // LDS row of this lane's pixel for tap kw = 0 (add kw for the others)
+  // LDS row of this lane's pixel for tap kw = 0 (add kw for the others): 32-row blocks (32x32x16) or 16-row blocks (16x16x32)
+  // (16x16x32: the two 16-row halves of a 32-pixel block lie in the same image row (tile rows are 64 / 128 / 256 wide), so the
+  // second half is the first + 16)
   int xrow[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int px = wm * 128 + t * 32 + l31;
+    const int px = wm * 128 + t * 32 + (M16 ? (lane & 15) : l31);
     const int Wt = W < 256 ? W : 256;               // tile row width (a segment of the image row when W > 256)
     xrow[t] = (px / Wt) * (Wt + 2) + (px % Wt);
   }
@@ -90,26 +101,56 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
         sw.issue(sW, (kh * 3 + kw) * Cin + cb * 64, p.K, zero, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (M16) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-          u32x4_t fa[2], fb[MT];
+          for (int sub = 0; sub < 2; ++sub) {
+            u32x4_t fa[4];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) fa[t] = frag_kmajor(sW, wn * 64 + t * 32 + l31, sub, lane);
+            for (int t = 0; t < 4; ++t) fa[t] = frag16_kmajor(sW, wn * 64 + t * 16 + (lane & 15), sub, lane);
 #pragma unroll
-          for (int t = 0; t < MT; ++t) fb[t] = frag_kmajor(sX, xrow[t] + kw, sub, lane);
+            for (int bh = 0; bh < 2; ++bh) {          // X fragments in two halves of 4 blocks: 32 instead of 48 live registers
+              u32x4_t fb[MT];
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+              for (int t = 0; t < MT; ++t) {
+                const int tb = bh * MT + t;           // 16-row block of the wave tile
+                fb[t] = frag16_kmajor(sX, xrow[tb >> 1] + 16 * (tb & 1) + kw, sub, lane);
+              }
 #pragma unroll
-            for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[a], fb[b]);
+              for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) mma16_lo<L>(acc16[a][bh * MT + t], fa[a], fb[t]);
+              __builtin_amdgcn_sched_barrier(0);      // keep the halves sequential: the scheduler must not hoist the next half's reads
+            }
+          }
+        } else {
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            u32x4_t fa[2], fb[MT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fa[t] = frag_kmajor(sW, wn * 64 + t * 32 + l31, sub, lane);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) fb[t] = frag_kmajor(sX, xrow[t] + kw, sub, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[a], fb[b]);
+          }
         }
         __syncthreads();
       }
     }
   }
-  if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
-  else
-    ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+  if constexpr (M16) {
+    if (vec_ok == 2)
+      ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
+    else
+      ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc16, m0, n0, wm, wn, lane, 0, 0, 1);
+  } else {
+    if (vec_ok == 2)
+      ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
+    else
+      ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+  }
 }
 
 uint16_t* g_zero_page[16] = {nullptr};

@@ -471,6 +471,13 @@ __device__ __forceinline__ u32x4_t frag_kmajor(const unsigned char* tile, int ro
   const int cp = (((row & 1) << 3) | (2 * sub + (lane >> 5))) ^ (line & 15);
   return *(const u32x4_t*)(tile + line * 256 + cp * 16);
 }
+// 16x16x32 fragment of the same K-major image: row = block base + (lane & 15), 16-byte chunk 4 * sub32 + (lane >> 4) of the
+// 64-deep K step.  The four 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct slots: conflict-free.
+__device__ __forceinline__ u32x4_t frag16_kmajor(const unsigned char* tile, int row, int sub32, int lane) {
+  const int line = row >> 1;
+  const int cp = (((row & 1) << 3) | (4 * sub32 + (lane >> 4))) ^ (line & 15);
+  return *(const u32x4_t*)(tile + line * 256 + cp * 16);
+}
 template <int ROWS>
 __device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row, int sub, int lane) {
   constexpr int RS = ROWS * 2;   // bytes per k-row
@@ -501,6 +508,12 @@ __device__ __forceinline__ u32x4_t frag_trans(const unsigned char* tile, int row
 constexpr bool FRAG_PREFETCH_256 = false;
 #else
 constexpr bool FRAG_PREFETCH_256 = true;   // 256-row tiles also fetch fragments one sub-step ahead (two register sets)
+#endif
+#ifndef FFVC_MFMA16
+#define FFVC_MFMA16 1       // K-major x K-major / implicit-im2col kernels on v_mfma_f32_16x16x32 (0: 32x32x16 as in round 2)
+#endif
+#ifndef FFVC_MFMA16_CONVROW
+#define FFVC_MFMA16_CONVROW FFVC_MFMA16   // the haloed-row convolution kernel (gemm2.hip) separately, for A/B builds
 #endif
 #ifndef FFVC_EXP_MODE
 #define FFVC_EXP_MODE 0     // timing experiments only (wrong results): 1 = no DMA after the first stage, 2 = no vmcnt wait / barrier
@@ -595,20 +608,58 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   else
     sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid, 0, 0);
 
-  f32x16_t acc[2][MT];
+  // MFMA shape: 16x16x32 for K-major / implicit-im2col operands (fragment = one 16-byte read per 16 rows x 32 k), 32x32x16
+  // where an operand is reduction-major (its fragments come through ds_read_b64_tr_b16 in the 32x32 arrangement)
+  constexpr bool M16 = FFVC_MFMA16 && XMODE != FFVC_OP_TRANS && WMODE != FFVC_OP_TRANS;
+  f32x16_t acc[M16 ? 1 : 2][M16 ? 1 : MT];
+  f32x4_t acc16[M16 ? 4 : 1][M16 ? 2 * MT : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < MT; ++b)
+      for (int b = 0; b < 2 * MT; ++b) acc16[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  }
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
   // `between(sub)` runs after the MFMAs of sub-step `sub` have been issued: the ring loop uses it to spread the next
   // stage's DMA issue over the first sub-steps, so the matrix pipe already has work queued while a wave is busy issuing
   // loads (issued in one burst right after the barrier, both waves of a SIMD leave the pipe idle for that long).
   auto compute = [&](const unsigned char* sX, const unsigned char* sW, auto&& between) {
-    if constexpr (BM == 256 && !FRAG_PREFETCH_256) {
+    if constexpr (M16) {
+      // two 32-deep sub-steps of 4 x 2MT MFMAs; the second one's fragments are fetched under the first one's MFMAs;
+      // between(0) / between(1) (the next stage's DMA issue) fall after the first and second quarter of the MFMAs
+      const int l15 = lane & 15;
+      // two fragment sets (the second sub-step's under the first one's MFMAs) where the registers allow it: the implicit-im2col
+      // loader keeps per-piece pixel coordinates, its 256-row tile gets ONE set (the partner wave covers the LDS latency)
+      constexpr bool PF = !(XMODE == FFVC_OP_CONV3X3 && BM == 256);
+      u32x4_t fa[PF ? 2 : 1][4], fb[PF ? 2 : 1][2 * MT];
+      auto fetch = [&](int sub, u32x4_t (&a)[4], u32x4_t (&b)[2 * MT]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = frag16_kmajor(sW, wn * 64 + t * 16 + l15, sub, lane);
+#pragma unroll
+        for (int t = 0; t < 2 * MT; ++t) b[t] = frag16_kmajor(sX, wm * (32 * MT) + t * 16 + l15, sub, lane);
+      };
+      fetch(0, fa[0], fb[0]);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if (PF && sub == 0) fetch(1, fa[PF ? 1 : 0], fb[PF ? 1 : 0]);
+        if (!PF && sub == 1) fetch(1, fa[0], fb[0]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int b = 0; b < 2 * MT; ++b) mma16_lo<L>(acc16[a][b], fa[PF ? sub : 0][a], fb[PF ? sub : 0][b]);
+          if (a == 1) between(2 * sub);
+          if (a == 3) between(2 * sub + 1);
+        }
+      }
+    } else if constexpr (BM == 256 && !FRAG_PREFETCH_256) {
       // one fragment set (register budget): the partner wave on the SIMD covers the LDS latency
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
@@ -704,11 +755,19 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       }
     }
   }
-  if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi,
-                                                                   smem + (RING ? 2 : 1) * STAGE + wid * 4096);
-  else
-    ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
+  if constexpr (M16) {
+    if (vec_ok == 2)
+      ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, zo, zi,
+                                                          smem + (RING ? 2 : 1) * STAGE + wid * 4096);
+    else
+      ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc16, m0, n0, wm, wn, lane, zo, zi, 1);
+  } else {
+    if (vec_ok == 2)
+      ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi,
+                                                               smem + (RING ? 2 : 1) * STAGE + wid * 4096);
+    else
+      ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, zo, zi, 1);
+  }
 }
 
 // ---- 8-phase 256x256 kernel (K-major W; K-major or implicit-im2col X) --------------------------------------------------

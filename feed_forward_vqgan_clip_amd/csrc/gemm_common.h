@@ -130,6 +130,44 @@ __device__ __forceinline__ void gemm_epilogue(const ffvc_gemm_desc& p, f32x16_t 
   }
 }
 
+// The same epilogue for 16x16x32 accumulators: acc16[a][b] = W rows (n) block a (16 wide) x X rows (m) block b; the lane owns
+// m = 16 b + (lane & 15) and the 4 consecutive n = 16 a + 4 (lane >> 4) .. + 3.
+template <typename T, int MT = 2, bool VEC_ONLY = false>
+__device__ __forceinline__ void gemm_epilogue16(const ffvc_gemm_desc& p, f32x4_t (&acc)[4][2 * MT], int m0, int n0, int wm,
+                                                int wn, int lane, int zo, int zi, int vec_ok, int zs = -1) {
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int flags = p.flags;
+  if (zs < 0) zs = blockIdx.z;
+  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)zs * p.slab_stride;
+  const int64_t rbz = zo * p.rbo + zi * p.rbi;
+  const int64_t abz = zo * p.abo + zi * p.abi;
+#pragma unroll
+  for (int b = 0; b < 2 * MT; ++b) {
+    const int m = m0 + wm * (32 * MT) + b * 16 + l15;
+    const bool mok = m < p.M;
+    const int mm = mok ? m : 0;
+    const int64_t yrow = ybz + (p.y_mi ? (int64_t)(mm / p.y_mi) * p.y_so + (int64_t)(mm % p.y_mi) * p.y_sm
+                                       : (int64_t)mm * p.y_sm);
+    const int64_t rrow = rbz + (p.r_mi ? (int64_t)(mm / p.r_mi) * p.r_so + (int64_t)(mm % p.r_mi) * p.r_sm
+                                       : (int64_t)mm * p.r_sm);
+    const int64_t arow = abz + (int64_t)mm * p.ldaux;
+    const float bias_m = (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) ? p.bias[mm] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int n = n0 + wn * 64 + a * 16 + 4 * g4;
+      f32x4_t v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] * p.alpha + bias_m;
+      if (mok && n < p.N) {
+        if constexpr (VEC_ONLY)
+          epilogue_quad<T>(p, v, n, yrow, rrow, arow, flags, true);
+        else
+          epilogue_quad<T>(p, v, n, yrow, rrow, arow, flags, vec_ok && (n + 3 < p.N));
+      }
+    }
+  }
+}
+
 // ---- row-store epilogue --------------------------------------------------------------------------------------------
 // The MFMA C layout gives a lane 4 consecutive n of ONE row per register quad, 32 rows per wave instruction: stored
 // directly, every store touches 32 lines with 16 bytes each and the epilogue is store-issue bound (~7 B/clk/CU
@@ -309,10 +347,10 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
 }
 
 // pad: this wave's 4 KiB of LDS.  Requires N % 8 == 0 and 16-byte aligned rows of y / aux / residual (host-checked).
-template <typename T, int MT, bool NSPLIT = false, int EPI = EPI_ALL>
-__device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0,
-                                                   int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
-                                                   int zs = -1) {
+template <typename T, int MT, bool NSPLIT, int EPI, typename WR>
+__device__ __forceinline__ void gemm_epilogue_rows_impl(const ffvc_gemm_desc& p, WR&& write_block, int m0, int n0,
+                                                        int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
+                                                        int zs) {
   const int l31 = lane & 31, h = lane >> 5;
   const int rr = lane >> 2, cc = lane & 3;
   const int flags = p.flags;
@@ -320,8 +358,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
   const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)zs * p.slab_stride;
   const int64_t rbz = zo * p.rbo + zi * p.rbi;
   const int64_t abz = zo * p.abo + zi * p.abi;
-  unsigned char* wr = pad + l31 * 128;
-  const int wsw = l31 & 7;
+  (void)l31;
+  (void)h;
   const bool gn = (EPI & EPI_GN) && (flags & FFVC_F_GN_SUMS);
   float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [nt][4-channel half]
   const bool cs_on = (EPI & (EPI_ACT | EPI_K_BWD | EPI_K_MULAUX)) && (flags & FFVC_F_COLSUM);
@@ -333,9 +371,6 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int mbase = m0 + wm * (32 * MT) + mt * 32;
-    float bias_m = 0.0f;
-    if constexpr ((EPI & EPI_K_ANY) == 0)
-      if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mbase + l31, p.M - 1)];
     int64_t yrow[2], rrow[2], arow[2];
     bool mok[2];
 #pragma unroll
@@ -349,13 +384,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4_t v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
-        *(f32x4_t*)(wr + (((2 * q + h) ^ wsw) << 4)) = v;
-      }
+      write_block(nt, mt, mbase);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -428,6 +457,59 @@ __device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x
         }
       }
   }
+}
+
+// 32x32x16 accumulators: the lane owns row (lane & 31) of the block and the 4 consecutive n = 8 q + 4 (lane >> 5) .. + 3 per quad q
+template <typename T, int MT, bool NSPLIT = false, int EPI = EPI_ALL>
+__device__ __forceinline__ void gemm_epilogue_rows(const ffvc_gemm_desc& p, f32x16_t (&acc)[2][MT], int m0, int n0,
+                                                   int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
+                                                   int zs = -1) {
+  const int l31 = lane & 31, h = lane >> 5;
+  unsigned char* wr = pad + l31 * 128;
+  const int wsw = l31 & 7;
+  gemm_epilogue_rows_impl<T, MT, NSPLIT, EPI>(
+      p,
+      [&](int nt, int mt, int mbase) {
+        float bias_m = 0.0f;
+        if constexpr ((EPI & EPI_K_ANY) == 0)
+          if (p.bias && (p.flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mbase + l31, p.M - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4_t v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][4 * q + j] * p.alpha + bias_m;
+          *(f32x4_t*)(wr + (((2 * q + h) ^ wsw) << 4)) = v;
+        }
+      },
+      m0, n0, wm, wn, lane, zo, zi, pad, zs);
+}
+
+// 16x16x32 accumulators (acc16[a][b], see gemm_epilogue16): the 32x32 block (nt, mt) is the four accumulators
+// a = 2 nt + i, b = 2 mt + j; the lane writes row 16 j + (lane & 15), 16-byte chunk 4 i + (lane >> 4) of the same pad image.
+template <typename T, int MT, int EPI = EPI_ALL>
+__device__ __forceinline__ void gemm_epilogue_rows16(const ffvc_gemm_desc& p, f32x4_t (&acc)[4][2 * MT], int m0, int n0,
+                                                     int wm, int wn, int lane, int zo, int zi, unsigned char* pad,
+                                                     int zs = -1) {
+  const int l15 = lane & 15, g4 = lane >> 4;
+  gemm_epilogue_rows_impl<T, MT, false, EPI>(
+      p,
+      [&](int nt, int mt, int mbase) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = 16 * j + l15;
+          float bias_m = 0.0f;
+          if constexpr ((EPI & EPI_K_ANY) == 0)
+            if (p.bias && (p.flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mbase + row, p.M - 1)];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[2 * nt + i][2 * mt + j][e] * p.alpha + bias_m;
+            *(f32x4_t*)(pad + row * 128 + (((4 * i + g4) ^ (row & 7)) << 4)) = v;
+          }
+        }
+      },
+      m0, n0, wm, wn, lane, zo, zi, pad, zs);
 }
 
 }  // namespace ffvc_gemm_detail

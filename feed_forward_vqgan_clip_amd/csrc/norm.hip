@@ -10,6 +10,9 @@
 #define FFVC_STREAM_NT 1
 #endif
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(
                                                      const float* __restrict__ rstd, const XT* __restrict__ dres,
                                                      XT* __restrict__ dx, float* __restrict__ part_g,
                                                      float* __restrict__ part_b, int64_t rows, int dim,
-                                                     int rows_per_block, int acc_mode, DYT* __restrict__ dx_lo) {
+                                                     int rows_per_block, int acc_mode, DYT* __restrict__ dx_lo,
+                                                     int64_t pstride) {
   constexpr int NIT = MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(
       }
     } else {
       for (int i = threadIdx.x; i < dim; i += 64 * NWB) {
-        part_g[(int64_t)blockIdx.x * dim + i] = ln_smem[i];
-        part_b[(int64_t)blockIdx.x * dim + i] = ln_smem[dim + i];
+        part_g[(int64_t)blockIdx.x * pstride + i] = ln_smem[i];
+        part_b[(int64_t)blockIdx.x * pstride + i] = ln_smem[dim + i];
       }
     }
   }
@@ -768,10 +772,57 @@ extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, i
   return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, part_g, part_b, rows, dim, stream, 0, dx_lo);
 }
 
+// Per-stream scratch for the parameter-gradient partials of the accumulate form: [workgroups][2 * dim] fp32.  Launches on one
+// stream run in order, so one buffer per stream is enough; it grows on demand (the old one is freed after a stream sync).
+static float* ln_scratch(hipStream_t st, size_t bytes) {
+  static std::mutex mu;
+  static std::map<hipStream_t, std::pair<float*, size_t>> pool;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& slot = pool[st];
+  if (slot.second < bytes) {
+    if (slot.first) {
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(slot.first);
+      slot = {nullptr, 0};
+    }
+    const size_t want = bytes < (8u << 20) ? (8u << 20) : bytes;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    slot = {(float*)p, want};
+  }
+  return slot.first;
+}
+
+extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, int cols, int64_t ld, int accumulate, void* stream);
+
 extern "C" int ffvc_layernorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                                       const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
                                       float* dbeta, void* dx_lo, int64_t rows, int dim, void* stream) {
   FFVC_CHECK_ARG(dgamma && dbeta, "ffvc_layernorm_bwd_acc: null gradient pointer");
+  // Same-address fp32 atomics serialise in L2 (~75 ns each): with hundreds of workgroups adding into the same [dim] gradient
+  // the tail of the kernel is that queue.  The alternative built in round 3 — one partial row per workgroup with plain stores
+  // and a column-sum launch that folds them (FFVC_LN_ATOMIC=0) — measured WORSE: 82 vs 75 us isolated at 16384 x 1024, and
+  // 17.6 vs 13.7 ms per cfg2 step for the 65 launches (profiles/r03_layernorm_bwd_ab.txt): the parameter-gradient cost is the
+  // in-kernel accumulation (32 more live registers, an LDS combine per workgroup), not the global atomics, and the extra launch
+  // boundary costs more than the queue.  Default stays the in-kernel atomics.
+  static int atomic_mode = -1;
+  if (atomic_mode < 0) {
+    const char* e = getenv("FFVC_LN_ATOMIC");
+    atomic_mode = e ? atoi(e) : 1;
+  }
+  const int nblk = ffvc_layernorm_bwd_blocks(rows);
+  if (!atomic_mode && nblk >= 64) {
+    float* scratch = ln_scratch((hipStream_t)stream, (size_t)nblk * 2 * dim * sizeof(float));
+    if (scratch) {
+      int e = ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, scratch, scratch + dim, rows, dim, stream,
+                            2, dx_lo);
+      if (e) return e;
+      if (dbeta == dgamma + dim) return ffvc_colsum(scratch, FFVC_F32, dgamma, nblk, 2 * dim, 2 * (int64_t)dim, 1, stream);
+      e = ffvc_colsum(scratch, FFVC_F32, dgamma, nblk, dim, 2 * (int64_t)dim, 1, stream);
+      if (e) return e;
+      return ffvc_colsum(scratch + dim, FFVC_F32, dbeta, nblk, dim, 2 * (int64_t)dim, 1, stream);
+    }
+  }
   return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, dim, stream, 1, dx_lo);
 }
 
@@ -788,6 +839,8 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
   const bool v4 = (dim % 4) == 0;
+  const int64_t pstride = acc_mode == 2 ? 2 * (int64_t)dim : (int64_t)dim;   // 2: [blocks][dgamma row | dbeta row]
+  if (acc_mode == 2) acc_mode = 0;
   static int wide = -1;
   if (wide < 0) {
     const char* e = getenv("FFVC_LN_WIDE");
@@ -800,7 +853,7 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
     DISPATCH_DT(dy_dtype, DYT, DISPATCH_DT(x_dtype, XT, {
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16, 16>), dim3(grid16), dim3(1024), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows, dim,
-                                     rpb16, acc_mode, (DYT*)dx_lo);
+                                     rpb16, acc_mode, (DYT*)dx_lo, (int64_t)dim);
                 }));
     FFVC_LAUNCH_CHECK();
     return 0;
@@ -809,15 +862,15 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
                 if (v4 && dim <= 1024)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (DYT*)dx_lo);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride);
                 else if (v4)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (DYT*)dx_lo);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride);
                 else
                   hipLaunchKernelGGL((ln_bwd_kernel<1, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (DYT*)dx_lo);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride);
               }));
   FFVC_LAUNCH_CHECK();
   return 0;

@@ -544,6 +544,20 @@ def sln_bwd_acc(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dgamma, dbeta, dscal
     return dhl, dw
 
 
+def split3(x, dtype=torch.float16, weight_order=False, out=None):
+    """fp32 (..., K) -> 16-bit (..., 3K): [hi | lo | hi] (activations) or [hi | hi | lo] (weights), see ffvc_split3."""
+    _req_f32(x)
+    _need_cuda(x)
+    Kd = x.shape[-1]
+    rows = x.numel() // Kd
+    if not x.is_contiguous():
+        raise ValueError("split3: contiguous input expected")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], 3 * Kd, dtype=dtype, device=x.device)
+    _call("ffvc_split3", x.data_ptr(), out.data_ptr(), dtype_code(out.dtype), rows, Kd, Kd, int(weight_order), stream_ptr())
+    return out
+
+
 def colsum(x, out, accumulate=False, ld=None):
     _req_f32(out)
     _need_cuda(x)
@@ -644,15 +658,19 @@ def spherical_loss(embed, feats, coef=1.0, want_grad=True):
     return loss, dembed
 
 
-def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0, ema=None, ema_weight=0.0, dev_scale=None):
+def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0, ema=None, ema_weight=0.0, dev_scale=None,
+         bad_count=None):
     """ema (fp32, same layout as p): torch_ema update folded into the pass, ema -= ema_weight * (ema - p_new).
-    dev_scale (fp32 device scalar): multiplied into grad_scale on the device (clip_grad_norm_ coefficient)."""
+    dev_scale (fp32 device scalar): multiplied into grad_scale on the device (clip_grad_norm_ coefficient).
+    bad_count (int32 device scalar): elements with a non-finite scaled gradient are skipped and counted (per wavefront)."""
     _req_f32(p, g, m, v, ema, dev_scale)
-    _need_cuda(shadow)
+    _need_cuda(shadow, bad_count)
+    if bad_count is not None and bad_count.dtype != torch.int32:
+        raise TypeError("adam: bad_count must be an int32 device scalar")
     with _hbm("adam", p.numel() * (28 + (shadow.element_size() if shadow is not None else 0) + (8 if ema is not None else 0))):
         _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
               dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
-              _ptr(ema), float(ema_weight), _ptr(dev_scale), stream_ptr())
+              _ptr(ema), float(ema_weight), _ptr(dev_scale), _ptr(bad_count), stream_ptr())
 
 
 def clip_coef(sumsq_buf, max_norm, grad_scale):
@@ -705,6 +723,13 @@ def tv_loss_bwd(x, g):
     dx = torch.empty_like(x)
     _call("ffvc_tv_loss_bwd", x.data_ptr(), g.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr())
     return dx
+
+
+def clock_sample():
+    """-> int64 [2] device tensor (shader-clock ticks, 100 MHz ticks) sampled on the current stream (ffvc_clock_sample)."""
+    out = torch.empty(2, dtype=torch.int64, device="cuda")
+    _call("ffvc_clock_sample", out.data_ptr(), stream_ptr())
+    return out
 
 
 def sumsq(x, out):

@@ -186,8 +186,16 @@ def tv_loss(Y_hat):
     return ops.tv_loss_nhwc(Y_hat.permute(0, 2, 3, 1).float())
 
 
+DEFAULT_COMPUTE_DTYPE = "f16"     # the ONE default of train / test / bench.py / INTEGRATION.md (see _cdt)
+
+
 def _cdt(config):
-    name = str(config.get("compute_dtype", "bf16"))
+    """Compute dtype of the step (config key `compute_dtype`: f16 | bf16 | fp32).  Default f16: IEEE half storage / MFMA inputs
+    with fp32 accumulation, fp32 residual streams, statistics, VQ distances and loss, and a loss-scaled backward guarded against
+    overflow (optim.FusedAdam.check_overflow).  BASELINE.json names bf16 for cfg2; f16 has the same width and MFMA rate and an
+    8x finer mantissa, which is what keeps the loss inside north_star's 1e-4 of the CPU reference (bf16: 6e-5..2e-3, measured);
+    `compute_dtype: bf16` selects BASELINE's own format, bench.py times both."""
+    name = str(config.get("compute_dtype", DEFAULT_COMPUTE_DTYPE))
     return {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "fp32": torch.float32, "f32": torch.float32}[name]
 
 
@@ -212,7 +220,7 @@ def clip_arch(model_type):
     return arch, quick
 
 
-def load_clip_model(model_type, path=None, cdt=torch.bfloat16, fp8=False):
+def load_clip_model(model_type, path=None, cdt=torch.float16, fp8=False):
     """main.py:1308-1333 for the OpenAI / OpenCLIP ViT families (state_dict in clip.model.CLIP layout).
     fp8: image-tower linears on the fp8 MFMA path (config key `clip_fp8`, BASELINE.json configs[4])."""
     arch, quick = clip_arch(model_type)
@@ -356,7 +364,7 @@ def build_model(config, vq_channels=None):
     return net
 
 
-def load_model(path, cdt=torch.bfloat16, vq_channels=256):
+def load_model(path, cdt=torch.float16, vq_channels=256):
     """main.py:1273-1290: dict checkpoints {"state_dict","config","step","epoch"} and the legacy form, a pickled module
     instance (`model.th`).  The legacy object graph is read with stand-in classes (checkpoint_io), its parameters are
     flattened into a state_dict and loaded into a freshly built mapper, so neither the reference's classes nor its
@@ -546,7 +554,7 @@ def train(config_file):
     cdt = _cdt(config)
     toks = load_dataset(config.path)
     vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt)
-    perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt)
+    perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt, fp8=bool(config.get("clip_fp8", False)))
     vq_channels = vq.codebook.shape[1]
     checkpoint_path = os.path.join(config.folder, "checkpoint.th")
     checkpoint_ema_path = os.path.join(config.folder, "checkpoint_ema.th")
@@ -617,6 +625,11 @@ def train(config_file):
                 loss, mid = stepper(inp, None if same else out, next_inp=nxt[0] if (nxt is not None and same) else None)
                 avg_dev.mul_(0.99).add_(loss, alpha=0.01)        # main.py:861, every step, no host sync
                 if step % log_interval == 0:                     # a collective: EVERY rank takes it at the same steps
+                    if opt.loss_scale != 1.0:                    # f16: overflow events since the last log -> back the scale off
+                        n_bad = opt.check_overflow()
+                        if n_bad and rank_zero:
+                            print(f"step:{step:05d} non-finite gradients in {n_bad} wavefront(s) since the last log: those "
+                                  f"elements were skipped, loss_scale -> {opt.loss_scale:g}")
                     sc = hvd.allreduce_scalars(loss, mid["dists"].detach(), zero if mid["l2"] is None else mid["l2"].detach(),
                                                zero if mid["tv"] is None else mid["tv"].detach(), avg_dev)
                     if rank_zero:
@@ -695,7 +708,7 @@ def _save_fixed_batch(stepper, first_batch, use_ema, prefix, step, bs):
 
 
 def test(model_path, text_or_path, *, nb_repeats=1, out_path="gen.png", images_per_row=None, seed=None,
-         cdt=torch.bfloat16, bpe_path=None, prior_path=None):
+         cdt=torch.float16, bpe_path=None, prior_path=None):
     """main.py:977-1061: prompts -> PNG grid; prior_path: a `train_prior` checkpoint whose flow maps the text embedding
     to an image-embedding sample before the mapper (main.py:1022-1023,1037-1040; prior.py).  `text_or_path`: "a|b|c", a `.txt` file with
     one prompt per line, a `.pkl` of token rows / features, or `synthetic:<n>[:seed]` token rows."""
@@ -703,7 +716,7 @@ def test(model_path, text_or_path, *, nb_repeats=1, out_path="gen.png", images_p
         torch.manual_seed(seed)
     net = load_model(model_path, cdt)
     config = net.config
-    perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt)
+    perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt, fp8=bool(config.get("clip_fp8", False)))
     vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt)
     if text_or_path.startswith("synthetic:") or text_or_path.endswith(".pkl"):
         toks = load_dataset(text_or_path)

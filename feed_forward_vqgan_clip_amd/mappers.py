@@ -16,7 +16,7 @@ from .kernels import ACT_GELU
 class _MapperBase(nn.Module):
     """Shared arena / shadow management."""
 
-    cdt = torch.bfloat16
+    cdt = torch.float16        # package-wide default (main.DEFAULT_COMPUTE_DTYPE)
 
     def prepare(self, cdt=None):
         """Move parameters into a flat arena and build the compute-dtype shadows. Idempotent per dtype."""

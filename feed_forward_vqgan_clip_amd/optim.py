@@ -31,6 +31,11 @@ class FusedAdam(torch.optim.Optimizer):
         self.loss_scale = 1.0           # gradients in the bucket are loss_scale x the true ones (f16 backward)
         self._ema, self._ema_decay, self._ema_updates = None, 0.0, 0
         self._clip = None               # device [coef, total_norm] of the pending clip_grad_norm_
+        # overflow guard of the loss-scaled f16 backward: the Adam kernel skips (and counts) non-finite gradient elements, the
+        # host reads the counter at its logging synchronisations (check_overflow) and backs the scale off / regrows it
+        self._bad = torch.zeros(1, dtype=torch.int32, device=a.params.device)
+        self._good_steps = 0
+        self.scale_growth_interval, self.scale_max, self.scale_min = 2000, 65536.0, 1.0
         for p in a.plist:
             o, n = a.param_range(p)
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[o:o + n].view(p.shape),
@@ -97,10 +102,26 @@ class FusedAdam(torch.optim.Optimizer):
             K.adam(a.params[s:e], a.grads[s:e], self._m[s:e], self._v[s:e], None if shadow is None else shadow[s:e], g["lr"],
                    g["betas"][0], g["betas"][1], g["eps"], self._step, self._eff_scale(),
                    ema=None if self._ema is None else self._ema[s:e], ema_weight=ema_w,
-                   dev_scale=None if clip is None else clip[0:1])
+                   dev_scale=None if clip is None else clip[0:1], bad_count=self._bad)
         a.refresh(cast=False)
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
+
+    def check_overflow(self):
+        """Dynamic loss scaling without a per-step host synchronisation.  Call where the host synchronises anyway (logging):
+        if any step since the last call met a non-finite gradient (those elements were skipped by the kernel, the optimizer
+        state stayed finite), halve `loss_scale`; after `scale_growth_interval` clean steps double it (up to scale_max).
+        Returns the number of wavefront-level overflow events seen since the last call."""
+        n = int(self._bad.item())
+        if n:
+            self._bad.zero_()
+            self._good_steps = self._step
+            if self.loss_scale > self.scale_min:
+                self.loss_scale = max(self.scale_min, self.loss_scale * 0.5)
+        elif self.loss_scale != 1.0 and self._step - self._good_steps >= self.scale_growth_interval:
+            self._good_steps = self._step
+            self.loss_scale = min(self.scale_max, self.loss_scale * 2.0)
+        return n
 
     def load_state_dict(self, state_dict):
         sd = state_dict["state"]

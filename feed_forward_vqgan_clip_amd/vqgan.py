@@ -117,7 +117,7 @@ class VQGAN:
     """Frozen VQGAN: `.quantize.embedding.weight` (fp32 codebook) and `.decode` like the object `synth` receives
     (main.py:140-143), plus the NHWC fast path used by the fused train step."""
 
-    def __init__(self, state_dict, cfg=F16_16384, cdt=torch.bfloat16):
+    def __init__(self, state_dict, cfg=F16_16384, cdt=torch.float16):
         if not torch.cuda.is_available():
             raise RuntimeError("VQGAN needs a HIP device; there is no CPU fallback")
         sd, self.cfg, self.cdt = state_dict, cfg, cdt
@@ -194,7 +194,7 @@ def synth(model, z):
     return xr.permute(0, 3, 1, 2)
 
 
-def load_vqgan_model(config_path, checkpoint_path, cdt=torch.bfloat16):
+def load_vqgan_model(config_path, checkpoint_path, cdt=torch.float16):
     """main.py:84-103: yaml read with PyYAML; the three targets the reference accepts —
       taming.models.vqgan.VQModel                        decoder / post_quant_conv / quantize.embedding
       taming.models.vqgan.GumbelVQ                       same decoder; the codebook is `quantize.embed` (main.py:95 aliases it)

@@ -243,6 +243,11 @@ int ffvc_attn_flash_bwd(const void* qkv, const void* out, const void* dout, cons
  * Glue kernels of the train step (main.py:715-837)
  * ------------------------------------------------------------------------- */
 int ffvc_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* Split-precision operand of an fp32-grade GEMM on the 16-bit matrix pipes (the frozen CLIP text tower, reference
+ * cloob.py:525-538 runs it in fp32): src fp32 [rows, K] (row stride ld_src) -> dst 16-bit [rows, 3K] holding hi = rn16(x) and
+ * lo = rn16(x - hi) as [hi | lo | hi] (weight_order 0: activations) or [hi | hi | lo] (weight_order 1: weights), so that one
+ * 16-bit GEMM of depth 3K accumulates every product but lo x lo in fp32 (relative error ~2^-21 with f16 segments). */
+int ffvc_split3(const float* src, void* dst, int dst_dtype, int64_t rows, int K, int64_t ld_src, int weight_order, void* stream);
 /* dst[b][c][r] = src[b][r][c] (+dtype conversion): einops Rearrange mlp_mixer_pytorch.py:31; W^T shadows for dgrad */
 /* dst_ld (0 = rows) >= rows pads every output row with zeros (per-head padding of VitGAN's (d k h) qkv layout,
  * vitgan.py:82) */
@@ -323,10 +328,16 @@ int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, 
  * ema -= ema_weight * (ema - p_new), ema_weight = 1 - min(decay, (1 + n_updates) / (10 + n_updates)). */
 int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr,
               float beta1, float beta2, float eps, int step, float grad_scale, float* ema, float ema_weight,
-              const float* dev_scale, void* stream);   /* dev_scale (may be NULL): grad_scale *= dev_scale[0] */
+              const float* dev_scale, uint32_t* nonfinite_count, void* stream);
+/* dev_scale (may be NULL): grad_scale *= dev_scale[0].  nonfinite_count (may be NULL): an element whose scaled gradient is inf /
+ * NaN (overflow of a loss-scaled f16 backward) keeps p, m, v, ema unchanged, and the counter is incremented once per wavefront
+ * that met one — the host polls it to back the loss scale off; nothing non-finite ever enters the optimizer state. */
 /* clip_grad_norm_ (main.py:833-834) without a host round trip: out[0] = min(1, max_norm / (sqrt(sumsq[0])*|grad_scale|
  * + 1e-6)) (feed it to ffvc_adam's dev_scale), out[1] = the total norm. */
 int ffvc_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* out, void* stream);
+/* out[0] = s_memtime (shader-clock ticks), out[1] = s_memrealtime (100 MHz ticks) sampled by a one-thread kernel on `stream`:
+ * two samples around a region give its average effective engine clock (bench.py reports it next to the roofline fraction). */
+int ffvc_clock_sample(uint64_t* out, void* stream);
 /* nn.Dropout of the mapper MLPs / attention outputs (mlp_mixer_pytorch.py:20-22; vitgan.py:34-41,114,133):
  * y[i] = (residual ? residual[i] : 0) + (keep(seed, i) ? x[i] / (1 - p) : 0).  The mask is a counter-based hash of
  * (seed, i): the backward pass calls the same function on the gradient with the same seed.  x may alias y. */

@@ -465,3 +465,35 @@ def test_text_prefetch_matches_inline(cuda):
     stepper._prefetched = None
     l2, _ = stepper.forward_loss(t, facs=facs.cuda(), noise=noise.cuda())
     assert abs(l1.item() - l2.item()) < 1e-6
+
+
+def test_split_precision_text_tower_is_fp32_grade():
+    """CLIP(text_exact=False): the text tower's Linear layers as ONE f16 GEMM of depth 3K over [hi | lo | hi] x [hi | hi | lo]
+    (ffvc_split3) — against the exact fp32 MFMA path and the CPU oracle, at the full ViT-B/32 text dimensions (cloob.py:525-538)."""
+    from feed_forward_vqgan_clip_amd import clip as fclip
+    from feed_forward_vqgan_clip_amd import kernels as K
+    from oracle import clip as oclip
+    cfg = dict(fclip.VIT_B32, vision_layers=1, transformer_layers=4)
+    sd = fclip.random_state_dict(cfg, 3)
+    g = torch.Generator().manual_seed(3)
+    for k in list(sd):                                                 # non-trivial biases / LayerNorm affine
+        if k.startswith("transformer") and (k.endswith("bias") or "ln_" in k):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    tok = torch.zeros(6, 77, dtype=torch.long)
+    for i, L in enumerate((3, 9, 20, 40, 60, 76)):
+        tok[i, 0] = 49406
+        tok[i, 1:L] = torch.randint(1, 49000, (L - 1,), generator=g)
+        tok[i, L] = 49407
+    exact = fclip.CLIP(sd, torch.float16, text_exact=True).encode_text(tok.cuda()).cpu()
+    split = fclip.CLIP(sd, torch.float16, text_exact=False)
+    assert not split.text_exact
+    got = split.encode_text(tok.cuda()).cpu()
+    want = oclip.encode_text(sd, tok)
+    assert _relrms(got, exact) < 5e-6, _relrms(got, exact)        # measured 2.3e-6 (the 16-bit epilogue's fast QuickGELU included)
+    assert _relrms(got, want) < 1e-5 and _relrms(exact, want) < 1e-5
+    # the split itself: hi + lo reproduces fp32 to ~2^-21, layout [hi | lo | hi] / [hi | hi | lo]
+    x = torch.randn(7, 64, generator=g).cuda() * 3
+    a, w = K.split3(x), K.split3(x, weight_order=True)
+    hi, lo = x.half(), (x - x.half().float()).half()
+    assert torch.equal(a, torch.cat([hi, lo, hi], 1)) and torch.equal(w, torch.cat([hi, hi, lo], 1))
+    assert float(((hi.float() + lo.float()) - x).abs().max() / x.abs().max()) < 1e-6

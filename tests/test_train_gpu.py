@@ -489,3 +489,59 @@ torch.save(root, sys.argv[1] + "/model.th")
     assert got.config.model_type == "mlp_mixer" and got.config.depth == 2
     for k, v in sd.items():
         assert torch.equal(got.state_dict()[k].cpu(), v), k
+
+
+def test_adam_skips_non_finite_gradients_and_backs_the_loss_scale_off(cuda):
+    """one overflowing f16 backward must not poison p / m / v / ema.  Elements whose scaled gradient is inf / NaN keep
+    their state, the event is counted on the device, `check_overflow` (called where the host synchronises anyway) halves the scale."""
+    cfg, net, vq, perceptor, opt, *_ = _setup(cdt=torch.float16)
+    opt.loss_scale = 1024.0
+    opt.enable_ema(0.9)
+    a = opt.arena
+    torch.manual_seed(0)
+    a.grads.copy_(torch.randn_like(a.grads) * 1024.0)
+    bad_idx = torch.tensor([0, 5, a.total // 2, a.total - 1], device="cuda")
+    a.grads[bad_idx[0]] = float("inf")
+    a.grads[bad_idx[1]] = float("-inf")
+    a.grads[bad_idx[2]] = float("nan")
+    a.grads[bad_idx[3]] = float("inf")
+    p0, g0 = a.params.clone(), a.grads.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.params).all() and torch.isfinite(opt._m).all() and torch.isfinite(opt._v).all()
+    assert torch.isfinite(opt._ema).all()
+    assert torch.equal(a.params[bad_idx], p0[bad_idx]) and float(opt._m[bad_idx].abs().max()) == 0.0   # skipped elements
+    ok = torch.ones(a.total, dtype=torch.bool, device="cuda")
+    ok[bad_idx] = False
+    ref = torch.nn.Parameter(p0.clone())
+    ref.grad = torch.where(ok, g0 / 1024.0, torch.zeros_like(g0))
+    torch.optim.Adam([ref], lr=cfg.lr).step()
+    assert float((a.params[ok] - ref.detach()[ok]).abs().max()) < 1e-6                                  # everything else: plain Adam
+    assert opt.check_overflow() >= 1 and opt.loss_scale == 512.0
+    assert opt.check_overflow() == 0 and opt.loss_scale == 512.0
+    # with global-norm clipping the coefficient is 0 x inf = NaN for every element: the whole step is skipped, nothing is poisoned
+    a.grads.copy_(g0)
+    p1 = a.params.clone()
+    opt.clip_grad_norm_(1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, p1) and torch.isfinite(opt._v).all()
+    assert opt.check_overflow() >= 1 and opt.loss_scale == 256.0
+    # regrowth after an interval of clean steps
+    opt.scale_growth_interval = 2
+    a.grads.copy_(torch.randn_like(a.grads))
+    opt.step()
+    opt.step()
+    assert opt.check_overflow() == 0 and opt.loss_scale == 512.0
+
+
+def test_clock_sample_reports_a_plausible_engine_clock(cuda):
+    c0 = K.clock_sample()
+    x = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):
+        x = (x @ x).clamp(-1, 1)
+    c1 = K.clock_sample()
+    torch.cuda.synchronize()
+    d = (c1 - c0).tolist()
+    mhz = d[0] / d[1] * 100.0
+    assert d[1] > 0 and 300.0 < mhz < 2600.0, mhz

@@ -42,6 +42,11 @@ for B, H, C in ((64, 256, 128), (64, 128, 256), (64, 64, 256), (64, 32, 512), (6
     dres = torch.randn(B, H, H, C, device=dev).to(bf)
     report(f"gn_bwd b{B} {H}^2 x{C} (stats + apply, +dres)",
            timeit(lambda: K.groupnorm_bwd(dy, x, g, b, mean, rstd, dres=dres, swish=True), iters=10), n * 12)
+    for nb in (2, 4, 8, 16):       # the same backward as a host loop over groups of `nb` images (do the re-reads of pass 2 hit the Infinity Cache?)
+        def loop():
+            for i in range(0, B, nb):
+                K.groupnorm_bwd(dy[i:i + nb], x[i:i + nb], g, b, mean[i:i + nb], rstd[i:i + nb], dres=dres[i:i + nb], swish=True)
+        report(f"   ... in groups of {nb} images", timeit(loop, iters=5), n * 12)
     del x, y, dy, dres
 
 for rows, cols in ((16384, 4096), (16384, 1024), (25600, 3072)):
