@@ -34,6 +34,7 @@ def init(backend=None):
             # box run the complete N-rank bench / train path for validation
             backend = os.environ.get("FFVC_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            _STATE["preset"] = apply_rccl_preset()         # before the communicator exists
             torch.cuda.set_device(local_rank())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -48,13 +49,39 @@ def init(backend=None):
     _STATE["init"] = True
 
 
+# RCCL over xGMI on one 8-GPU MI355X node: every GPU has 7 point-to-point links (~153 GB/s each), rings are per-link bound, the
+# exchange is ~20 slices of 64 MiB per step.  `setdefault` only — anything the user exports wins; `describe()` records the result.
+# UNMEASURED (no multi-GPU box was available to this build): the values follow the topology, not a sweep.
+RCCL_PRESET = {
+    "HSA_ENABLE_IPC_MODE_LEGACY": "0",     # the host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
+    "NCCL_IB_DISABLE": "1",                # single node: no verbs transport probing
+    "NCCL_SOCKET_IFNAME": "lo",            # bootstrap over loopback (the container hostname may not resolve)
+    "NCCL_MIN_NCHANNELS": "28",            # >= 4 channels per xGMI link (7 links): large slices need all links busy
+    "NCCL_BUFFSIZE": str(8 << 20),         # 8 MiB per channel: fewer, larger steps for 64 MiB all-reduces
+    "NCCL_DEBUG": "VERSION",
+}
+
+
+def apply_rccl_preset():
+    """Export RCCL_PRESET for the keys the environment does not already set (FFVC_RCCL_PRESET=0 disables)."""
+    if os.environ.get("FFVC_RCCL_PRESET", "1") == "0":
+        return {}
+    applied = {}
+    for k, v in RCCL_PRESET.items():
+        if k not in os.environ:
+            os.environ[k] = v
+            applied[k] = v
+    return applied
+
+
 def describe():
     """What the data-parallel layer actually runs on (goes into the bench line): backend, ranks the process group
     sees, and every NCCL_* / RCCL_* / HSA_* knob of the environment (channel / link configuration of RCCL over xGMI)."""
     env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "FFVC_DP", "FFVC_SHARE"))}
     if not (dist.is_available() and dist.is_initialized()):
         return {"backend": None, "ranks": 1, "env": env}
-    return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env}
+    return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env,
+            "preset_applied": sorted(_STATE.get("preset", {}))}
 
 
 def is_distributed():
@@ -125,6 +152,8 @@ def broadcast_optimizer_state(opt, root_rank=0):
         step = torch.tensor([inner._step], dtype=torch.int64, device=inner._m.device)
         dist.broadcast(step, src=root_rank)
         inner._step = int(step.item())
+        if getattr(inner, "_ema", None) is not None:      # the averaged copy starts from rank 0's weights on every rank
+            dist.broadcast(inner._ema, src=root_rank)
     else:
         for st in inner.state.values():
             for v in st.values():
@@ -199,22 +228,45 @@ class DistributedOptimizer:
     # -- gradient-ready plumbing ------------------------------------------------
     def _param_ready_hook(self, p):
         # autograd's own notification.  The engine also runs the AccumulateGrad node (and this hook) of a parameter whose
-        # gradient a fused kernel already wrote (its Function returned None for it): that repeat is not a second use.
+        # gradient a fused kernel already wrote (its Function returned None for it): that repeat is not a second use —
+        # within ONE backward pass.  A hook that fires after that pass has ended is a second backward() before step().
+        if getattr(self, "_backward_done", False) and is_distributed():
+            self._refuse(p)
         if id(p) not in self._seen:
             self._param_ready(p)
+
+    def _mark_backward(self):
+        """First gradient report of a step: ask the autograd engine to tell us when this backward pass ends."""
+        if getattr(self, "_cb_armed", False):
+            return
+        self._cb_armed = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._on_backward_end)
+        except RuntimeError:                 # not inside a backward pass (a kernel-side report outside autograd): nothing to arm
+            self._cb_armed = False
+
+    def _on_backward_end(self):
+        self._backward_done = True
+
+    def _refuse(self, p):
+        name = next((n for n, q in self.arena.module.named_parameters() if q is p), "?")
+        raise RuntimeError(f"DistributedOptimizer: parameter '{name}' received another gradient contribution after its "
+                           "bucket's all-reduce was launched.  Causes: a second backward() before step() (gradient "
+                           "accumulation is not supported: the exchange overlaps the FIRST backward) or a weight shared "
+                           "between two layers")
 
     def _param_ready(self, p):
         if not is_distributed():
             return
         if id(p) in self._seen:
             # The fused wgrad / LayerNorm paths report a parameter once per USE.  A second report after the bucket went
-            # out means a weight shared between two layers: its later contribution would be written into a slice that is
-            # already being all-reduced (replicas stay identical, the gradient is silently wrong) -> refuse.
+            # out means either a weight shared between two layers or a second backward() before step() (gradient
+            # accumulation): the later contribution would be written into a slice that is already being all-reduced
+            # (replicas stay identical, the gradient is silently wrong) -> refuse, naming both causes.
             if any(b in self._handles for b in self._bucket_of[id(p)]):
-                name = next((n for n, q in self.arena.module.named_parameters() if q is p), "?")
-                raise RuntimeError(f"DistributedOptimizer: parameter '{name}' received a second gradient contribution after "
-                                   "its bucket was launched (weight sharing is not supported by the fused gradient path)")
+                self._refuse(p)
             return
+        self._mark_backward()
         self._seen.add(id(p))
         for b in self._bucket_of[id(p)]:
             self._pending[b] -= 1
@@ -264,6 +316,7 @@ class DistributedOptimizer:
             self.arena.grads[s:e].copy_(w)
 
     def _reset(self):
+        self._backward_done = self._cb_armed = False
         self._handles, self._wire = {}, {}
         self._pending = [len(idxs) for _, _, idxs in self.buckets]
         self._seen = set()

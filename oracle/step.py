@@ -93,12 +93,12 @@ def spherical_loss(embed, target_feats, cutn, coef=1.0):
 
 def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_size, z_min, z_max,
                     facs=None, noise=None, vq_cfg=ovq.F16_16384, clip_heads=(None, None),
-                    pool_size=None, text_feats=None, decode_fn=None, aug_params=None):
+                    pool_size=None, text_feats=None, decode_fn=None, aug_params=None, quick_gelu=True):
     """Forward half of one training step (main.py:729-811,831) with repeat=1, noise_dim=0,
     l2/tv/diversity coefficients 0.  Returns (loss, dict of intermediates)."""
     if text_feats is None:
         with torch.no_grad():
-            text_feats = oclip.encode_text(clip_sd, tokens, clip_heads[1]).float()     # main.py:733,737
+            text_feats = oclip.encode_text(clip_sd, tokens, clip_heads[1], quick_gelu).float()     # main.py:733,737
     z = mapper_fn(mapper_sd, text_feats).contiguous()                                   # :754-757
     z = clamp_with_grad(z, z_min, z_max)                                                # :763
     xr = synth(vq_sd, z, vq_cfg, decode_fn)                                             # :767
@@ -111,7 +111,7 @@ def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_s
     mean = torch.tensor(CLIP_MEAN, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     std = torch.tensor(CLIP_STD, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     x = (x - mean) / std                                                                # :797
-    embed = oclip.encode_image(clip_sd, x, clip_heads[0]).float()                       # :799
+    embed = oclip.encode_image(clip_sd, x, clip_heads[0], quick_gelu).float()           # :799
     loss = spherical_loss(embed, text_feats, cutn)                                      # :801-811
     return loss, {"text_feats": text_feats, "z": z, "xr": xr, "embed": embed}
 

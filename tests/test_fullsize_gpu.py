@@ -227,3 +227,84 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
     print(f"[cfg5] loss fp32 {ref['loss']:.7f} | f16 rel {r16:.2e} embed {e16:.2e} | fp8 rel {r8:.2e} embed {e8:.2e}")
     assert rr(out["f16"]["xr"], ref["xr"]) < 3e-3 and e16 < 3e-3 and r16 < 1e-4        # the north_star tolerance in f16 mode
     assert e8 < 6e-2 and r8 < 3e-3                                                      # fp8 tower: its own budget
+
+
+# ----------------------------------------------------------------------------- the TIMED dtype at full model size vs the oracle
+def _timed_dtype_vs_oracle(cfg, mapper_fn, clip_arch, quick, Bn, cutn, seed):
+    """One forward of the step in fp32-MFMA mode and in f16 (bench.py's dtype; the package default) on the same weights, prompts,
+    augmentation draws and noise, against the CPU oracle: (oracle loss, fp32 loss, f16 loss with the oracle's codes, f16 loss
+    free-running, code flips of the free-running f16 run, stage errors)."""
+    from feed_forward_vqgan_clip_amd import augment as faug
+    from oracle import step as ostep
+    torch.manual_seed(seed)
+    net0 = fmain.build_model(cfg, 256)
+    msd = {k: v.detach().clone() for k, v in net0.state_dict().items()}
+    vq_sd, clip_sd = fvq.random_state_dict(fvq.F16_16384, seed=seed), fclip.random_state_dict(clip_arch, seed=seed)
+    tok = fmain.synthetic_tokens(Bn, seed=seed + 2)
+    g = torch.Generator().manual_seed(seed + 6)
+    facs, noise = torch.rand(cutn * Bn, generator=g) * 0.1, torch.randn(cutn * Bn, 3, 224, 224, generator=g)
+    prm = faug.draw_params(cutn * Bn, 224, generator=g)
+    res = {}
+    oidx = None
+    for name, cdt in (("fp32", torch.float32), ("f16", torch.float16)):
+        net = fmain.build_model(cfg, 256)
+        net.load_state_dict(msd)
+        net = net.cuda().prepare(cdt)
+        vq, perceptor = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt, quick_gelu=quick)
+        stepper = fmain.TrainStep(cfg, net, vq, perceptor, FusedAdam(net.parameters(), lr=cfg.lr))
+        kw = dict(facs=facs.cuda(), noise=noise.cuda(), aug_params={k: v.cuda() for k, v in prm.items()})
+        if oidx is None:
+            with torch.no_grad():
+                oloss, omid = ostep.train_step_loss(mapper_fn, msd, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=vq.z_min,
+                                                    z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise, aug_params=prm,
+                                                    quick_gelu=quick)
+            oidx = ostep.vq_indices(omid["z"].movedim(1, 3), vq_sd["quantize.embedding.weight"])
+            res["oracle"] = oloss.item()
+        with torch.no_grad():
+            lfree, mfree = stepper.forward_loss(tok.cuda(), **kw)
+            lsame, msame = stepper.forward_loss(tok.cuda(), force_idx=oidx.cuda(), **kw)
+        res[name] = dict(free=lfree.item(), same=lsame.item(),
+                         flips=int((mfree["indices"].cpu().view(-1) != oidx.view(-1)).sum()), n=oidx.numel(),
+                         xr=_rr(msame["xr"].permute(0, 3, 1, 2).cpu(), omid["xr"]), embed=_rr(msame["embed"].cpu(), omid["embed"]))
+        del stepper, net, vq, perceptor
+        torch.cuda.empty_cache()
+    return res
+
+
+def _rr(a, b):
+    return ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
+
+
+def test_cfg2_full_size_f16_step_matches_oracle(cuda):
+    """BASELINE configs[1] models at full size (Mixer 32x1024, f16-16384 decoder 256x256, ViT-B/32), default augmentations with
+    explicit draws, batch 2 x 2 cutouts, in the dtype bench.py times: north_star's 1e-4 on the loss with the reference's codes
+    (the VQ argmin is a discontinuity of the reference itself; flips of the free-running run are reported and bounded)."""
+    from oracle import mappers as omap
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=1024, depth=32, dropout=0, cutn=2, batch_size=2, repeat=1, nb_noise=None,
+                       diversity_coef=0, clip_model="ViT-B/32", model_type="mlp_mixer", vq_image_size=16)
+    r = _timed_dtype_vs_oracle(cfg, lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=32), fclip.VIT_B32, True, 2, 2, 21)
+    o = r["oracle"]
+    print(f"[cfg2 f16] oracle {o:.7f} | fp32 same {abs(r['fp32']['same'] - o) / o:.2e} | f16 same {abs(r['f16']['same'] - o) / o:.2e} "
+          f"free {abs(r['f16']['free'] - o) / o:.2e} flips {r['f16']['flips']}/{r['f16']['n']} xr {r['f16']['xr']:.2e} embed {r['f16']['embed']:.2e}")
+    assert abs(r["fp32"]["same"] - o) / o < 1e-4 and r["fp32"]["flips"] <= 1
+    assert abs(r["f16"]["same"] - o) / o < 1e-4                      # the timed dtype, reference's codes: north_star tolerance
+    assert r["f16"]["xr"] < 3e-3 and r["f16"]["embed"] < 3e-3
+    assert r["f16"]["flips"] <= 0.01 * r["f16"]["n"] and abs(r["f16"]["free"] - o) / o < 5e-3
+
+
+def test_cfg5_full_size_f16_step_matches_oracle(cuda):
+    """BASELINE configs[4] models at full size (Mixer 1x1024 on a 32x32 grid, 512x512 decode, OpenCLIP ViT-L/14: erf GELU, 257 tokens,
+    588-wide patch rows) in f16 against the CPU oracle — round 2 only compared HIP modes with each other."""
+    from oracle import mappers as omap
+    name = "openclip/ViT-L-14/laion2b_s32b_b82k"
+    cfg = fmain.Config(lr=1e-4, epochs=1, noise_dim=0, dropout=0, cutn=2, batch_size=2, repeat=1, nb_noise=None, diversity_coef=0,
+                       clip_model=name, model_type="mlp_mixer", dim=1024, depth=1, vq_image_size=32)
+    arch, quick = fmain.clip_arch(name)
+    r = _timed_dtype_vs_oracle(cfg, lambda sd, f: omap.mixer_forward(sd, f, image_size=32, channels=256, depth=1), arch, quick, 2, 2, 23)
+    o = r["oracle"]
+    print(f"[cfg5 f16] oracle {o:.7f} | fp32 same {abs(r['fp32']['same'] - o) / o:.2e} | f16 same {abs(r['f16']['same'] - o) / o:.2e} "
+          f"free {abs(r['f16']['free'] - o) / o:.2e} flips {r['f16']['flips']}/{r['f16']['n']} xr {r['f16']['xr']:.2e} embed {r['f16']['embed']:.2e}")
+    assert abs(r["fp32"]["same"] - o) / o < 1e-4
+    assert abs(r["f16"]["same"] - o) / o < 1e-4
+    assert r["f16"]["xr"] < 3e-3 and r["f16"]["embed"] < 3e-3
+    assert r["f16"]["flips"] <= 0.01 * r["f16"]["n"] and abs(r["f16"]["free"] - o) / o < 5e-3
