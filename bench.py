@@ -338,8 +338,7 @@ def main():
     clk1 = K.clock_sample()
     sync()
     dt = time.perf_counter() - t0
-    dclk = (clk1 - clk0).tolist()            # (shader-clock ticks, 100 MHz ticks) over the timed region
-    sclk_mhz = dclk[0] / max(dclk[1], 1) * 100.0
+    sclk_mhz = K.effective_clock_mhz(clk0, clk1)     # engine clock averaged over the timed region (and over the XCDs)
     if hvd.is_distributed():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

@@ -36,17 +36,24 @@ extern "C" int ffvc_device_info(int32_t* n_cu, int32_t* clock_khz, int64_t* hbm_
   return 0;
 }
 
-// out[0] = shader-clock counter (s_memtime, ticks at the CURRENT engine clock), out[1] = the constant 100 MHz counter
-// (s_memrealtime) of whichever CU runs the sample: two samples bracketing a region give its average effective clock,
-// (d out[0]) / (d out[1] * 10 ns) — the chip clocks to its power budget under MFMA load (profiles/r03_power_ceiling.txt).
+// out[2 x + 0] = shader-clock counter (s_memtime, ticks at the CURRENT engine clock), out[2 x + 1] = the constant 100 MHz counter
+// (s_memrealtime), sampled on XCD x (0..7; the counters are per XCD, so a pair of samples is only comparable on the same XCD):
+// 64 one-thread workgroups are dealt round-robin to the XCDs, each writes its XCD's slot.  Two samples bracketing a region give
+// its average effective clock per XCD, (d out[2x]) / (d out[2x+1] * 10 ns) — the chip clocks to its power budget under MFMA load
+// (profiles/r03_power_ceiling.txt).  out: 16 x uint64, zero-filled first (an XCD that ran no block keeps zeros).
 __global__ void clock_sample_kernel(unsigned long long* out) {
-  out[0] = __builtin_amdgcn_s_memtime();
-  out[1] = __builtin_amdgcn_s_memrealtime();
+  unsigned int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  out[2 * xcc] = __builtin_amdgcn_s_memtime();
+  out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 extern "C" int ffvc_clock_sample(uint64_t* out, void* stream) {
   FFVC_CHECK_ARG(out, "ffvc_clock_sample: null pointer");
-  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, 16 * sizeof(uint64_t), st) != hipSuccess) return FFVC_E_BADARG;
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(64), dim3(1), 0, st, (unsigned long long*)out);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

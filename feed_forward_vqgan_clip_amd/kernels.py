@@ -726,10 +726,20 @@ def tv_loss_bwd(x, g):
 
 
 def clock_sample():
-    """-> int64 [2] device tensor (shader-clock ticks, 100 MHz ticks) sampled on the current stream (ffvc_clock_sample)."""
-    out = torch.empty(2, dtype=torch.int64, device="cuda")
+    """-> int64 [8, 2] device tensor: per XCD (shader-clock ticks, 100 MHz ticks) sampled on the current stream."""
+    out = torch.empty(8, 2, dtype=torch.int64, device="cuda")
     _call("ffvc_clock_sample", out.data_ptr(), stream_ptr())
     return out
+
+
+def effective_clock_mhz(c0, c1):
+    """Average engine clock between two clock_sample() results: mean over the XCDs present in both."""
+    a, b = c0.cpu(), c1.cpu()
+    ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1])
+    if not bool(ok.any()):
+        return float("nan")
+    d = (b - a)[ok].double()
+    return float((d[:, 0] / d[:, 1]).mean() * 100.0)
 
 
 def sumsq(x, out):

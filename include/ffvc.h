@@ -335,8 +335,9 @@ int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int sh
 /* clip_grad_norm_ (main.py:833-834) without a host round trip: out[0] = min(1, max_norm / (sqrt(sumsq[0])*|grad_scale|
  * + 1e-6)) (feed it to ffvc_adam's dev_scale), out[1] = the total norm. */
 int ffvc_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* out, void* stream);
-/* out[0] = s_memtime (shader-clock ticks), out[1] = s_memrealtime (100 MHz ticks) sampled by a one-thread kernel on `stream`:
- * two samples around a region give its average effective engine clock (bench.py reports it next to the roofline fraction). */
+/* out: 16 x uint64 = per XCD x (0..7): out[2x] = s_memtime (shader-clock ticks), out[2x+1] = s_memrealtime (100 MHz ticks), sampled
+ * by one-thread workgroups on `stream` (the counters are per XCD; zeros = that XCD ran no sampling block).  Two samples around a
+ * region give its average effective engine clock per XCD (bench.py reports the mean next to the roofline fraction). */
 int ffvc_clock_sample(uint64_t* out, void* stream);
 /* nn.Dropout of the mapper MLPs / attention outputs (mlp_mixer_pytorch.py:20-22; vitgan.py:34-41,114,133):
  * y[i] = (residual ? residual[i] : 0) + (keep(seed, i) ? x[i] / (1 - p) : 0).  The mask is a counter-based hash of

@@ -151,3 +151,21 @@ def test_dp_world2_equals_single_process(cuda):
     err = (torch.from_numpy(res[0][1]) - torch.from_numpy(ref)).abs()[sig].max().item()
     assert err < 1e-4, f"parameter deviation {err}"        # (gradient check above is the strict one)
     assert abs(res[0][2] - ref_loss) < 1e-3 * abs(ref_loss) + 1e-6, (res[0][2], ref_loss)
+
+
+@pytest.mark.parametrize("kind", ["mlp_mixer", "vitgan"])
+def test_exchange_is_enqueued_under_the_backward_pass(cuda, kind):
+    """Single rank on a real RCCL communicator (FFVC_DP_FORCE=1): every slice of the gradient bucket except the slices of the LAST
+    gradient of the backward pass has its all-reduce finished before the last 2 % of backward (tools/dp_overlap.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFVC_DP_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_overlap.py"), kind, "4"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(r.stdout)
+    assert summary["dp"]["backend"] == "nccl" and summary["frac_bytes_early"] > 0.85

@@ -542,6 +542,5 @@ def test_clock_sample_reports_a_plausible_engine_clock(cuda):
         x = (x @ x).clamp(-1, 1)
     c1 = K.clock_sample()
     torch.cuda.synchronize()
-    d = (c1 - c0).tolist()
-    mhz = d[0] / d[1] * 100.0
-    assert d[1] > 0 and 300.0 < mhz < 2600.0, mhz
+    mhz = K.effective_clock_mhz(c0, c1)
+    assert int((c1[:, 1] > 0).sum()) >= 4 and 300.0 < mhz < 2600.0, (mhz, c0.tolist(), c1.tolist())
