@@ -37,6 +37,16 @@ namespace {
 // 3x3 conv with the haloed row tile: block tile 256 pixels x 128 output channels, 4 waves x (128 x 64), ONE stage
 // (X 33 KiB + W 16 KiB) so that two workgroups share a CU and alternate DMA / MFMA phases.
 // K order: kh (3) x 64-channel block (Cin/64) x kw (3); the X tile is (re)loaded only when (kh, block) changes.
+#ifdef FFVC_CR_TIMING
+// debug build (tools/cr_timing.py): s_memtime stamps of every wave of one workgroup over K steps 3..8 (two kw sweeps)
+__device__ unsigned long long cr_stamps[4][6][8];     // [wave][step - 3][event]
+#define CR_STAMP(ev)                                                                                          \
+  do {                                                                                                        \
+    if (blockIdx.x == 300 && lane == 0 && cr_step >= 3 && cr_step < 9) cr_stamps[wid][cr_step - 3][ev] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CR_STAMP(ev)
+#endif
 template <typename L, bool BUF, int EPI = ffvc_gemm_detail::EPI_GN>
 __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
                                                           const uint16_t* zero) {
@@ -93,14 +103,20 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
   unsigned char* sX = smem;
   unsigned char* sW = smem + XTILE;
   const int nblk = Cin / 64;
+  int cr_step = 0;
+  (void)cr_step;
   for (int kh = 0; kh < 3; ++kh) {
     for (int cb = 0; cb < nblk; ++cb) {
 #pragma unroll 1
-      for (int kw = 0; kw < 3; ++kw) {
+      for (int kw = 0; kw < 3; ++kw, ++cr_step) {
+        CR_STAMP(0);
         if (kw == 0) sx.issue(sX, kh, cb * 64, zero, tid);
         sw.issue(sW, (kh * 3 + kw) * Cin + cb * 64, p.K, zero, tid);
+        CR_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CR_STAMP(2);
         __syncthreads();
+        CR_STAMP(3);
         if constexpr (M16) {
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub) {
@@ -121,7 +137,9 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
                 for (int t = 0; t < MT; ++t) mma16_lo<L>(acc16[a][bh * MT + t], fa[a], fb[t]);
               __builtin_amdgcn_sched_barrier(0);      // keep the halves sequential: the scheduler must not hoist the next half's reads
             }
+            if (sub == 0) CR_STAMP(4);
           }
+          CR_STAMP(5);
         } else {
 #pragma unroll
           for (int sub = 0; sub < 4; ++sub) {
@@ -137,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
           }
         }
         __syncthreads();
+        CR_STAMP(6);
       }
     }
   }
@@ -324,6 +343,12 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   return 0;
 }
 
+#ifdef FFVC_CR_TIMING
+extern "C" int ffvc_debug_cr_stamps(unsigned long long* host_out) {   // debug builds only (tools/cr_timing.py)
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cr_stamps), sizeof(unsigned long long) * 4 * 6 * 8);
+}
+#endif
 #ifdef FFVC_G8_TIMING
 extern "C" int ffvc_debug_g8_stamps(unsigned long long* host_out) {   // debug builds only (tools/g8_timing.py)
   (void)hipDeviceSynchronize();
