@@ -172,6 +172,177 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
   }
 }
 
+
+// ---- 3x3 conv, haloed row tile, software-pipelined (round 3) -------------------------------------------------------------
+// conv_row_kernel above spends 59 % of its time outside MFMAs (tools/cr_timing.py, profiles/r03_conv_row_timing.txt): every K
+// step pays the DMA issue (100-190 cycles per 1-KiB piece, 13 pieces when the X tile is reloaded), the wait for the data, two
+// barriers and four exposed LDS round trips, and the second workgroup on the CU does not cover them.  Here ONE workgroup owns
+// the CU (4 waves = one per SIMD, 512 registers each) and the K steps form a pipeline, as in tools/probe kernel G:
+//   * X tile double-buffered (2 x 33 KiB), filter tile in a ring of three (3 x 16 KiB): W of step s+2 and the X tile of the next
+//     (kh, channel block) group stream in under the MFMAs of step s — 4 pieces after the barrier-free first half, the X pieces
+//     in the second half of the kw = 0 and kw = 1 steps; ONE barrier per step with a counted vmcnt (only this step's own four
+//     filter pieces may still be in flight);
+//   * fragments double-buffered in registers: the second 32-deep half of a step is fetched under the first half's MFMAs, the
+//     first half of step s+1 under the second half of step s (behind the barrier that publishes its tiles);
+//   * accumulators pinned to the AGPR file through inline-asm MFMAs (hipcc otherwise shuffles 16x16x32 accumulators between the
+//     two register files of a 512-register kernel, tools/probe/gemm_probe.hip).
+// Same tile geometry, DMA address generators, LDS images and epilogue as conv_row_kernel.
+// MEASURED (round 3, tools/cr_timing.py): a K step takes ~2500 cycles here against ~4500 in conv_row_kernel (two workgroups), i.e.
+// the pipeline works, but a half of 32 MFMAs (512 pipe cycles) still takes 750-1260 cycles because every LDS-DMA piece costs the
+// issuing wave ~100 cycles of address VALU + issue with nothing else on the SIMD to cover it, and with ONE workgroup per CU the
+// prologue (~6k cycles) and the row-store epilogue (~12k cycles of a 63k-cycle tile) are exposed: 635 vs 777 TFLOP/s at 256^2
+// 128->128, cfg2 step 148.8 vs 136.5 ms.  Kept behind FFVC_CONV_ROW2=1 for the next round (a persistent tile loop that overlaps
+// the epilogue with the next tile's first steps is what it needs), off by default.
+template <typename L>
+__device__ __forceinline__ void mma16_agpr(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b);
+template <>
+__device__ __forceinline__ void mma16_agpr<uint16_t>(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <>
+__device__ __forceinline__ void mma16_agpr<f16_t>(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <typename L, int EPI = ffvc_gemm_detail::EPI_GN>
+__global__ __launch_bounds__(256, 1) void conv_row2_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok) {
+  constexpr int MT = 4, BM = 256, BN = 128;
+  constexpr int XTILE = 264 * 128, WTILE = BN * 128;
+  constexpr int XOFF = 0, WOFF = 2 * XTILE;                 // [X0 | X1 | W0 | W1 | W2]; the epilogue pads alias X0
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l15 = lane & 15;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int W = p.conv_W, Cin = p.conv_Cin;
+  ConvRowDmaB sx;
+  KMajorDmaB<BN, 4> sw;
+#ifdef FFVC_CR_TIMING
+  if (blockIdx.x == 300 && lane == 0) cr_stamps[wid][0][5] = __builtin_amdgcn_s_memtime();
+#endif
+  sx.init((const uint16_t*)p.x, m0, p.conv_H, W, Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  sw.init((const uint16_t*)p.w + (int64_t)n0 * p.ldw, p.ldw, p.N - n0, tid);
+
+  f32x4_t acc[4][2 * MT];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2 * MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int xrow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int px = wm * 128 + t * 32 + l15;
+    const int Wt = W < 256 ? W : 256;
+    xrow[t] = (px / Wt) * (Wt + 2) + (px % Wt);
+  }
+  const int nblk = Cin / 64;
+  u32x4_t fw[2][4], fx[2][2 * MT];
+  auto read_frag = [&](int i, const unsigned char* sX, const unsigned char* sW, int kw, int sub, u32x4_t (&w4)[4], u32x4_t (&x8)[2 * MT]) {
+    // i = 0..11: the 8 X blocks first (every MFMA of a half needs them), then the 4 W blocks
+    if (i < 8) x8[i] = frag16_kmajor(sX, xrow[i >> 1] + 16 * (i & 1) + kw, sub, lane);
+    else w4[i - 8] = frag16_kmajor(sW, wn * 64 + (i - 8) * 16 + l15, sub, lane);
+  };
+
+  // prologue: X tile of group 0, filter tiles of steps 0 and 1 (K offsets in the [Cout][kh][kw][Cin] filter: (3 kh + kw) Cin + 64 cb)
+#pragma unroll
+  for (int j = 0; j < 9; ++j) sx.issue1(smem + XOFF, j, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sw.issue1(smem + WOFF, j, 0, p.K);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sw.issue1(smem + WOFF + WTILE, j, Cin, p.K);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 12; ++i) read_frag(i, smem + XOFF, smem + WOFF, 0, 0, fw[0], fx[0]);
+
+  int cr_step = 0;                                           // (debug stamps only)
+  (void)cr_step;
+  // One K step.  KW is compile-time (it selects which X pieces of the NEXT group travel in this step and where step s + 2's
+  // filter tile lies); wslot = s % 3 (ring slot of this step's filter tile), xcur / xnxt = the two X buffers, k2 = K offset of
+  // step s + 2 (< 0: none), (khn, cin) = next group (khn < 0: none), more = a step s + 1 exists.
+  auto step = [&](auto kw_tag, int wslot, const unsigned char* xcur, unsigned char* xnxt, int k2, int khn, int cin, bool more) {
+    constexpr int KW = decltype(kw_tag)::value;
+    const unsigned char* sW = smem + WOFF + wslot * WTILE;
+    const int s1 = wslot == 2 ? 0 : wslot + 1, s2 = wslot == 0 ? 2 : wslot - 1;     // (s + 1) % 3, (s + 2) % 3
+    unsigned char* wnext = smem + WOFF + s2 * WTILE;
+    // ---- first half: MFMAs (s, k 0..31) | fragments (s, k 32..63) | the four filter pieces of step s + 2
+    CR_STAMP(0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2 * MT; ++b) {
+        mma16_agpr<L>(acc[a][b], fw[0][a], fx[0][b]);
+        const int i = a * 8 + b;
+        if (i < 12) read_frag(i, xcur, sW, KW, 1, fw[1], fx[1]);
+        if (i >= 14 && i < 30 && ((i - 14) & 3) == 0 && k2 >= 0) sw.issue1(wnext, (i - 14) >> 2, k2, p.K);
+      }
+    // everything older than this step's own filter pieces has landed (W of step s + 1, the X pieces issued in earlier steps)
+    CR_STAMP(1);
+    if (k2 >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    CR_STAMP(2);
+    __builtin_amdgcn_s_barrier();
+    CR_STAMP(3);
+    // ---- second half: MFMAs (s, k 32..63) | fragments (s + 1, k 0..31) | X pieces of the next group (kw = 0: 0..4, kw = 1: 5..8)
+    const unsigned char* sXn = (KW == 2) ? (const unsigned char*)xnxt : xcur;
+    const unsigned char* sWn = smem + WOFF + s1 * WTILE;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2 * MT; ++b) {
+        mma16_agpr<L>(acc[a][b], fw[1][a], fx[1][b]);
+        const int i = a * 8 + b;
+        if (i < 12 && more) read_frag(i, sXn, sWn, KW == 2 ? 0 : KW + 1, 0, fw[0], fx[0]);
+        if constexpr (KW == 0) {
+          if (i >= 13 && i < 28 && ((i - 13) % 3) == 0 && khn >= 0) sx.issue1(xnxt, (i - 13) / 3, khn, cin);
+        } else if constexpr (KW == 1) {
+          if (i >= 13 && i < 25 && ((i - 13) % 3) == 0 && khn >= 0) sx.issue1(xnxt, 5 + (i - 13) / 3, khn, cin);
+        }
+      }
+    CR_STAMP(4);
+    ++cr_step;
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  int gpar = 0;                                              // parity of the group index: which X buffer is current
+  for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll 1
+    for (int cb = 0; cb < nblk; ++cb) {
+      const bool last = (kh == 2 && cb == nblk - 1);
+      const int cbn = cb + 1 < nblk ? cb + 1 : 0;
+      const int khn = last ? -1 : (cb + 1 < nblk ? kh : kh + 1);
+      const unsigned char* xcur = smem + XOFF + gpar * XTILE;
+      unsigned char* xnxt = smem + XOFF + (gpar ^ 1) * XTILE;
+      // a group is three steps, so the filter ring (three slots) is at slot 0 at the start of every group
+      step(K0{}, 0, xcur, xnxt, (kh * 3 + 2) * Cin + cb * 64, khn, cbn * 64, true);
+      step(K1{}, 1, xcur, xnxt, last ? -1 : (khn * 3 + 0) * Cin + cbn * 64, khn, cbn * 64, true);
+      step(K2{}, 2, xcur, xnxt, last ? -1 : (khn * 3 + 1) * Cin + cbn * 64, khn, cbn * 64, !last);
+      gpar ^= 1;
+    }
+  }
+#ifdef FFVC_CR_TIMING
+  if (blockIdx.x == 300 && lane == 0) cr_stamps[wid][0][6] = __builtin_amdgcn_s_memtime();
+#endif
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last MFMAs' results before the VALU reads them
+  __builtin_amdgcn_s_barrier();                              // every wave is done with the X tiles: the pads may alias X0
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
+  else
+    ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+#ifdef FFVC_CR_TIMING
+  if (blockIdx.x == 300 && lane == 0) cr_stamps[wid][0][7] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
 uint16_t* g_zero_page[16] = {nullptr};
 
 // run-time options (ffvc_set_option); -1 = not initialised (take the environment variable, else the default)
@@ -309,7 +480,27 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
         (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, true, EL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr2 = true;
       }
-      if (d.in_dtype == FFVC_F16) {
+      static int row2 = -1;
+      if (row2 < 0) {
+        const char* e = getenv("FFVC_CONV_ROW2");
+        row2 = e ? atoi(e) : 0;     // measured (profiles/r03_conv_row_timing.txt): 635 vs 777 TFLOP/s at 256^2 128->128, step 148.8 vs 136.5 ms
+                                    // -> the pipelined single-workgroup kernel is opt-in (FFVC_CONV_ROW2=1)
+        constexpr int lds2 = 2 * 264 * 128 + 3 * 128 * 128;
+        (void)hipFuncSetAttribute((const void*)conv_row2_kernel<uint16_t, EG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        (void)hipFuncSetAttribute((const void*)conv_row2_kernel<f16_t, EG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        (void)hipFuncSetAttribute((const void*)conv_row2_kernel<uint16_t, EL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        (void)hipFuncSetAttribute((const void*)conv_row2_kernel<f16_t, EL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+      }
+      if (row2 && buf) {       // the software-pipelined kernel: one workgroup per CU
+        constexpr int lds2 = 2 * 264 * 128 + 3 * 128 * 128;
+        if (d.in_dtype == FFVC_F16) {
+          if (!gnv) hipLaunchKernelGGL((conv_row2_kernel<f16_t, EL>), dim3(n_tiles), dim3(256), lds2, st, d, tiles_n, n_tiles, vec_ok);
+          else hipLaunchKernelGGL((conv_row2_kernel<f16_t, EG>), dim3(n_tiles), dim3(256), lds2, st, d, tiles_n, n_tiles, vec_ok);
+        } else {
+          if (!gnv) hipLaunchKernelGGL((conv_row2_kernel<uint16_t, EL>), dim3(n_tiles), dim3(256), lds2, st, d, tiles_n, n_tiles, vec_ok);
+          else hipLaunchKernelGGL((conv_row2_kernel<uint16_t, EG>), dim3(n_tiles), dim3(256), lds2, st, d, tiles_n, n_tiles, vec_ok);
+        }
+      } else if (d.in_dtype == FFVC_F16) {
         if (buf && !gnv) hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EL>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
         else if (buf) hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EG>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
         else hipLaunchKernelGGL((conv_row_kernel<f16_t, false, EG>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);

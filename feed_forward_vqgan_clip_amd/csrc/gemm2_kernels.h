@@ -29,6 +29,10 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_b
 // 64-bit per-lane addresses — half the address VALU per piece — and out-of-range rows / K tails / conv halo are simply an
 // offset beyond num_records (the hardware writes zeros), so no zero page and no select on pointers.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// The scalar offset of a buffer instruction is NOT part of the hardware's range check (raw buffers check voffset + inst_offset
+// against num_records), so an out-of-range piece keeps the wave-uniform scalar offset: a per-lane select on it (`ok ? so : 0`,
+// rounds 1-2) made hipcc wrap every LDS-DMA piece in a readfirstlane "waterfall" loop — the 100-190 cycles per piece that
+// tools/cr_timing.py measured in conv_row_kernel's DMA issue (profiles/r03_conv_row_timing.txt).
 constexpr uint32_t DMA_OOB = 0xFFFFFFF0u;
 constexpr int DMA_NUMREC = 0x7FFFFF00;            // every valid offset must stay below 2 GiB (launcher-checked)
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
@@ -270,8 +274,17 @@ struct ConvRowDmaB {
       const int iy = oy0 + seg[j] + kh - 1;
       const bool ok = colpart[j] >= 0 && (unsigned)iy < (unsigned)H;
       const uint32_t off = (uint32_t)(colpart[j] + (iy >> ups) * wincin) * 2u;
-      dma16bs(rs, ok ? off : DMA_OOB, ok ? so : 0u, tile + (4 * j + w) * 1024);
+      dma16bs(rs, ok ? off : DMA_OOB, so, tile + (4 * j + w) * 1024);
     }
+  }
+  // one piece (the pipelined kernel spreads a tile's nine pieces over two K steps)
+  __device__ __forceinline__ void issue1(unsigned char* tile, int j, int kh, int ci0) {
+    if (4 * j + w >= 33) return;        // wave-uniform: this piece lies beyond the 33-KiB tile (rows past the halo'd rows of a
+                                        // partly used last piece get zeros instead of an exec-masked skip: no divergence here)
+    const int iy = oy0 + seg[j] + kh - 1;
+    const bool ok = colpart[j] >= 0 && (unsigned)iy < (unsigned)H;
+    const uint32_t off = (uint32_t)(colpart[j] + (iy >> ups) * wincin) * 2u;
+    dma16bs(rs, ok ? off : DMA_OOB, (uint32_t)ci0 * 2u, tile + (4 * j + w) * 1024);
   }
 };
 
@@ -347,7 +360,7 @@ struct KMajorDmaB {
       dma16bs(rs, voff[j], so, tile + (NW * j + w) * 1024);
     } else {                 // K tail: chunks beyond kend read as zero
       const bool ok = k0 + kc + EPC <= kend;
-      dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? so : 0u, tile + (NW * j + w) * 1024);
+      dma16bs(rs, ok ? voff[j] : DMA_OOB, so, tile + (NW * j + w) * 1024);
     }
   }
   template <int J0, int J1>
@@ -363,7 +376,7 @@ struct KMajorDmaB {
     } else {
       const bool ok = k0 + kc + EPC <= kend;
 #pragma unroll
-      for (int j = 0; j < NP; ++j) dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? so : 0u, tile + (NW * j + w) * 1024);
+      for (int j = 0; j < NP; ++j) dma16bs(rs, ok ? voff[j] : DMA_OOB, so, tile + (NW * j + w) * 1024);
     }
   }
   __device__ __forceinline__ void issue(unsigned char* tile, int k0, int kend, const uint16_t*, int) { issue(tile, k0, kend); }
@@ -401,7 +414,7 @@ struct TransDmaB {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const bool ok = k0 + krow[j] < kend;
-        dma16bs(rs, ok ? voff[j] : DMA_OOB, ok ? so : 0u, tile + (NW * j + w) * 1024);
+        dma16bs(rs, ok ? voff[j] : DMA_OOB, so, tile + (NW * j + w) * 1024);
       }
     }
   }
@@ -451,7 +464,7 @@ struct ConvDmaB {
     const int iy = oy[j] + kh - 1, ix = ox[j] + kw - 1;
     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     const uint32_t off = (uint32_t)(pixo[j] + ((iy >> ups) * Win + (ix >> ups)) * Cin) * 2u;
-    dma16bs(rs, ok ? off : DMA_OOB, ok ? (uint32_t)ci0 * 2u : 0u, tile + (NW * j + w) * 1024);
+    dma16bs(rs, ok ? off : DMA_OOB, (uint32_t)ci0 * 2u, tile + (NW * j + w) * 1024);
   }
   template <int J0, int J1>
   __device__ __forceinline__ void issue2(unsigned char* tile, int k0, int kend) {

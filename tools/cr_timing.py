@@ -21,14 +21,19 @@ buf = (ctypes.c_ulonglong * (4 * 6 * 8))()
 lib = _lib.load()
 lib.ffvc_debug_cr_stamps.argtypes = [ctypes.c_void_p]
 print("rc", lib.ffvc_debug_cr_stamps(buf))
-ev = ["step start", "DMA issued", "vmcnt(0) passed", "barrier 1 passed", "sub 0 done", "sub 1 done", "barrier 2 passed"]
+row2 = os.environ.get("FFVC_CONV_ROW2", "1") != "0"
+ev = (["step start", "half 1 issued", "vmcnt passed", "barrier passed", "half 2 issued", "-", "-"] if row2 else
+      ["step start", "DMA issued", "vmcnt(0) passed", "barrier 1 passed", "sub 0 done", "sub 1 done", "barrier 2 passed"])
 for wv in range(4):
+    if row2:
+        k0, k1, k2 = (buf[(wv * 6) * 8 + e] for e in (5, 6, 7))
+        print(f"wave {wv}: kernel start -> main loop end {k1 - k0} cycles, epilogue {k2 - k1} cycles")
     base = buf[(wv * 6 + 0) * 8 + 0]
     print(f"wave {wv}: cycles since its step-3 start; per event (delta to previous event)")
     prev = base
     for st in range(6):
         row = []
-        for e in range(7):
+        for e in range(5 if row2 else 7):
             v = buf[(wv * 6 + st) * 8 + e]
             row.append(f"{ev[e]} {v - base} (+{v - prev})")
             prev = v
