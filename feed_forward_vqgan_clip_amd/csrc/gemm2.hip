@@ -343,6 +343,89 @@ __global__ __launch_bounds__(256, 1) void conv_row2_kernel(const ffvc_gemm_desc 
 #endif
 }
 
+
+// ---- 3x3 conv with a handful of output channels (the decoder's conv_out: 128 -> 3) -------------------------------------------
+// N = 3 wastes 125 of the 128 columns of every other tile (round 2: 1.4 ms at 256^2 x 64 images on the register-staged kernel,
+// 20 TFLOP/s).  The work is a stream: 1 GB of activations in, 50 MB out.  Same haloed X row tile as conv_row_kernel (one load per
+// (kernel row, 64-channel block), three kw taps served from it), the filter tile is 16 rows (rows >= N read as zeros), every wave
+// owns 64 pixels x one 16-wide MFMA column block; 36 KiB of LDS and < 64 registers -> four workgroups per CU hide the loads.
+template <typename L>
+__global__ __launch_bounds__(256, 4) void conv_row_n16_kernel(const ffvc_gemm_desc p, int n_tiles, const uint16_t* zero) {
+  constexpr int XTILE = 264 * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = tile * 256;
+  const int W = p.conv_W, Cin = p.conv_Cin;
+  ConvRowDmaB sx;
+  sx.init((const uint16_t*)p.x, m0, p.conv_H, W, Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  // filter tile: 16 rows x 128 B = two 1-KiB pieces (waves 0 and 1), K-major image of gemm2_kernels.h
+  const rsrc_t rsw = make_rsrc(p.w);
+  uint32_t voffw;
+  {
+    const int line = 4 * (wid & 1) + (lane >> 4);
+    const int cp = (lane & 15) ^ (line & 15);
+    const int row = 2 * line + (cp >> 3);
+    voffw = row < p.N ? (uint32_t)((int64_t)row * p.ldw + (cp & 7) * EPC) * 2u : DMA_OOB;
+  }
+  unsigned char* sX = smem;
+  unsigned char* sW = smem + XTILE;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int xrow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int px = wid * 64 + t * 32 + l15;
+    const int Wt = W < 256 ? W : 256;
+    xrow[t] = (px / Wt) * (Wt + 2) + (px % Wt);
+  }
+  const int nblk = Cin / 64;
+  for (int kh = 0; kh < 3; ++kh) {
+    for (int cb = 0; cb < nblk; ++cb) {
+#pragma unroll 1
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kw == 0) sx.issue(sX, kh, cb * 64, zero, tid);
+        if (wid < 2) dma16bs(rsw, voffw, (uint32_t)(((kh * 3 + kw) * Cin + cb * 64) * 2), sW + wid * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const u32x4_t fw = frag16_kmajor(sW, l15, sub, lane);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const u32x4_t fx = frag16_kmajor(sX, xrow[b >> 1] + 16 * (b & 1) + kw, sub, lane);
+            mma16_lo<L>(acc[b], fw, fx);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // lane: pixel m = 16 b + (lane & 15) of the wave's 64, output channels n = 4 (lane >> 4) .. + 3
+  const bool out32 = p.flags & FFVC_F_OUT_F32;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int m = m0 + wid * 64 + b * 16 + l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = 4 * g4 + i;
+      if (n >= p.N) continue;
+      const float v = acc[b][i] * p.alpha + (p.bias ? p.bias[n] : 0.0f);
+      if (out32) ((float*)p.y)[(int64_t)m * p.y_sm + n] = v;
+      else ElemTraits<L>::store((L*)p.y + (int64_t)m * p.y_sm + n, v);
+    }
+  }
+}
+
 uint16_t* g_zero_page[16] = {nullptr};
 
 // run-time options (ffvc_set_option); -1 = not initialised (take the environment variable, else the default)
@@ -377,6 +460,34 @@ inline bool m8(int64_t v) { return (v % 8) == 0; }
 // 1 = enqueued here, 0 = shape not eligible (caller falls back to gemm.hip), < 0 = launch error.
 int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if ((d.in_dtype != FFVC_BF16 && d.in_dtype != FFVC_F16) || (d.flags & FFVC_F_TR_SAFE)) return 0;
+  if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR && d.N <= 16) {
+    // a 3x3 conv with <= 16 output channels (conv_out): the narrow-N row-tile kernel
+    static int n16 = -1;
+    if (n16 < 0) {
+      const char* e = getenv("FFVC_CONV_N16");
+      n16 = e ? atoi(e) : 1;
+    }
+    const int W = d.conv_W;
+    const uint16_t* zero = zero_page();
+    const bool ok = n16 && zero && (W == 64 || W == 128 || (W >= 256 && W % 256 == 0)) && ((int64_t)d.conv_H * W) % 256 == 0 && d.batch == 1 &&
+                    d.split_k <= 1 && (d.M % 256) == 0 && (d.conv_Cin % 64) == 0 && d.K == 9 * d.conv_Cin && d.act == FFVC_ACT_NONE &&
+                    !d.residual && !d.aux && d.y_mi == 0 && (d.ldw % 8) == 0 && ((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.w % 16) == 0 &&
+                    !(d.flags & (FFVC_F_GN_SUMS | FFVC_F_COLSUM | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_MUL_ACT_GRAD |
+                                 FFVC_F_WRITE_PREACT | FFVC_F_BIAS_ALONG_M)) &&
+                    g8_offsets_ok<FFVC_OP_CONV3X3>(d);
+    if (ok) {
+      const int n_tiles = d.M / 256;
+      constexpr int lds = 264 * 128 + 2048;
+      if (d.in_dtype == FFVC_F16) hipLaunchKernelGGL((conv_row_n16_kernel<f16_t>), dim3(n_tiles), dim3(256), lds, st, d, n_tiles, zero);
+      else hipLaunchKernelGGL((conv_row_n16_kernel<uint16_t>), dim3(n_tiles), dim3(256), lds, st, d, n_tiles, zero);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        ffvc_set_error("conv_row_n16 launch failed: %s", hipGetErrorString(e));
+        return -(int)e - 1000;
+      }
+      return 1;
+    }
+  }
   if (!vec_ok || (d.N % 4) != 0) return 0;     // this path carries the vectorised epilogue only
   // the DMA moves whole 16-byte chunks from 16-byte aligned addresses
   if (((uintptr_t)d.x % 16) || ((uintptr_t)d.w % 16)) return 0;

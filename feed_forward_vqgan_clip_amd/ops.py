@@ -143,6 +143,7 @@ def _grad_buf(p):
     return p.grad
 
 
+_SK_TARGET = int(os.environ.get("FFVC_SK_TARGET", "768"))  # A/B: workgroups a small-output weight gradient is split into
 _WGRAD_SK = int(os.environ.get("FFVC_WGRAD_SK", "0"))     # A/B: cap of the split-K factor of the 256x256-tile wgrads
 
 
@@ -156,7 +157,7 @@ def _split_k(n_out, k_out, red, bk, big_tiles=False):
     tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
     if tiles >= 512:
         return 1
-    return max(1, min((768 + tiles - 1) // tiles, red // (8 * bk)))
+    return max(1, min((_SK_TARGET + tiles - 1) // tiles, red // (8 * bk)))
 
 
 def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):

@@ -170,6 +170,29 @@ def test_conv3x3(cuda, dt, ups):
     assert _rel(y, ref) < LOTOL[dt]
 
 
+@pytest.mark.parametrize("W,Cin,Cout,ups,out32", [(64, 128, 3, False, True), (128, 64, 3, False, False), (256, 128, 3, False, True),
+                                                  (128, 128, 5, True, True), (512, 64, 16, False, False)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_conv_narrow_output_kernel(cuda, W, Cin, Cout, ups, out32, dt):
+    """conv_row_n16_kernel (the decoder's conv_out, 128 -> 3; taming Decoder.conv_out): <= 16 output channels on the haloed row
+    tile with a 16-row filter tile, vs F.conv2d incl. borders, bias, fp32 / 16-bit output and the fused 2x upsample; the generic
+    path (FFVC_CONV_N16=0 is process-wide, so compare against the reference instead) must agree too."""
+    B, H = (1, min(W, 128)) if W >= 128 else (2, 64)
+    Hin, Win = (H // 2, W // 2) if ups else (H, W)
+    x = _mk((B, Hin, Win, Cin), dt, cuda, 1)
+    w = _mk((Cout, 3, 3, Cin), dt, cuda, 2, 0.05)
+    b = _mk((Cout,), torch.float32, cuda, 3)
+    y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32 if out32 else dt, device=cuda)
+    K.gemm(x, w, y, B * H * W, Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=b, conv=(H, W, Cin),
+           flags=K.F_UPSAMPLE2X if ups else 0)
+    xn = x.double().permute(0, 3, 1, 2)
+    if ups:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xn, w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(y).all()
+    assert _rel(y, ref) < (2e-5 if out32 else LOTOL[dt]) * (10 if out32 and dt == torch.bfloat16 else 1) + (0 if out32 else 0)
+
+
 def test_bad_args_raise(cuda):
     x = torch.zeros(8, 8, dtype=torch.bfloat16, device=cuda)
     y = torch.zeros(8, 8, dtype=torch.bfloat16, device=cuda)
