@@ -141,12 +141,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 
 // y[i] (+)= sum_s slab[s][i]  — combine of split-K partial slabs (plain vector stores instead of scalar fp32
 // atomics, each of which is its own fabric transaction)
+// NS > 0: slab count fixed at compile time — every slab's 16-byte load of an element is in flight before the first add
+// (a runtime loop issued them one by one: 2.4 TB/s on the 4-slab weight-gradient reduces, round 2); NS == 0: any count.
+template <int NS>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ y,
                                                           int64_t n, int nslab, int accumulate) {
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4_t a = accumulate ? load4(y + i * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int s2 = 0; s2 < nslab; ++s2) a += load4(slabs + (int64_t)s2 * n + i * 4);
+    if constexpr (NS > 0) {
+      f32x4_t v[NS];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) v[s2] = load4(slabs + (int64_t)s2 * n + i * 4);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) a += v[s2];
+    } else {
+      for (int s2 = 0; s2 < nslab; ++s2) a += load4(slabs + (int64_t)s2 * n + i * 4);
+    }
     store4(y + i * 4, a);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -609,6 +620,31 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ x, fl
     a = wave_sum(a);
     if (lane == 0) atomicAdd(out + (r % period), a);
   }
+}
+
+// The same sums with one wave per (output index o, chunk of the rows o, o + period, ... that share it): the wave keeps its sum
+// in registers across its rows (16-byte loads, two rows in flight) and issues ONE atomic — the row-per-wave form above issues
+// rows / period same-address atomics per output (256 at the token-mixing bias gradients) and 8-byte loads.
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_grouped_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                             int cols, int period, int chunks, int rows_per_chunk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int o = (int)(wv % period), ch = (int)(wv / period);
+  if (ch >= chunks) return;
+  const int64_t per = rows / period;                 // rows that share one output
+  const int64_t b0 = (int64_t)ch * rows_per_chunk, b1 = min(per, b0 + rows_per_chunk);
+  float a = 0.f;
+  for (int64_t b = b0; b < b1; ++b) {
+    const T* px = x + (b * period + o) * (int64_t)cols;
+    for (int c = lane * 8; c < cols; c += 512) {
+      const f32x8 v = load8(px + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += v.v[j];
+    }
+  }
+  a = wave_sum(a);
+  if (lane == 0) atomicAdd(out + o, a);
 }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ s, int64_t ss, float* __restrict__ d,
@@ -1159,6 +1195,22 @@ extern "C" int ffvc_rowsum(const void* x, int dtype, float* out, int64_t rows, i
       return (int)e;
     }
   }
+  if (dtype != FFVC_F32 && (cols % 8) == 0 && (rows % period) == 0 && rows / period >= 8 && ((uintptr_t)x % 16) == 0) {
+    const int64_t per = rows / period;
+    int chunks = (int)((4096 + period - 1) / period);            // ~4096 waves in flight
+    if (chunks > per / 4) chunks = (int)(per / 4);
+    if (chunks < 1) chunks = 1;
+    const int rpc = (int)((per + chunks - 1) / chunks);
+    chunks = (int)((per + rpc - 1) / rpc);
+    const int64_t waves = (int64_t)period * chunks;
+    DISPATCH_DT(dtype, T, {
+      if constexpr (sizeof(T) == 2)
+        hipLaunchKernelGGL((rowsum_grouped_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const T*)x, out, rows, cols,
+                           period, chunks, rpc);
+    });
+    FFVC_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_DT(dtype, T, hipLaunchKernelGGL((rowsum_kernel<T>), dim3(ew_grid(rows, 4)), dim3(256), 0, st, (const T*)x,
                                            out, rows, cols, period));
   FFVC_LAUNCH_CHECK();
@@ -1209,8 +1261,15 @@ extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nsl
   FFVC_CHECK_ARG(slabs && y && n > 0 && nslab > 0, "ffvc_slab_reduce: bad args");
   FFVC_CHECK_ARG(((uintptr_t)slabs % 16) == 0 && ((uintptr_t)y % 16) == 0 && (n % 4) == 0,
                  "ffvc_slab_reduce: needs 16-byte aligned buffers and n %% 4 == 0");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, slabs, y, n, nslab,
-                     accumulate);
+  const dim3 grid(ew_grid(n / 4, 256));
+  hipStream_t st = (hipStream_t)stream;
+  switch (nslab) {
+    case 2: hipLaunchKernelGGL(slab_reduce_kernel<2>, grid, dim3(256), 0, st, slabs, y, n, nslab, accumulate); break;
+    case 3: hipLaunchKernelGGL(slab_reduce_kernel<3>, grid, dim3(256), 0, st, slabs, y, n, nslab, accumulate); break;
+    case 4: hipLaunchKernelGGL(slab_reduce_kernel<4>, grid, dim3(256), 0, st, slabs, y, n, nslab, accumulate); break;
+    case 8: hipLaunchKernelGGL(slab_reduce_kernel<8>, grid, dim3(256), 0, st, slabs, y, n, nslab, accumulate); break;
+    default: hipLaunchKernelGGL(slab_reduce_kernel<0>, grid, dim3(256), 0, st, slabs, y, n, nslab, accumulate); break;
+  }
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -455,3 +455,32 @@ def test_tokmix_fused_autograd_matches_unfused(cuda, dt):
     assert len(g1) == 6
     for k in g1:
         assert _rel(g1[k], g0[k]) < tol, k
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols,period", [(64 * 256, 1024, 256), (16 * 96, 72, 96), (40, 24, 8), (7 * 5, 16, 5)])
+def test_rowsum_grouped_and_row_forms(cuda, dt, rows, cols, period):
+    """ffvc_rowsum: out[r % period] (+)= sum_c x[r, c] (token-mixing bias gradients, mlp_mixer_pytorch.py:28) — the grouped form
+    (one wave per output and row chunk, 16-bit inputs) and the row-per-wave form, with and without accumulate."""
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(dt).cuda()
+    ref = x.double().sum(1).view(-1, period).sum(0)
+    out = torch.full((period,), 3.0, device="cuda")
+    K.rowsum(x, out, period, accumulate=True)
+    tol = 2e-5 * max(1.0, float(ref.abs().max())) * (cols * rows / period) ** 0.5
+    assert float((out.double().cpu() - (ref.cpu() + 3.0)).abs().max()) < tol
+    K.rowsum(x, out, period, accumulate=False)
+    assert float((out.double().cpu() - ref.cpu()).abs().max()) < tol
+
+
+@pytest.mark.parametrize("nslab", [1, 2, 3, 4, 5, 8])
+def test_slab_reduce_every_specialisation(cuda, nslab):
+    g = torch.Generator().manual_seed(nslab)
+    slabs = torch.randn(nslab, 300, 44, generator=g).cuda()
+    y = torch.randn(300, 44, generator=g).cuda()
+    want = y.double() + slabs.double().sum(0)
+    from feed_forward_vqgan_clip_amd.kernels import _call, stream_ptr
+    _call("ffvc_slab_reduce", slabs.data_ptr(), y.data_ptr(), 300 * 44, nslab, 1, stream_ptr())
+    assert float((y.double() - want).abs().max()) < 1e-5
+    _call("ffvc_slab_reduce", slabs.data_ptr(), y.data_ptr(), 300 * 44, nslab, 0, stream_ptr())
+    assert float((y.double() - slabs.double().sum(0)).abs().max()) < 1e-5
