@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(
                                                      XT* __restrict__ dx, float* __restrict__ part_g,
                                                      float* __restrict__ part_b, int64_t rows, int dim,
                                                      int rows_per_block, int acc_mode, DYT* __restrict__ dx_lo,
-                                                     int64_t pstride) {
+                                                     int64_t pstride, int ln_plain_combine) {
   constexpr int NIT = MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] when partials requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(
   float ag[MAXE], ab[MAXE];
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) ag[i] = ab[i] = 0.f;
-  if (want_p) {
+  if (want_p && !ln_plain_combine) {
     for (int i = threadIdx.x; i < 2 * dim; i += 64 * NWB) ln_smem[i] = 0.f;
     __syncthreads();
   }
@@ -168,6 +168,28 @@ __global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(
         if (dx_lo) st_vec<VEC>(dx_lo + row * dim + idx, o);   // bf16 copy for the GEMM that consumes this gradient
       }
     }
+  }
+  if (want_p && ln_plain_combine) {
+    // every wave parks its column sums in its own LDS rows with plain vector stores ([wave][2][dim]); the column loop below adds
+    // the NWB rows — the LDS float atomics this replaces serialise per lane (32 ds_add_f32 per lane and wave)
+    float* mine = ln_smem + (size_t)wave * 2 * dim;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) {
+        st_vec<VEC>(mine + idx, &ag[k * VEC]);
+        st_vec<VEC>(mine + dim + idx, &ab[k * VEC]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * dim; i += 64 * NWB) {
+      float t = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NWB; ++w2) t += ln_smem[(size_t)w2 * 2 * dim + i];
+      if (acc_mode) atomicAdd((i < dim ? part_g : part_b - dim) + i, t);
+      else (i < dim ? part_g : part_b - dim)[(int64_t)blockIdx.x * pstride + i] = t;
+    }
+    return;
   }
   if (want_p) {
 #pragma unroll
@@ -837,7 +859,13 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
   hipStream_t st = (hipStream_t)stream;
   const int rpb = ln_rows_per_block();
   const int grid = ffvc_layernorm_bwd_blocks(rows);
-  const size_t smem = part_g ? 2 * (size_t)dim * sizeof(float) : 0;
+  static int plain_opt = -1;
+  if (plain_opt < 0) {
+    const char* e = getenv("FFVC_LN_PLAIN");
+    plain_opt = e ? atoi(e) : 1;
+  }
+  const int plain = (plain_opt && part_g) ? 1 : 0;           // per-wave LDS rows + plain stores instead of LDS float atomics
+  const size_t smem = part_g ? (plain ? 4 : 1) * 2 * (size_t)dim * sizeof(float) : 0;
   const bool v4 = (dim % 4) == 0;
   const int64_t pstride = acc_mode == 2 ? 2 * (int64_t)dim : (int64_t)dim;   // 2: [blocks][dgamma row | dbeta row]
   if (acc_mode == 2) acc_mode = 0;
@@ -853,7 +881,7 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
     DISPATCH_DT(dy_dtype, DYT, DISPATCH_DT(x_dtype, XT, {
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16, 16>), dim3(grid16), dim3(1024), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows, dim,
-                                     rpb16, acc_mode, (DYT*)dx_lo, (int64_t)dim);
+                                     rpb16, acc_mode, (DYT*)dx_lo, (int64_t)dim, 0);
                 }));
     FFVC_LAUNCH_CHECK();
     return 0;
@@ -862,15 +890,15 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
                 if (v4 && dim <= 1024)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT, 16>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride, plain);
                 else if (v4)
                   hipLaunchKernelGGL((ln_bwd_kernel<4, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride, plain);
                 else
                   hipLaunchKernelGGL((ln_bwd_kernel<1, DYT, XT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy,
                                      (const XT*)x, gamma, mean, rstd, (const XT*)dres, (XT*)dx, part_g, part_b, rows,
-                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride);
+                                     dim, rpb, acc_mode, (DYT*)dx_lo, pstride, plain);
               }));
   FFVC_LAUNCH_CHECK();
   return 0;
