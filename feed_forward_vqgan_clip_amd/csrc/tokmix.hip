@@ -229,6 +229,15 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
 
 // Backward, hidden part: recompute pre = W1 xn + b1 and g = W2^T dy chunk by chunk; write h = gelu(pre) and
 // dh = g * gelu'(pre) as [B][O][D] (16-bit) for the weight-gradient GEMMs and the dx GEMM.
+#ifdef FFVC_TM_TIMING
+__device__ unsigned long long tm_stamps[8][6][8];      // [wave][chunk - 4][event], workgroup (1, 7)
+#define TM_STAMP(ev)                                                                                                   \
+  do {                                                                                                                 \
+    if (blockIdx.x == 1 && blockIdx.y == 7 && lane == 0 && c >= 4 && c < 10) tm_stamps[wid][c - 4][ev] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define TM_STAMP(ev)
+#endif
 template <typename L, int T_>
 __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ dy,
                                                                    const uint16_t* __restrict__ w1, const float* __restrict__ b1,
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_
     dm.issueA(st + HALF, rs2, (uint32_t)c * (TM_OC * T_ * 2));
   };
 #pragma unroll
-  for (int c = 0; c < NST - 1; ++c)
+  for (int c = 0; c < NST; ++c)
     if (c < NC) issue(c);
 
   const int64_t out0 = (int64_t)b * O * D;
@@ -287,64 +296,156 @@ __global__ __launch_bounds__(512, 2) void tokmix_bwd_hidden_kernel(const uint16_
         }
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
-        if ((lane & 31) == 0) atomicAdd(db1 + c * TM_OC + (row & 31), sum);   // (2 extra vm ops per flush: the counted
-      }                                                                        //  waits below stay conservative)
+        // scalar base + 32-bit lane offset, spelled out: left to the compiler the loop-invariant per-lane 64-bit address is
+        // hoisted, spilled, and reloaded from scratch behind a vmcnt(0) that drains the LDS-DMA ring every chunk
+        if ((lane & 31) == 0) {
+          const float* base = db1 + __builtin_amdgcn_readfirstlane(c) * TM_OC;
+          asm volatile("global_atomic_add_f32 %0, %1, %2" ::"v"((uint32_t)(row & 31) * 4u), "v"(sum), "s"(base) : "memory");
+        }                      // (2 extra vm ops per flush: the counted waits below stay conservative)
+      }
     }
   };
 
-  for (int c = 0; c < NC; ++c) {
-    // vmcnt retires in issue order and counts the flush stores too.  Issued after chunk c's pieces: the flush of iteration
-    // c-2 (4 stores, c >= 3), chunk c+1 (PPC pieces), the flush of iteration c-1 (4 stores, c >= 2).
-    const bool more = c + 1 < NC;
-    if (c >= 3) {
-      if (more) wait_vm<PPC + 8>(); else wait_vm<8>();
-    } else if (c == 2) {
-      if (more) wait_vm<PPC + 4>(); else wait_vm<4>();
-    } else {
-      if (more) wait_vm<PPC>(); else wait_vm<0>();
+  // Software pipeline over the chunks: iteration c runs the erf-GELU / staging VALU work of chunk c INTERLEAVED with the
+  // MFMAs of chunk c+1 (into the other accumulator pair), so the matrix pipe works under the VALU phase instead of after
+  // it (measured before: ~2200 cycles of MFMA then ~2500-3000 cycles of VALU per chunk, both waves of a SIMD in lockstep).
+  // Ring: reading c+1, landing c+2, issuing c+3 into the slot of c (whose MFMAs every wave finished before the barrier).
+  auto mfma_k = [&](int s, const unsigned char* s1, const unsigned char* s2, f32x16_t& n1, f32x16_t& n2) {
+    mma_lo<L>(n1, fragA<T_>(s1, l31, s, hh), xf[s]);
+    mma_lo<L>(n2, fragA<T_>(s2, l31, s, hh), yf[s]);
+  };
+  auto gelu_pair = [&](int r, const f32x16_t& a1, const f32x16_t& a2, unsigned char* ob, const_f32p bc) {
+    f32x2_t pre, cdf, e;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ru = r + u;
+      const float blo = bc[8 * (ru >> 2) + (ru & 3)], bhi = bc[8 * (ru >> 2) + 4 + (ru & 3)];
+      pre[u] = a1[ru] + (hh ? bhi : blo);
     }
+    gelu_parts_fast2(pre, cdf, e);
+    const f32x2_t hv = pre * cdf;
+    const f32x2_t dv = f32x2_t{a2[r], a2[r + 1]} * (cdf + pre * 0.39894228040143267794f * e);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ru = r + u;
+      const int ol = 8 * (ru >> 2) + 4 * hh + (ru & 3);
+      const uint32_t pk = lo_pack2<L>(hv[u], dv[u]);
+      *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk & 0xffffu);
+      *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk >> 16);
+    }
+  };
+  f32x16_t accA1, accA2, accB1, accB2;
+  // chunk 0's MFMAs ahead of the loop
+  if (NC >= 3) wait_vm<2 * PPC>(); else if (NC == 2) wait_vm<PPC>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accA1[i] = accA2[i] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < NK1; ++s) mfma_k(s, smem, smem + HALF, accA1, accA2);
+
+  auto body = [&](auto has_next, int c, f32x16_t& c1, f32x16_t& c2, f32x16_t& n1, f32x16_t& n2) {
+    constexpr bool NEXT = decltype(has_next)::value;
+    TM_STAMP(0);
+    if constexpr (NEXT) {
+      // chunk c+1 must have landed.  vmcnt retires in issue order and counts the flush stores too; issued after chunk
+      // c+1's pieces: the flush of iteration c-2 (4 stores, c >= 3), chunk c+2 (PPC pieces), the flush of iteration c-1
+      // (4 stores, c >= 2)
+      const bool more = c + 2 < NC;
+      if (c >= 3) {
+        if (more) wait_vm<PPC + 8>(); else wait_vm<8>();
+      } else if (c == 2) {
+        if (more) wait_vm<PPC + 4>(); else wait_vm<4>();
+      } else {
+        if (more) wait_vm<PPC>(); else wait_vm<0>();
+      }
+    }
+    TM_STAMP(1);
     __builtin_amdgcn_s_barrier();
-    if (c + NST - 1 < NC) issue(c + NST - 1);
+    TM_STAMP(2);
+    if (c + NST < NC) issue(c + NST);          // into chunk c's slot
+    TM_STAMP(3);
     if (c > 0) flush(c - 1);                   // staged by everyone before this barrier
-    const unsigned char* s1 = smem + (c % NST) * STAGE;
-    const unsigned char* s2 = s1 + HALF;
-    f32x16_t a1, a2;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a1[i] = a2[i] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NK1; ++s) {
-      mma_lo<L>(a1, fragA<T_>(s1, l31, s, hh), xf[s]);
-      mma_lo<L>(a2, fragA<T_>(s2, l31, s, hh), yf[s]);
-    }
+    TM_STAMP(4);
     unsigned char* ob = outb + (c & 1) * OUTB;
     // the chunk's 32 biases come through SCALAR loads (wave-uniform addresses): an ordinary vector load here would make
     // hipcc drain the LDS-DMA ring with vmcnt(0) at its first use
     const const_f32p bc = (const_f32p)(b1 + __builtin_amdgcn_readfirstlane(c) * TM_OC);
+    if constexpr (NEXT) {
+      const unsigned char* s1 = smem + ((c + 1) % NST) * STAGE;
+      const unsigned char* s2 = s1 + HALF;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {          // two hidden rows at a time: the erf / pdf polynomial runs on v_pk_*_f32
-      f32x2_t pre, cdf, e;
+      for (int i = 0; i < 16; ++i) n1[i] = n2[i] = 0.0f;
+      constexpr int KPG = NK1 / 8;             // k-steps of the next chunk per GELU pair
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ru = r + u;
-        const float blo = bc[8 * (ru >> 2) + (ru & 3)], bhi = bc[8 * (ru >> 2) + 4 + (ru & 3)];
-        pre[u] = a1[ru] + (hh ? bhi : blo);
+      for (int r = 0; r < 16; r += 2) {        // two hidden rows at a time: the erf / pdf polynomial runs on v_pk_*_f32
+        // the next chunk's fragments are read one VALU block ahead of the MFMAs that consume them: the LDS latency hides
+        // under the GELU arithmetic instead of sitting in front of every MFMA (one k-step = 8 VGPRs in flight)
+        static_assert(KPG == 1 || KPG == 2, "k-steps per GELU pair");
+        const int s0 = (r / 2) * KPG;
+        u32x4_t f0 = fragA<T_>(s1, l31, s0, hh), f1 = fragA<T_>(s2, l31, s0, hh);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x2_t pre, cdf, e;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int ru = r + u;
+          const float blo = bc[8 * (ru >> 2) + (ru & 3)], bhi = bc[8 * (ru >> 2) + 4 + (ru & 3)];
+          pre[u] = c1[ru] + (hh ? bhi : blo);
+        }
+        gelu_parts_fast2(pre, cdf, e);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_lo<L>(n1, f0, xf[s0]);
+        mma_lo<L>(n2, f1, yf[s0]);
+        if constexpr (KPG == 2) {
+          f0 = fragA<T_>(s1, l31, s0 + 1, hh);
+          f1 = fragA<T_>(s2, l31, s0 + 1, hh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2_t hv = pre * cdf;
+        const f32x2_t dv = f32x2_t{c2[r], c2[r + 1]} * (cdf + pre * 0.39894228040143267794f * e);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int ru = r + u;
+          const int ol = 8 * (ru >> 2) + 4 * hh + (ru & 3);
+          const uint32_t pk = lo_pack2<L>(hv[u], dv[u]);
+          *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk & 0xffffu);
+          *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk >> 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KPG == 2) {
+          mma_lo<L>(n1, f0, xf[s0 + 1]);
+          mma_lo<L>(n2, f1, yf[s0 + 1]);
+        }
       }
-      gelu_parts_fast2(pre, cdf, e);
-      const f32x2_t hv = pre * cdf;
-      const f32x2_t dv = f32x2_t{a2[r], a2[r + 1]} * (cdf + pre * 0.39894228040143267794f * e);
+    } else {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ru = r + u;
-        const int ol = 8 * (ru >> 2) + 4 * hh + (ru & 3);
-        const uint32_t pk = lo_pack2<L>(hv[u], dv[u]);
-        *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk & 0xffffu);
-        *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(pk >> 16);
-      }
+      for (int r = 0; r < 16; r += 2) gelu_pair(r, c1, c2, ob, bc);
+    }
+    TM_STAMP(6);
+  };
+  {
+    std::true_type yes;
+    std::false_type no;
+    int c = 0;
+    for (; c + 2 < NC; c += 2) {
+      body(yes, c, accA1, accA2, accB1, accB2);
+      body(yes, c + 1, accB1, accB2, accA1, accA2);
+    }
+    if (c + 1 < NC) {
+      body(yes, c, accA1, accA2, accB1, accB2);
+      body(no, c + 1, accB1, accB2, accA1, accA2);
+    } else {
+      body(no, c, accA1, accA2, accB1, accB2);
     }
   }
   __syncthreads();
   flush(NC - 1);
 }
+#ifdef FFVC_TM_TIMING
+extern "C" int ffvc_debug_tm_stamps(unsigned long long* host_out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tm_stamps), sizeof(unsigned long long) * 8 * 6 * 8);
+}
+#endif
 
 const uint16_t* tm_zero_page() {
   static uint16_t* page[16] = {nullptr};
