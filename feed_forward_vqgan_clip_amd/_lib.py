@@ -82,6 +82,8 @@ class GemmDesc(Structure):
         ("gn_hw", c_int32),
         ("gn_cpg", c_int32),
         ("colsum", c_void_p),
+        ("sk_ws", c_void_p),
+        ("sk_cnt", c_void_p),
     ]
 
 
@@ -100,6 +102,11 @@ _SIGNATURES = {
                                    c_int, c_float, c_void_p]),
     "ffvc_attn_small_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ffvc_attn_tiny_supported": (c_int, [c_int, c_int]),
+    "ffvc_attn_tiny_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+                                   c_int64, c_int64, c_float, c_void_p]),
+    "ffvc_attn_tiny_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                                   c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "ffvc_attn_flash_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ffvc_attn_flash_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_float, c_int, c_void_p]),

@@ -46,6 +46,7 @@ class ParamArena:
             p._ffvc_arena = self
         self._index = {id(p): i for i, p in enumerate(ps)}
         self._packs = []          # (Weights, param index) needing a transposed shadow
+        self._padded = []         # (Weights, flat shadow view) whose GEMM-side shadow is a zero-padded copy
         self._grad_cbs = []
         self._tplan = None
         module._ffvc_arena = self
@@ -56,11 +57,25 @@ class ParamArena:
         o = self.offsets[i]
         return self.shadow[o:o + p.numel()].view(p.shape)
 
-    def make_weights(self, weight, bias):
-        """Weights pack for a trainable [N, K, ...] parameter (Conv1d k=1 weights are viewed as [N, K])."""
-        sh = self.shadow_of(weight).view(weight.shape[0], -1)
-        sht = torch.empty(sh.shape[1], sh.shape[0], dtype=self.cdt, device=sh.device)
-        W = Weights(weight, bias, sh, sht, on_grad=self._on_grad)
+    def make_weights(self, weight, bias, pad_n=0, pad_k=0):
+        """Weights pack for a trainable [N, K, ...] parameter (Conv1d k=1 weights are viewed as [N, K]).
+
+        pad_n / pad_k: the GEMM-side shadows get that many extra all-zero rows / columns (W.N, W.K are the PADDED sizes), for
+        layers whose natural width leaves rows off the 16-byte grid the LDS-DMA kernels need (VitGAN: 6 heads x 170 = 1020
+        channels, 3060-wide qkv).  Activations then carry zero pad columns; the master weight and its gradient keep their
+        shape (ops._wgrad contracts only the real rows / columns)."""
+        flat = self.shadow_of(weight).view(weight.shape[0], -1)
+        if pad_n or pad_k:
+            if bias is not None and pad_n:
+                raise ValueError("make_weights: row padding of a layer with a bias is not supported")
+            N, Kd = flat.shape
+            sh = torch.zeros(N + pad_n, Kd + pad_k, dtype=self.cdt, device=flat.device)
+            sht = torch.zeros(Kd + pad_k, N + pad_n, dtype=self.cdt, device=flat.device)
+            W = Weights(weight, bias, sh, sht, on_grad=self._on_grad)
+            self._padded.append((W, flat))
+        else:
+            sht = torch.empty(flat.shape[1], flat.shape[0], dtype=self.cdt, device=flat.device)
+            W = Weights(weight, bias, flat, sht, on_grad=self._on_grad)
         self._packs.append(W)
         return W
 
@@ -68,6 +83,9 @@ class ParamArena:
         """Re-derive the shadows from the fp32 masters (after load_state_dict / an optimizer step)."""
         if cast and self.cdt != torch.float32:
             K.cast_into(self.params, self.shadow)
+        for W, flat in self._padded:            # padded GEMM-side copies (zero rows / columns stay zero)
+            N, Kd = flat.shape
+            K.copy2d(flat, Kd, N, Kd, W.K, self.cdt, out=W.sh)
         if self._packs and self.shadow.is_cuda:
             if self._tplan is None or self._tplan.n != len(self._packs):
                 self._tplan = K.TransposePlan([(W.sh, W.sht) for W in self._packs])

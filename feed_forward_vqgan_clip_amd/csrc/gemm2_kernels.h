@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -624,6 +626,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // MFMA shape: 16x16x32 for K-major / implicit-im2col operands (fragment = one 16-byte read per 16 rows x 32 k), 32x32x16
   // where an operand is reduction-major (its fragments come through ds_read_b64_tr_b16 in the 32x32 arrangement)
   constexpr bool M16 = FFVC_MFMA16 && XMODE != FFVC_OP_TRANS && WMODE != FFVC_OP_TRANS;
+  constexpr bool SKFIX = M16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM == 128 && BN == 128;
   f32x16_t acc[M16 ? 1 : 2][M16 ? 1 : MT];
   f32x4_t acc16[M16 ? 4 : 1][M16 ? 2 * MT : 1];
   if constexpr (M16) {
@@ -766,6 +769,63 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
         }
         compute(cur, cur + XTILE, [](int) {});
       }
+    }
+  }
+  // In-kernel split-K (under-filled grids, launch2 decides): every K slice parks its fp32 accumulators in accumulator order
+  // (16 bytes per lane, fully coalesced), the LAST workgroup to arrive on the tile sums all slices in slice order (the result
+  // does not depend on which one that was) and carries on into the ordinary epilogue; the others are done.
+  // The slices of a tile may run on different XCDs, whose L2s are not coherent with each other: the partial tiles therefore
+  // travel with system-scope accesses (volatile = sc0 sc1: written through to / read from the memory side) and the ticket is
+  // a device-scope atomic.  A release fence instead (buffer_wbl2: write back the XCD's whole L2) made the split launch
+  // SLOWER than the under-filled one (cfg3 step 78.3 vs 72.4 ms).
+  if constexpr (SKFIX) {
+    if (p.sk_ws != nullptr) {
+      constexpr int NT = 64 * NW, TILE = BM * BN;
+      const int nz = gridDim.z;
+      const int64_t tile_id = (int64_t)blockIdx.y * n_tiles + tile;
+      float* base = p.sk_ws + tile_id * nz * TILE;
+      float* mine = base + (int64_t)blockIdx.z * TILE;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * MT; ++b) *(volatile f32x4_t*)(mine + ((a * 2 * MT + b) * NT + tid) * 4) = acc16[a][b];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial tile has left this CU before the ticket is taken
+      __syncthreads();
+      if (tid == 0) *(volatile unsigned*)smem = atomicAdd(p.sk_cnt + tile_id, 1u);
+      __syncthreads();
+      const unsigned ticket = *(volatile unsigned*)smem;
+      if (ticket != (unsigned)(nz - 1)) return;
+      if (tid == 0) p.sk_cnt[tile_id] = 0;   // ready for the next launch on this stream
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * MT; ++b) acc16[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      // four slices' loads in flight at a time (memory-side round trips: one slice per trip made the combine as long as the
+      // K loop); the additions keep slice order
+      constexpr int G = 4;
+      for (int s0 = 0; s0 < nz; s0 += G) {
+        f32x4_t part[G][4][2 * MT];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (s0 + g < nz) {
+            const float* src = base + (int64_t)(s0 + g) * TILE;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int b = 0; b < 2 * MT; ++b) part[g][a][b] = *(const volatile f32x4_t*)(src + ((a * 2 * MT + b) * NT + tid) * 4);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (s0 + g < nz) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int b = 0; b < 2 * MT; ++b) acc16[a][b] += part[g][a][b];
+          }
+        }
+      }
+      __syncthreads();
     }
   }
   if constexpr (M16) {
@@ -1168,12 +1228,86 @@ inline bool g8_offsets_ok(const ffvc_gemm_desc& d) {
   return dma_operand_ok<XMODE>(d, true) && dma_operand_ok<FFVC_OP_KMAJOR>(d, false);
 }
 
+// Per-stream scratch of the in-kernel split-K: partial tiles + one (self-resetting) ticket counter per tile.
+inline bool skfix_scratch(hipStream_t st, size_t ws_bytes, size_t n_cnt, float** ws, uint32_t** cnt) {
+  struct Slot {
+    float* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint32_t* cnt = nullptr;
+    size_t n_cnt = 0;
+  };
+  static std::mutex mu;
+  static std::map<hipStream_t, Slot> pool;
+  std::lock_guard<std::mutex> lk(mu);
+  Slot& s = pool[st];
+  if (s.ws_bytes < ws_bytes) {
+    if (s.ws) {
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(s.ws);
+      s.ws = nullptr;
+      s.ws_bytes = 0;
+    }
+    const size_t want = ws_bytes < (32u << 20) ? (32u << 20) : ws_bytes;
+    void* q = nullptr;
+    if (hipMalloc(&q, want) != hipSuccess) return false;
+    s.ws = (float*)q;
+    s.ws_bytes = want;
+  }
+  if (s.n_cnt < n_cnt) {
+    if (s.cnt) {
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(s.cnt);
+      s.cnt = nullptr;
+      s.n_cnt = 0;
+    }
+    const size_t want = n_cnt < 4096 ? 4096 : n_cnt;
+    void* q = nullptr;
+    if (hipMalloc(&q, want * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMemsetAsync(q, 0, want * sizeof(uint32_t), st) != hipSuccess) return false;
+    s.cnt = (uint32_t*)q;
+    s.n_cnt = want;
+  }
+  *ws = s.ws;
+  *cnt = s.cnt;
+  return true;
+}
+
 template <typename L, int XMODE, int WMODE, int BM, int BN>
-int launch2(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero) {
+int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16_t* zero) {
+  ffvc_gemm_desc d = d_in;
+  d.sk_ws = nullptr;
+  d.sk_cnt = nullptr;
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
   const int n_tiles = tiles_m * tiles_n;
   int split = d.split_k < 1 ? 1 : d.split_k;
   const int ksteps = ceil_div(d.K, BK);
+  if constexpr (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM == 128 && BN == 128) {
+    // Under-filled grid with a long reduction (VitGAN / x-transformer linears at a per-GPU batch of 16-32 samples: 512 rows):
+    // 32 workgroups walking K = 4096 leave 7/8 of the chip idle (52 TFLOP/s).  Split K inside the launch; FFVC_SK_FIXUP=0 off.
+    static int fix_opt = -1;
+    if (fix_opt < 0) {
+      const char* e = getenv("FFVC_SK_FIXUP");
+      fix_opt = e ? atoi(e) : 1;
+    }
+    const int64_t wgs = (int64_t)n_tiles * d.batch;
+    if (fix_opt && split == 1 && d.slab_stride == 0 && wgs <= 64 && ksteps >= 16 && dma_operand_ok<XMODE>(d, true) &&
+        dma_operand_ok<WMODE>(d, false)) {
+      int want = (int)((fix_opt > 1 ? fix_opt : 256) / wgs);     // ~one workgroup per CU
+      if (want > ksteps / 4) want = ksteps / 4;                   // at least 4 K steps (256 deep) per slice
+      if (want > 16) want = 16;                                   // the last workgroup reads every slice of its tile
+      if (want >= 2) {
+        const int len = ceil_div(ksteps, want);
+        const int nz = ceil_div(ksteps, len);
+        float* ws = nullptr;
+        uint32_t* cnt = nullptr;
+        if (nz >= 2 && skfix_scratch(st, (size_t)wgs * nz * BM * BN * sizeof(float), (size_t)wgs, &ws, &cnt)) {
+          split = nz;
+          d.sk_ws = ws;
+          d.sk_cnt = cnt;
+        }
+      }
+    }
+  }
   if (split > ksteps) split = ksteps < 1 ? 1 : ksteps;
   const int ksplit_len = ceil_div(ksteps, split) * BK;
   split = ceil_div(d.K, ksplit_len);

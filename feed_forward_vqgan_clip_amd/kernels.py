@@ -489,10 +489,15 @@ class TransposePlan:
               stream_ptr())
 
 
-def copy2d(src, src_ld, rows, cols, dst_cols, out_dtype, dst_ld=None):
-    """dst[r, c] = src[r, c] (c < cols) else 0, for c < dst_cols."""
+def copy2d(src, src_ld, rows, cols, dst_cols, out_dtype, dst_ld=None, out=None):
+    """dst[r, c] = src[r, c] (c < cols) else 0, for c < dst_cols.  out: write into the first `rows` rows of an existing
+    [>= rows, dst_ld] buffer instead of allocating one."""
     dst_ld = dst_ld or dst_cols
-    dst = torch.empty(rows, dst_ld, dtype=out_dtype, device=src.device)
+    if out is not None:
+        _need_cuda(src, out)
+        if out.dtype != out_dtype or not out.is_contiguous() or out.numel() < rows * dst_ld:
+            raise TypeError("copy2d: `out` must be a contiguous buffer of the output dtype with >= rows * dst_ld elements")
+    dst = out if out is not None else torch.empty(rows, dst_ld, dtype=out_dtype, device=src.device)
     _call("ffvc_copy2d", src.data_ptr(), dtype_code(src.dtype), src_ld, dst.data_ptr(), dtype_code(out_dtype), dst_ld, rows,
           cols, dst_cols, stream_ptr())
     return dst
@@ -822,6 +827,51 @@ def attn_small_bwd(qkv, do, heads, scale):
     _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
           float(scale),
           stream_ptr())
+    return dqkv
+
+
+def _tiny_strides(layout, T, heads, dh, row_ld):
+    """Element strides (sample, token, which-of-q/k/v, head, channel) of a [B, T, row_ld] projection whose first 3*heads*dh
+    columns hold q, k, v as '(d k h)' (vitgan.py:81-82) or '(k h d)'."""
+    if layout == "dkh":
+        return (T * row_ld, row_ld, heads, 1, 3 * heads)
+    if layout == "khd":
+        return (T * row_ld, row_ld, heads * dh, dh, 1)
+    raise ValueError(f"attn_tiny: unknown layout {layout!r}")
+
+
+def attn_tiny_ok(T, dh):
+    """A handful of tokens x any head width: one workgroup per (sample, head), everything in LDS (csrc/attn_tiny.hip)."""
+    return os.environ.get("FFVC_ATTN_TINY", "1") != "0" and bool(_lib.load().ffvc_attn_tiny_supported(int(T), int(dh)))
+
+
+def attn_tiny_fwd(qkv, heads, dh, scale, layout="dkh", out_ld=None):
+    """qkv [B, T, row_ld] (row_ld >= 3*heads*dh) -> out [B, T, out_ld] with heads*dh valid columns (pad zeroed)."""
+    _need_cuda(qkv)
+    if not qkv.is_contiguous():
+        raise TypeError("attn_tiny_fwd: contiguous qkv expected")
+    B, T, row_ld = qkv.shape
+    if row_ld < 3 * heads * dh:
+        raise ValueError("attn_tiny_fwd: rows shorter than 3 * heads * head_dim")
+    out_ld = heads * dh if out_ld is None else int(out_ld)
+    o = torch.empty(B, T, out_ld, dtype=qkv.dtype, device=qkv.device)
+    sb, st, sk, sh, sd = _tiny_strides(layout, T, heads, dh, row_ld)
+    _call("ffvc_attn_tiny_fwd", qkv.data_ptr(), o.data_ptr(), dtype_code(qkv.dtype), B, T, heads, dh, sb, st, sk, sh, sd, out_ld,
+          float(scale), stream_ptr())
+    return o
+
+
+def attn_tiny_bwd(qkv, do, heads, dh, scale, layout="dkh"):
+    """-> dqkv, same shape / layout as qkv (columns beyond 3*heads*dh zeroed)."""
+    _need_cuda(qkv, do)
+    if not (qkv.is_contiguous() and do.is_contiguous()) or do.dtype != qkv.dtype or do.shape[:2] != qkv.shape[:2]:
+        raise TypeError("attn_tiny_bwd: contiguous qkv / dout of one dtype and matching [B, T] expected")
+    B, T, row_ld = qkv.shape
+    out_ld = do.shape[2]
+    dqkv = torch.empty_like(qkv)
+    sb, st, sk, sh, sd = _tiny_strides(layout, T, heads, dh, row_ld)
+    _call("ffvc_attn_tiny_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, dh, sb, st, sk,
+          sh, sd, out_ld, 3 * heads * dh, float(scale), stream_ptr())
     return dqkv
 
 

@@ -8,6 +8,7 @@ layers are used ONLY as parameter holders / default initialisers — their forwa
 import torch
 from torch import nn
 
+from . import kernels as K
 from . import ops
 from .arena import ParamArena
 from .kernels import ACT_GELU
@@ -160,7 +161,12 @@ class _VitGANBase(_MapperBase):
         mk = arena.make_weights
         self._bp = []
         for blk in self.Transformer_Encoder.blocks:
-            self._bp.append((blk.norm1, mk(blk.attn.to_qkv.weight, None), mk(blk.attn.w_out.weight, blk.attn.w_out.bias),
+            # 6 heads x (1024 // 6 = 170) channels = 1020: the 3060-wide qkv rows and the 1020-deep w_out reduction are padded to
+            # multiples of 8 elements (zero weight rows / columns) so every GEMM of the block runs on the LDS-DMA kernels
+            inner = blk.attn.num_heads * blk.attn.dim_head
+            pq, po = (-3 * inner) % 8, (-inner) % 8
+            self._bp.append((blk.norm1, mk(blk.attn.to_qkv.weight, None, pad_n=pq),
+                             mk(blk.attn.w_out.weight, blk.attn.w_out.bias, pad_k=po),
                              blk.norm2, mk(blk.mlp.linear1.weight, blk.mlp.linear1.bias),
                              mk(blk.mlp.linear2.weight, blk.mlp.linear2.bias), blk.attn))
         self._w_mlp = mk(self.mlp.weight, self.mlp.bias)
@@ -175,13 +181,21 @@ class _VitGANBase(_MapperBase):
         for (n1, Wqkv, Wout, n2, W1, W2, att) in self._bp:
             H, dh = att.num_heads, att.dim_head
             dhp = (dh + align - 1) // align * align
+            tiny = dh != 64 and K.attn_tiny_ok(T, dh)
             y, hid = ops.sln_fork(hl, x, n1.ln.weight, n1.ln.bias, n1.gamma, n1.beta, cdt)       # vitgan.py:132
-            qkv = ops.linear(y, Wqkv)                                                            # (B,T,(d k h)) :81
-            qkv = ops.transpose_pad(qkv.view(B * T, dh, 3 * H), dhp).view(B, T, 3 * H * dhp)      # -> (k h d) :82
-            o = ops.attention(qkv, H, float(dim) ** -0.5)                                        # scale = dim^-0.5 :65
-            if dhp != dh:
-                o = ops.copy2d(o, B * T * H, dh, dhp, dh)
-            hl = ops.linear(o.view(B, T, H * dh), Wout, residual=hid, out_dtype=f32, drop=drop)  # w_out + hl :97,132
+            qkv = ops.linear(y, Wqkv)                                                            # (B,T,(d k h) + pad) :81
+            if tiny:       # a handful of tokens: one launch per direction, read in the projection's own (d k h) order
+                o = ops.attention_tiny(qkv, H, dh, float(dim) ** -0.5, "dkh", out_ld=Wout.K)     # :82-93, scale = dim^-0.5 :65
+            else:
+                if Wqkv.N != 3 * H * dh:
+                    qkv = ops.copy2d(qkv, B * T, 3 * H * dh, Wqkv.N, 3 * H * dh)
+                qkv = ops.transpose_pad(qkv.view(B * T, dh, 3 * H), dhp).view(B, T, 3 * H * dhp)  # -> (k h d) :82
+                o = ops.attention(qkv, H, float(dim) ** -0.5)
+                if dhp != dh or Wout.K != H * dh:                                                # per-head pad off, row pad on
+                    o = ops.copy2d(o, B * T * H, dh, dhp, dh)
+                    if Wout.K != H * dh:
+                        o = ops.copy2d(o, B * T, H * dh, H * dh, Wout.K)
+            hl = ops.linear(o.view(B, T, Wout.K), Wout, residual=hid, out_dtype=f32, drop=drop)  # w_out + hl :97,132
             y, hid = ops.sln_fork(hl, x, n2.ln.weight, n2.ln.bias, n2.gamma, n2.beta, cdt)
             hl = ops.mlp(y, W1, W2, ACT_GELU, residual=hid, out_dtype=f32, drop=drop)            # :133
         return hl

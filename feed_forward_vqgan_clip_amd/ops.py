@@ -166,9 +166,12 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
     wg = _grad_buf(W.weight)
     bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad and not bias_done) else None
     bk = 64 if dy2d.dtype in K.LOWP else 32
-    sk = _split_k(W.N, W.K, rows, bk, big_tiles=dy2d.dtype in K.LOWP and (ldy or W.N) == W.N)
+    # the master's own shape: W.N / W.K are the (possibly zero-padded) row strides of dy / x (ParamArena.make_weights)
+    Nr = W.weight.shape[0]
+    Kr = W.weight.numel() // Nr
+    sk = _split_k(Nr, Kr, rows, bk, big_tiles=dy2d.dtype in K.LOWP and (ldy or W.N) == Nr and W.K == Kr)
     with _on_side(dy2d, x2d):
-        K.gemm_splitk_accumulate(dy2d, x2d, wg, W.N, W.K, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
+        K.gemm_splitk_accumulate(dy2d, x2d, wg, Nr, Kr, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
                                  w_mode=K.OP_TRANS)
         if bg is not None:
             K.colsum(dy2d, bg, accumulate=True, ld=ldy)
@@ -680,6 +683,28 @@ class _AttentionFn(Function):
 
 def attention(qkv, heads, scale, causal=False):
     return _AttentionFn.apply(qkv, heads, scale, causal)
+
+
+class _AttentionTinyFn(Function):
+    """softmax(scale q k^T) v for a handful of tokens and any head width, straight from the projection's own column order."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, dh, scale, layout, out_ld):
+        qkv = _contig(qkv)
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (heads, dh, scale, layout)
+        return K.attn_tiny_fwd(qkv, heads, dh, scale, layout, out_ld)
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        heads, dh, scale, layout = ctx.cfg
+        return K.attn_tiny_bwd(qkv, _as(_contig(do), qkv.dtype), heads, dh, scale, layout), None, None, None, None, None
+
+
+def attention_tiny(qkv, heads, dh, scale, layout="dkh", out_ld=None):
+    """qkv [B, T, >= 3*heads*dh] in the reference's '(d k h)' column order (vitgan.py:81-82) or '(k h d)' -> [B, T, out_ld]."""
+    return _AttentionTinyFn.apply(qkv, heads, dh, scale, layout, out_ld)
 
 
 # ---------------------------------------------------------------------------

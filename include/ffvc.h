@@ -135,6 +135,11 @@ typedef struct ffvc_gemm_desc {
    * where the tensor is produced instead of by a separate read pass.  16-bit LDS-DMA path with the row-store epilogue
    * only, batch == 1, no split-K. */
   float* colsum;
+  /* RESERVED, leave NULL: scratch of the in-kernel split-K (set by the library itself when an under-filled K-major x K-major
+   * launch is split along K: every K slice parks its fp32 partial tile, the last workgroup to arrive on a tile sums them
+   * in slice order and runs the ordinary epilogue, so any fused epilogue stays available). */
+  float* sk_ws;
+  uint32_t* sk_cnt;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
@@ -228,6 +233,20 @@ int ffvc_attn_small_fwd(const void* qkv, void* out, int dtype, int B, int T, int
                         void* stream);   /* dtype: FFVC_BF16 | FFVC_F16 */
 int ffvc_attn_small_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int B, int T, int heads, int head_dim,
                         float scale, void* stream);
+
+/* Attention for a handful of tokens and ANY head width (VitGAN mapper, vitgan.py:44-97: 16 tokens, 6 heads of 170 channels):
+ * one workgroup per (sample, head), q / k / v staged in LDS, fp32 VALU arithmetic, one launch per direction instead of seven
+ * batched GEMMs + two softmax passes.  qkv[b, t, which, h, d] sits at b*sb + t*st + which*sk + h*sh + d*sd ELEMENTS, so the
+ * projection output is read where it lies: the reference's '(d k h)' interleave (vitgan.py:81-82) is sk = heads, sh = 1,
+ * sd = 3*heads.  out: [B, T, out_ld] with heads*head_dim valid columns per row (the pad, if any, is zeroed); dqkv has qkv's
+ * layout, columns row_len .. st-1 of every token row zeroed.  dtype FFVC_BF16 | FFVC_F16 | FFVC_F32;
+ * ffvc_attn_tiny_supported(T, head_dim): the panels fit the CU's LDS. */
+int ffvc_attn_tiny_supported(int T, int head_dim);
+int ffvc_attn_tiny_fwd(const void* qkv, void* out, int dtype, int B, int T, int heads, int head_dim, int64_t sb, int64_t st,
+                       int64_t sk, int64_t sh, int64_t sd, int64_t out_ld, float scale, void* stream);
+int ffvc_attn_tiny_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int B, int T, int heads, int head_dim,
+                       int64_t sb, int64_t st, int64_t sk, int64_t sh, int64_t sd, int64_t out_ld, int64_t row_len, float scale,
+                       void* stream);
 
 /* Flash-style attention for any sequence length, head_dim 64, optional causal mask: the x-transformer mapper's
  * self-attention (transformer.py:11-20 -> x-transformers Decoder, 1024 tokens at cfg4) and ViT-L/14's 257 tokens

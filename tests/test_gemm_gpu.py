@@ -488,3 +488,42 @@ def test_gemm_actgrad_storage(cuda, M, N, Kd, act, ldt):
     ref = (dy.double() @ wt.double().t()) * want
     scale = ref.abs().max().item()
     assert (d1.double() - ref).abs().max().item() < 3 * tol * scale and (d0.double() - ref).abs().max().item() < 3 * tol * scale
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K_", [(512, 1024, 4096), (512, 1024, 1024), (300, 200, 2048), (616, 768, 9216), (64, 128, 8192)])
+def test_underfilled_grid_in_kernel_split_k(cuda, dt, M, N, K_):
+    """Few output tiles x long reduction (VitGAN / x-transformer linears at a per-GPU batch of 16-32 samples): the launch is split
+    along K inside the kernel and the last workgroup per tile runs the fused epilogue on the summed tile.  Same answers as the
+    unsplit launch (bias + GELU + pre-activation write + fp32 residual), repeatable bit for bit, also from two streams at once."""
+    x, w = _mk((M, K_), dt, cuda, 1, 0.5), _mk((N, K_), dt, cuda, 2, 0.05)
+    b = _mk((N,), torch.float32, cuda, 3)
+    res = _mk((M, N), torch.float32, cuda, 4)
+    pre = x.double() @ w.double().T + b.double()
+    ref = F.gelu(pre) + res.double()
+
+    def run():
+        y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+        aux = torch.empty(M, N, dtype=dt, device=cuda)
+        K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_, bias=b, residual=res, aux=aux, ldaux=N, act=K.ACT_GELU, flags=K.F_WRITE_PREACT)
+        return y, aux
+
+    y, aux = run()
+    assert _rel(aux, pre) < LOTOL[dt]
+    assert _rel(y, ref) < 3e-5
+    y2, aux2 = run()
+    assert torch.equal(y, y2) and torch.equal(aux, aux2)           # slice order, not arrival order
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(run())
+    torch.cuda.synchronize()
+    for yy, aa in outs:
+        assert torch.equal(yy, y) and torch.equal(aa, aux)
+    # plain 16-bit output without any epilogue (the lean kernel class)
+    yl = torch.empty(M, N, dtype=dt, device=cuda)
+    K.gemm(x, w, yl, M, N, K_, ldx=K_, ldw=K_)
+    assert _rel(yl, x.double() @ w.double().T) < LOTOL[dt]

@@ -484,3 +484,34 @@ def test_slab_reduce_every_specialisation(cuda, nslab):
     assert float((y.double() - want).abs().max()) < 1e-5
     _call("ffvc_slab_reduce", slabs.data_ptr(), y.data_ptr(), 300 * 44, nslab, 0, stream_ptr())
     assert float((y.double() - slabs.double().sum(0)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,T,H,dh,layout,pad", [(3, 16, 6, 170, "dkh", 0), (2, 16, 6, 170, "dkh", 4), (2, 9, 3, 40, "khd", 8),
+                                                 (1, 32, 2, 96, "dkh", 0)])
+def test_attention_tiny_vs_fp64(cuda, dt, B, T, H, dh, layout, pad):
+    """One-workgroup-per-(sample, head) attention (csrc/attn_tiny.hip) against fp64 autograd, reading q/k/v in the reference's
+    '(d k h)' column order (vitgan.py:81-82) or '(k h d)', with and without padded rows."""
+    from feed_forward_vqgan_clip_amd import kernels as K
+    assert K.attn_tiny_ok(T, dh)
+    g = torch.Generator().manual_seed(5)
+    row, out_ld = 3 * H * dh + pad, H * dh + pad
+    qkv = torch.randn(B, T, row, generator=g).to(dt).cuda()
+    do = torch.randn(B, T, out_ld, generator=g).to(dt).cuda()
+    scale = 0.11
+    o = K.attn_tiny_fwd(qkv, H, dh, scale, layout, out_ld)
+    dqkv = K.attn_tiny_bwd(qkv, do, H, dh, scale, layout)
+    x = qkv.double()[:, :, :3 * H * dh].detach().requires_grad_(True)
+    if layout == "dkh":
+        q, k, v = x.view(B, T, dh, 3, H).permute(3, 0, 4, 1, 2)          # 'b t (d k h) -> k b h t d'
+    else:
+        q, k, v = x.view(B, T, 3, H, dh).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, T, H * dh)              # 'b h t d -> b t (h d)'
+    ref.backward(do.double()[:, :, :H * dh])
+    tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dt]
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()
+    assert rel(o[:, :, :H * dh], ref.detach()) < tol
+    assert rel(dqkv[:, :, :3 * H * dh], x.grad) < tol
+    if pad:
+        assert torch.count_nonzero(o[:, :, H * dh:]) == 0 and torch.count_nonzero(dqkv[:, :, 3 * H * dh:]) == 0
