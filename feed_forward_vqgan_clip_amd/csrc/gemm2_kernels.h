@@ -774,21 +774,28 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // In-kernel split-K (under-filled grids, launch2 decides): every K slice parks its fp32 accumulators in accumulator order
   // (16 bytes per lane, fully coalesced), the LAST workgroup to arrive on the tile sums all slices in slice order (the result
   // does not depend on which one that was) and carries on into the ordinary epilogue; the others are done.
-  // The slices of a tile may run on different XCDs, whose L2s are not coherent with each other: the partial tiles therefore
-  // travel with system-scope accesses (volatile = sc0 sc1: written through to / read from the memory side) and the ticket is
-  // a device-scope atomic.  A release fence instead (buffer_wbl2: write back the XCD's whole L2) made the split launch
-  // SLOWER than the under-filled one (cfg3 step 78.3 vs 72.4 ms).
+  // The slices of a tile may run on different XCDs, whose L2s are not coherent with each other: the partial tiles travel as
+  // relaxed device-scope 64-bit atomic stores / loads (sc1: coherent at the memory side, no ordering of their own) and the
+  // ticket is a device-scope atomic taken after the stores have retired.  Measured alternatives: a release fence
+  // (buffer_wbl2 = write back the XCD's whole L2) made the split launch slower than the under-filled one (cfg3 78.3 vs
+  // 72.4 ms); `volatile` accesses are followed by a full vmcnt(0) each (16 serial round trips per slice, +25 us per launch).
   if constexpr (SKFIX) {
     if (p.sk_ws != nullptr) {
-      constexpr int NT = 64 * NW, TILE = BM * BN;
+      constexpr int NT = 64 * NW, TILE = BM * BN, NP = 4 * 2 * MT * 2;       // 8-byte pieces per thread
       const int nz = gridDim.z;
       const int64_t tile_id = (int64_t)blockIdx.y * n_tiles + tile;
-      float* base = p.sk_ws + tile_id * nz * TILE;
-      float* mine = base + (int64_t)blockIdx.z * TILE;
+      uint64_t* base = (uint64_t*)(p.sk_ws + tile_id * nz * TILE);
+      uint64_t* mine = base + (int64_t)blockIdx.z * (TILE / 2);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2 * MT; ++b) *(volatile f32x4_t*)(mine + ((a * 2 * MT + b) * NT + tid) * 4) = acc16[a][b];
+        for (int b = 0; b < 2 * MT; ++b)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2_t v = {acc16[a][b][2 * h], acc16[a][b][2 * h + 1]};
+            __hip_atomic_store(mine + (((a * 2 * MT + b) * 2 + h) * NT + tid), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial tile has left this CU before the ticket is taken
       __syncthreads();
       if (tid == 0) *(volatile unsigned*)smem = atomicAdd(p.sk_cnt + tile_id, 1u);
@@ -800,19 +807,16 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 2 * MT; ++b) acc16[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      // four slices' loads in flight at a time (memory-side round trips: one slice per trip made the combine as long as the
-      // K loop); the additions keep slice order
-      constexpr int G = 4;
+      // two slices' loads in flight at a time; the additions keep slice order
+      constexpr int G = 2;
       for (int s0 = 0; s0 < nz; s0 += G) {
-        f32x4_t part[G][4][2 * MT];
+        uint64_t part[G][NP];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (s0 + g < nz) {
-            const float* src = base + (int64_t)(s0 + g) * TILE;
+            const uint64_t* src = base + (int64_t)(s0 + g) * (TILE / 2);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-              for (int b = 0; b < 2 * MT; ++b) part[g][a][b] = *(const volatile f32x4_t*)(src + ((a * 2 * MT + b) * NT + tid) * 4);
+            for (int i = 0; i < NP; ++i) part[g][i] = __hip_atomic_load(src + (i * NT + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
 #pragma unroll
@@ -821,7 +825,13 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-              for (int b = 0; b < 2 * MT; ++b) acc16[a][b] += part[g][a][b];
+              for (int b = 0; b < 2 * MT; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const f32x2_t v = __builtin_bit_cast(f32x2_t, part[g][(a * 2 * MT + b) * 2 + h]);
+                  acc16[a][b][2 * h] += v[0];
+                  acc16[a][b][2 * h + 1] += v[1];
+                }
           }
         }
       }

@@ -464,12 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemmR(const uint16_t* __restrict__ X, 
     const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  if constexpr ((VAR & 32) != 0) {        // groups of 4 tile rows, column-major inside a group (tiles_m % 4 == 0 assumed)
-    const int width = 4 * tiles_n, grp = tile / width, rem = tile - grp * width;
-    tn = rem / 4;
-    tm = grp * 4 + (rem - tn * 4);
-  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * 256, n0 = tn * 256;
   // DMA: K-major tile [256 rows][128 B]; piece p = lines 4p..4p+3 (a line = 2 rows), slot' = slot ^ (line & 15)
   const rsrc_t rsx = make_rsrc(X + (int64_t)m0 * K), rsw = make_rsrc(W + (int64_t)n0 * K);
