@@ -67,7 +67,11 @@ class Mixer(_MapperBase):
         super().__init__()
         assert (image_size % patch_size) == 0, "image must be divisible by patch size"
         if patch_size != 1:
-            raise NotImplementedError("ffvc Mixer supports patch_size=1 (the only value main.py:479-488 passes)")
+            # the reference itself cannot run any other value: its forward ends in x.view(bs, S, S, C) on a [bs, (S/p)^2, C]
+            # tensor (mlp_mixer_pytorch.py:88-89) and raises "shape ... is invalid for input of size ..." for p > 1
+            # (tests/test_mappers_cpu.py pins that); main.py:479-488 only ever passes 1
+            raise NotImplementedError("Mixer: patch_size must be 1 (the reference's own forward raises for any other value: "
+                                      "mlp_mixer_pytorch.py:88-89 views [bs, (S/p)^2, C] as [bs, S, S, C])")
         self.dropout = float(dropout)       # nn.Dropout after GELU and after the second Linear of every FeedForward (:20-22)
         self.input_dim, self.channels, self.image_size, self.dim, self.depth = input_dim, channels, image_size, dim, depth
         P = image_size * image_size
