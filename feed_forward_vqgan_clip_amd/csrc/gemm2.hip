@@ -550,6 +550,20 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     const double e256 = t256 >= 256 ? eff(t256, 512) * 1.07 : 0.0;
     const double e128 = eff(t128, 512);
     cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
+    // K-major x K-major (Linear forward / dgrad): since the 16x16x32 MFMA switch the 128x128 kernel runs at about half the
+    // per-FLOP rate of the 256-row kernels (16384x1024x4096: 268 vs 113 us), so a partly filled last round of big tiles beats
+    // a well-filled grid of small ones: ViT's 768-wide outputs (300 tiles of 256x256 on 256 CUs) 253 -> 141 us
+    // (profiles/r03_gemm_tile_sweep.txt).  Small grids (< 96 big tiles) stay on 128x128.  FFVC_TILE_RULE=0: previous rule.
+    static int rule = -1;
+    if (rule < 0) {
+      const char* e = getenv("FFVC_TILE_RULE");
+      rule = e ? atoi(e) : 1;
+    }
+    if (rule && d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) {
+      if (d.N > 128 && t512 >= 96) cfg = 512;
+      else if (t256 >= 192) cfg = 256;
+      else cfg = 128;
+    }
     // short reductions are epilogue-dominated: keep two (smaller) workgroups per CU so one's epilogue overlaps the
     // other's K loop (threshold via FFVC_SHORTK for A/B runs)
     static int shortk = -1;
