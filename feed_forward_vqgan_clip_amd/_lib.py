@@ -84,6 +84,8 @@ class GemmDesc(Structure):
         ("colsum", c_void_p),
         ("sk_ws", c_void_p),
         ("sk_cnt", c_void_p),
+        ("sk_full", c_int32),
+        ("sk_slices", c_int32),
     ]
 
 

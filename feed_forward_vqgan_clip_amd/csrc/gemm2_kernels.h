@@ -575,9 +575,26 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   const int wm = wid & 1, wn = wid >> 1;
   const int l31 = lane & 31;
 
+  // in-kernel split-K (see the combine in front of the epilogue): uniform mode = blockIdx.z is the K slice of every tile;
+  // tail mode (p.sk_slices > 1, 1-D grid) = work items below p.sk_full are whole tiles, the rest are K slices of the tiles of
+  // the last, partly filled round
+  constexpr bool SKFIX = FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256));
+  int wl = blockIdx.x, sk_slice = blockIdx.z, sk_n = gridDim.z;
+  if constexpr (SKFIX) {
+    if (p.sk_slices > 1) {
+      sk_slice = 0;
+      sk_n = 1;
+      if (wl >= p.sk_full) {
+        const int r = wl - p.sk_full, t = r / p.sk_slices;
+        sk_slice = r - t * p.sk_slices;
+        sk_n = p.sk_slices;
+        wl = p.sk_full + t;
+      }
+    }
+  }
   int tile;
   {
-    const int bid = blockIdx.x;
+    const int bid = wl;
     const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -599,8 +616,15 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
   const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
-  const int k_begin = blockIdx.z * ksplit_len;
-  const int k_end = min(p.K, k_begin + ksplit_len);
+  int k_begin = blockIdx.z * ksplit_len;
+  int k_end = min(p.K, k_begin + ksplit_len);
+  if constexpr (SKFIX) {
+    if (p.sk_slices > 1 && sk_n > 1) {
+      const int ks = (p.K + BK - 1) / BK, len = (ks + sk_n - 1) / sk_n;
+      k_begin = sk_slice * len * BK;
+      k_end = min(p.K, k_begin + len * BK);          // may be empty: the slice then parks a zero tile
+    }
+  }
   const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
   const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
 
@@ -626,7 +650,6 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // MFMA shape: 16x16x32 for K-major / implicit-im2col operands (fragment = one 16-byte read per 16 rows x 32 k), 32x32x16
   // where an operand is reduction-major (its fragments come through ds_read_b64_tr_b16 in the 32x32 arrangement)
   constexpr bool M16 = FFVC_MFMA16 && XMODE != FFVC_OP_TRANS && WMODE != FFVC_OP_TRANS;
-  constexpr bool SKFIX = M16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM == 128 && BN == 128;
   f32x16_t acc[M16 ? 1 : 2][M16 ? 1 : MT];
   f32x4_t acc16[M16 ? 4 : 1][M16 ? 2 * MT : 1];
   if constexpr (M16) {
@@ -779,13 +802,13 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // ticket is a device-scope atomic taken after the stores have retired.  Measured alternatives: a release fence
   // (buffer_wbl2 = write back the XCD's whole L2) made the split launch slower than the under-filled one (cfg3 78.3 vs
   // 72.4 ms); `volatile` accesses are followed by a full vmcnt(0) each (16 serial round trips per slice, +25 us per launch).
-  if constexpr (SKFIX) {
-    if (p.sk_ws != nullptr) {
+  if constexpr (SKFIX && M16) {
+    if (p.sk_ws != nullptr && sk_n > 1) {
       constexpr int NT = 64 * NW, TILE = BM * BN, NP = 4 * 2 * MT * 2;       // 8-byte pieces per thread
-      const int nz = gridDim.z;
-      const int64_t tile_id = (int64_t)blockIdx.y * n_tiles + tile;
+      const int nz = sk_n;
+      const int64_t tile_id = p.sk_slices > 1 ? (int64_t)(wl - p.sk_full) : (int64_t)blockIdx.y * n_tiles + tile;
       uint64_t* base = (uint64_t*)(p.sk_ws + tile_id * nz * TILE);
-      uint64_t* mine = base + (int64_t)blockIdx.z * (TILE / 2);
+      uint64_t* mine = base + (int64_t)sk_slice * (TILE / 2);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -803,36 +826,35 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       const unsigned ticket = *(volatile unsigned*)smem;
       if (ticket != (unsigned)(nz - 1)) return;
       if (tid == 0) p.sk_cnt[tile_id] = 0;   // ready for the next launch on this stream
+      // the combine walks the accumulator in chunks of CH pieces with the loads of ALL slices of a chunk in flight together
+      // (memory-side round trips; one slice per trip made the combine as long as the K loop); additions keep slice order
+      constexpr int CH = (BM == 256) ? 4 : 8, SMAX = (BM == 256) ? 8 : 16;
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int c0 = 0; c0 < NP; c0 += CH) {
+        uint64_t part[SMAX][CH];
 #pragma unroll
-        for (int b = 0; b < 2 * MT; ++b) acc16[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      // two slices' loads in flight at a time; the additions keep slice order
-      constexpr int G = 2;
-      for (int s0 = 0; s0 < nz; s0 += G) {
-        uint64_t part[G][NP];
+        for (int s = 0; s < SMAX; ++s)
+          if (s < nz) {
+            const uint64_t* src = base + (int64_t)s * (TILE / 2);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (s0 + g < nz) {
-            const uint64_t* src = base + (int64_t)(s0 + g) * (TILE / 2);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) part[g][i] = __hip_atomic_load(src + (i * NT + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < CH; ++i) part[s][i] = __hip_atomic_load(src + ((c0 + i) * NT + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-        }
+        f32x2_t sum[CH];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (s0 + g < nz) {
+        for (int i = 0; i < CH; ++i) sum[i] = f32x2_t{0.f, 0.f};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int s = 0; s < SMAX; ++s)
+          if (s < nz) {
 #pragma unroll
-              for (int b = 0; b < 2 * MT; ++b)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                  const f32x2_t v = __builtin_bit_cast(f32x2_t, part[g][(a * 2 * MT + b) * 2 + h]);
-                  acc16[a][b][2 * h] += v[0];
-                  acc16[a][b][2 * h + 1] += v[1];
-                }
+            for (int i = 0; i < CH; ++i) sum[i] += __builtin_bit_cast(f32x2_t, part[s][i]);
           }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int pc = c0 + i, a = pc / (2 * MT * 2), b = (pc / 2) % (2 * MT), h = pc % 2;
+          acc16[a][b][2 * h] = sum[i][0];
+          acc16[a][b][2 * h + 1] = sum[i][1];
         }
       }
       __syncthreads();
@@ -1287,6 +1309,8 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
   ffvc_gemm_desc d = d_in;
   d.sk_ws = nullptr;
   d.sk_cnt = nullptr;
+  d.sk_full = 0;
+  d.sk_slices = 0;
   const int tiles_m = ceil_div(d.M, BM), tiles_n = ceil_div(d.N, BN);
   const int n_tiles = tiles_m * tiles_n;
   int split = d.split_k < 1 ? 1 : d.split_k;
@@ -1437,6 +1461,38 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
       }
       const bool wants_act = d.act != FFVC_ACT_NONE || (d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM));
       const bool wants_gn = d.flags & FFVC_F_GN_SUMS;
+      if constexpr (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM == 256 && BN == 256) {
+        // Tail mode of the in-kernel split-K: one 256x256 workgroup per CU, so 260 tiles (ViT-L/14's 16448 rows x 1024) or 300
+        // (ViT-B/32's 25600 x 768) run TWO rounds with the second one nearly empty.  The tiles of a last round that fills at
+        // most half of the chip are cut along K so that it takes a fraction of a round; capped by the partial-tile traffic
+        // (256 KiB per slice, written and read once) and kept to reductions of 2048 and more: the ONE workgroup that combines a
+        // tile reads all its slices through the memory side (~20 us for 8 x 256 KiB), which a shorter K loop does not repay
+        // (16448x1024x4096: 189 -> 167 us, 25600x768x3072: 141 -> 127; K = 1024 / 768: 4-6 us slower, left alone).
+        // FFVC_SK_TAIL=0 off.
+        static int tail_opt = -1;
+        if (tail_opt < 0) {
+          const char* e = getenv("FFVC_SK_TAIL");
+          tail_opt = e ? atoi(e) : 1;
+        }
+        if (tail_opt && split == 1 && d.batch == 1 && d.slab_stride == 0 && d.sk_ws == nullptr && n_tiles > n_cu && ksteps >= 32) {
+          const int full = (n_tiles / n_cu) * n_cu, tail = n_tiles - full;
+          if (tail > 0 && 2 * tail <= n_cu) {
+            int S = n_cu / tail;
+            if (S > 8) S = 8;
+            if (S > ksteps / 4) S = ksteps / 4;
+            while (S > 1 && tail * S > (tail_opt > 1 ? tail_opt : 96)) --S;
+            float* ws = nullptr;
+            uint32_t* cnt = nullptr;
+            if (S >= 2 && skfix_scratch(st, (size_t)tail * S * BM * BN * sizeof(float), (size_t)tail, &ws, &cnt)) {
+              d.sk_ws = ws;
+              d.sk_cnt = cnt;
+              d.sk_full = full;
+              d.sk_slices = S;
+              grid = dim3(full + tail * S, 1, 1);
+            }
+          }
+        }
+      }
       auto go = [&](auto epi_tag) -> int {
         constexpr int EPI = decltype(epi_tag)::value;
         static bool attr_b = false;

@@ -192,11 +192,13 @@ int launch_f8_cfg(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s
 // state[0] = scale applied before the conversion, state[1] = running max|x| (for the next update), state[2] = 1 / scale
 template <int FMT>
 __device__ __forceinline__ uint32_t cvt4_f8(float a, float b, float c, float d) {
-  constexpr float LIM = FMT == 0 ? 448.0f : 57344.0f;       // e4m3fn / e5m2 finite maxima: saturate instead of NaN / inf
-  a = fminf(fmaxf(a, -LIM), LIM);
-  b = fminf(fmaxf(b, -LIM), LIM);
-  c = fminf(fmaxf(c, -LIM), LIM);
-  d = fminf(fmaxf(d, -LIM), LIM);
+  constexpr float LIM = FMT == 0 ? 448.0f : 57344.0f;       // e4m3fn / e5m2 finite maxima: saturate instead of inf
+  // fminf / fmaxf return the non-NaN operand: a NaN activation or gradient would be quantised to -LIM and the divergence
+  // hidden.  NaN goes through unclamped and converts to the format's NaN encoding.
+  a = a != a ? a : fminf(fmaxf(a, -LIM), LIM);
+  b = b != b ? b : fminf(fmaxf(b, -LIM), LIM);
+  c = c != c ? c : fminf(fmaxf(c, -LIM), LIM);
+  d = d != d ? d : fminf(fmaxf(d, -LIM), LIM);
   int r = 0;
   if constexpr (FMT == 0) {
     r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);

@@ -140,6 +140,9 @@ typedef struct ffvc_gemm_desc {
    * in slice order and runs the ordinary epilogue, so any fused epilogue stays available). */
   float* sk_ws;
   uint32_t* sk_cnt;
+  /* RESERVED, leave 0: tail mode of the same machinery — work items >= sk_full are the tiles of the last, partly filled round of
+   * a 256x256-tile launch, each cut into sk_slices K slices (260 tiles on 256 CUs would otherwise run two full rounds). */
+  int32_t sk_full, sk_slices;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);

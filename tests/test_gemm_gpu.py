@@ -403,6 +403,10 @@ def test_fp8_quant_matches_torch_float8(cuda, fmt):
     assert torch.isfinite(_f8_ref(sat, fmt)).all() and _f8_ref(sat, fmt).abs().max().item() == fmax
     K.fp8_next_scale(sc)
     assert abs(sc.state[0].item() - fmax / ((x * 100).float().abs().max().item() * K.FP8_MARGIN)) < 1e-2 * sc.state[0].item()
+    xn = x.clone()
+    xn[3, 7] = float("nan")                              # a NaN must stay a NaN (not be clamped to -max and hidden)
+    qn = _f8_ref(K.fp8_quant(xn, K.Fp8Scale(fmt, x.device)), fmt)
+    assert torch.isnan(qn[3, 7]) and torch.isnan(qn).sum().item() == 1
 
 
 @pytest.mark.parametrize("ldt", [torch.float16, torch.bfloat16])
@@ -527,3 +531,28 @@ def test_underfilled_grid_in_kernel_split_k(cuda, dt, M, N, K_):
     yl = torch.empty(M, N, dtype=dt, device=cuda)
     K.gemm(x, w, yl, M, N, K_, ldx=K_, ldw=K_)
     assert _rel(yl, x.double() @ w.double().T) < LOTOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K_", [(16448, 1024, 2048), (25600, 768, 2304), (16448, 1024, 4096), (66000, 256, 2112), (16448, 1024, 1024)])
+def test_partly_filled_last_round_is_split_along_k(cuda, dt, M, N, K_):
+    """A few 256x256 tiles more than a multiple of the CU count (260 / 300 on 256 CUs): the tiles of the last round are cut along
+    K inside the launch (tail mode of the in-kernel split-K).  Same answers as fp64 math through the fused epilogues, repeatable
+    bit for bit, and identical to the unsplit launch where no slice boundary changes the fp32 summation order."""
+    x, w = _mk((M, K_), dt, cuda, 1, 0.5), _mk((N, K_), dt, cuda, 2, 0.05)
+    b = _mk((N,), torch.float32, cuda, 3)
+    res = _mk((M, N), torch.float32, cuda, 4)
+    y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_, bias=b, residual=res)
+    ref = x.double() @ w.double().T + b.double() + res.double()
+    assert _rel(y, ref) < 3e-5
+    y2 = torch.empty_like(y)
+    K.gemm(x, w, y2, M, N, K_, ldx=K_, ldw=K_, bias=b, residual=res)
+    assert torch.equal(y, y2)
+    h = torch.empty(M, N, dtype=dt, device=cuda)
+    aux = torch.empty(M, N, dtype=dt, device=cuda)
+    K.gemm(x, w, h, M, N, K_, ldx=K_, ldw=K_, bias=b, aux=aux, ldaux=N, act=K.ACT_GELU, flags=K.F_WRITE_PREACT)
+    pre = x.double() @ w.double().T + b.double()
+    assert _rel(aux, pre) < LOTOL[dt] and _rel(h, F.gelu(pre)) < LOTOL[dt]
+    # the tail rows (last tile row) against the head rows of the same launch: both must be right
+    assert _rel(y[-64:], ref[-64:]) < 3e-5 and _rel(y[:256], ref[:256]) < 3e-5
