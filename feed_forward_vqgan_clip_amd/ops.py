@@ -143,6 +143,7 @@ def _grad_buf(p):
     return p.grad
 
 
+_TM_WGRAD_INKERNEL = os.environ.get("FFVC_TOKMIX_WGRAD_INKERNEL", "0") != "0"   # A/B: one launch with the in-kernel split-K instead of slabs + reduce
 _SK_TARGET = int(os.environ.get("FFVC_SK_TARGET", "768"))  # A/B: workgroups a small-output weight gradient is split into
 _WGRAD_SK = int(os.environ.get("FFVC_WGRAD_SK", "0"))     # A/B: cap of the split-K factor of the 256x256-tile wgrads
 
@@ -434,7 +435,7 @@ class _TokenMLPFn(Function):
                 with _on_side(g, a):
                     if seg_ok:
                         # dW[n,k] = sum_{b,d} g[b][n,d] a[b][k,d]: K-major GEMM over the segmented (b,d) axis
-                        sk = _split_k(n_out, k_out, B * D, bk)
+                        sk = 1 if _TM_WGRAD_INKERNEL else _split_k(n_out, k_out, B * D, bk)
                         K.gemm_splitk_accumulate(g, a, wg, n_out, k_out, B * D, sk, ldx=D, ldw=D, kseg=D,
                                                  xkso=n_out * D, wkso=k_out * D)
                     else:
