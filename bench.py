@@ -346,7 +346,10 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
 
+    import hashlib
+    from feed_forward_vqgan_clip_amd import _lib as _flib
     out = {
+        "lib_sha256": hashlib.sha256(open(_flib.LIB_PATH, "rb").read()).hexdigest(),   # which libffvc_hip.so produced the line
         "metric": "train-step images/sec (whole node), ViT-B/32 + VQGAN-f16 256x256, bs=64, 1/2/4/8 GPU",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,

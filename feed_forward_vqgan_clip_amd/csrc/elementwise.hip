@@ -1159,7 +1159,11 @@ extern "C" int ffvc_tv_loss_bwd(const float* x, const float* g, float* dx, int B
 
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float gscale, float* __restrict__ out) {
   const float total = sqrtf(sumsq[0]) * fabsf(gscale);        // norm of the gradients as the optimizer will see them
-  out[0] = fminf(1.0f, max_norm / (total + 1e-6f));           // torch.nn.utils.clip_grad_norm_ (main.py:833-834)
+  // torch.nn.utils.clip_grad_norm_ (main.py:833-834).  A non-finite norm (an inf / NaN gradient somewhere: f16 overflow) makes
+  // the coefficient NaN ON PURPOSE: every scaled gradient then fails the Adam kernel's finite test and the whole step is
+  // skipped — fminf alone would drop the NaN and return 1, an inf norm would give 0 and a half-applied step.
+  const bool finite = total == total && total < 3.0e38f;
+  out[0] = finite ? fminf(1.0f, max_norm / (total + 1e-6f)) : __builtin_nanf("");
   out[1] = total;
 }
 

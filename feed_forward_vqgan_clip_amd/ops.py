@@ -1016,13 +1016,16 @@ class _Copy2dFn(Function):
     @staticmethod
     def forward(ctx, x, rows, cols, src_ld, dst_cols):
         x = _contig(x)
-        ctx.cfg = (rows, cols, src_ld, dst_cols)
+        if x.numel() != rows * src_ld:
+            raise ValueError(f"copy2d: {tuple(x.shape)} is not {rows} rows of {src_ld}")
+        ctx.cfg = (rows, cols, src_ld, dst_cols, x.shape)
         return K.copy2d(x, src_ld, rows, cols, dst_cols, x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        rows, cols, src_ld, dst_cols = ctx.cfg
-        return K.copy2d(_contig(g), dst_cols, rows, min(cols, dst_cols), src_ld, g.dtype), None, None, None, None
+        rows, cols, src_ld, dst_cols, xshape = ctx.cfg
+        gx = K.copy2d(_contig(g), dst_cols, rows, min(cols, dst_cols), src_ld, g.dtype)
+        return gx.view(xshape), None, None, None, None          # the input may have been any view of the rows x src_ld block
 
 
 def copy2d(x, rows, cols, src_ld, dst_cols):

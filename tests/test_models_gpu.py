@@ -386,6 +386,19 @@ def test_simple_vitgan_fp32_matches_reference_golden(cuda):
                                                               input_dim=24), (3, 8, 4, 4))
 
 
+@pytest.mark.parametrize("which", ["vitgan", "simple_vitgan"])
+def test_vitgan_golden_without_the_one_launch_attention(cuda, which, monkeypatch):
+    """The batched-GEMM attention path (what sequences too long for csrc/attn_tiny.hip's LDS panels take), with the zero-padded
+    projection rows stripped / restored around it: same golden vectors, forward and every gradient."""
+    monkeypatch.setenv("FFVC_ATTN_TINY", "0")
+    if which == "vitgan":
+        _check_mapper_golden("vitgan.npz", Generator(initialize_size=1, out_channels=8, input_dim=24, dim=12, num_heads=6,
+                                                     blocks=2), (3, 8, 8, 8))
+    else:
+        _check_mapper_golden("simple_vitgan.npz", SimpleGenerator(size=4, dim=12, num_heads=6, blocks=2, out_channels=8,
+                                                                  input_dim=24), (3, 8, 4, 4))
+
+
 @pytest.mark.parametrize("kind", ["vitgan", "simple_vitgan", "xtransformer"])
 @pytest.mark.parametrize("cdt", [F32, BF16, F16])
 def test_other_mappers_match_oracle(cuda, kind, cdt):
