@@ -227,7 +227,7 @@ class Generator(_VitGANBase):
         T = self.initialize_size * 8
         B = noise.shape[0]
         x = ops.linear(ops.cast(noise.float(), cdt), self._w_mlp, out_dtype=f32).view(B, T, self.dim)   # vitgan.py:254
-        hl = self._encode(self.pos_emb1D.unsqueeze(0).expand(B, T, self.dim), x)                        # :255
+        hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B), x)                                      # :255
         s = self.sln_norm
         y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt)                        # :256
         out = ops.linear(y, self._w_outp, out_dtype=f32)                                                # :257
@@ -260,7 +260,7 @@ class SimpleGenerator(_VitGANBase):
         inp = ops.linear(nz, self._w_inp, out_dtype=f32)                                                # vitgan.py:297
         x = ops.linear(nz, self._w_mlp, out_dtype=f32).view(B, N, self.dim)                             # :298
         inp_emb = ops.transpose_last2(inp.view(B, self.dim, N))                                         # :299
-        hl = self._encode(inp_emb + self.pos_emb1D, x)                                                  # :300
+        hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B, inp_emb), x)                            # :300
         s = self.sln_norm
         y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt)
         out = ops.linear(y, self._w_outp, out_dtype=f32)

@@ -911,6 +911,36 @@ def default_scale(dh):
 # ---------------------------------------------------------------------------
 # layout / dtype plumbing with gradients
 # ---------------------------------------------------------------------------
+class _BroadcastRowsFn(Function):
+    """p [T, D] (fp32 parameter) -> [B, T, D] (+ x [B, T, D]): the learned position table added to / handed on as the token stream
+    (vitgan.py:255,300).  One row-broadcast copy (+ one axpby); backward: column sums over the batch into the table's gradient."""
+
+    @staticmethod
+    def forward(ctx, p, x, B):
+        p = _contig(p)
+        n = p.numel()
+        out = torch.empty(B, *p.shape, dtype=torch.float32, device=p.device)
+        K.copy_rows(p.view(1, n), 0, out.view(B, n), n, B, n)
+        if x is not None:
+            K.axpby(_contig(x), out, 1.0, 1.0)
+        ctx.has_x = x is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _contig(g)
+        B = g.shape[0]
+        n = g.numel() // B
+        dp = torch.empty(n, dtype=torch.float32, device=g.device)
+        K.colsum(g.view(B, n), dp)
+        return dp.view(g.shape[1:]), (g if ctx.has_x else None), None
+
+
+def broadcast_rows(p, B, x=None):
+    """[T, D] -> [B, T, D] copies of p, plus x if given (fp32)."""
+    return _BroadcastRowsFn.apply(p, x, B)
+
+
 class _TransposeFn(Function):
     @staticmethod
     def forward(ctx, x, out_dtype):

@@ -119,7 +119,7 @@ def _worker(rank, world, port, q):
     q.put((rank, params, float(l), grads))
 
 
-def test_dp_world2_equals_single_process(cuda):
+def _two_ranks_once(limit):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -127,17 +127,29 @@ def test_dp_world2_equals_single_process(cuda):
     for p in procs:
         p.start()
     try:
-        res = _collect(q, procs)
+        res = _collect(q, procs, limit)
     finally:
         for p in procs:                      # never leave a rank behind (it would keep the device / the port)
             if p.is_alive():
                 p.join(timeout=20)
             if p.is_alive():
                 p.terminate()
-
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return res
+
+
+def test_dp_world2_equals_single_process(cuda):
+    # Two processes sharing ONE GPU through gloo is an arrangement only this test uses; on a loaded box a rank has been seen to
+    # stall past the limit (cold imports, the other rank holding the device).  One retry on a fresh port tells an environment
+    # hiccup from a defect: a real deadlock fails twice.
+    try:
+        res = _two_ranks_once(180.0)
+    except AssertionError as e:
+        if "hung after the rendezvous" not in str(e):
+            raise
+        res = _two_ranks_once(300.0)
     assert (res[0][1] == res[1][1]).all(), "replicas diverged"   # replicas stay bit-identical
     torch.manual_seed(0)
     ref, ref_loss, ref_grads = _run(0, 1)                      # rank-0 seed (5), all four prompts, no exchange
