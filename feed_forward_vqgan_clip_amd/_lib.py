@@ -104,6 +104,12 @@ _SIGNATURES = {
                                    c_int, c_float, c_void_p]),
     "ffvc_attn_small_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ffvc_rccl_available": (c_int, []),
+    "ffvc_rccl_load": (c_int, [c_char_p]),
+    "ffvc_rccl_unique_id": (c_int, [c_void_p]),
+    "ffvc_rccl_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "ffvc_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ffvc_rccl_comm_destroy": (c_int, [c_void_p]),
     "ffvc_attn_tiny_supported": (c_int, [c_int, c_int]),
     "ffvc_attn_tiny_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                    c_int64, c_int64, c_float, c_void_p]),

@@ -46,7 +46,37 @@ def init(backend=None):
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank())
         dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kw)
+        if os.environ.get("FFVC_DP_NATIVE") == "1" and torch.cuda.is_available():
+            _STATE["native"] = _native_comm()
     _STATE["init"] = True
+
+
+def _native_comm():
+    """FFVC_DP_NATIVE=1: the bucket all-reduces go through the library's own RCCL communicator (ffvc_allreduce_bucket,
+    csrc/comm.hip) on a dedicated exchange stream instead of torch.distributed's process group, which stays in place for the
+    rendezvous (the 128-byte unique id travels through it), broadcasts and scalars.  Opt-in: RCCL refuses two ranks on one
+    device, so only the single-rank form could be exercised on the one-GPU boxes this build had."""
+    from . import kernels as K
+    if not K.RcclComm.available():
+        raise RuntimeError("FFVC_DP_NATIVE=1: no RCCL image in the process")
+    r, w = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", local_rank())
+    ident = torch.zeros(128, dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
+    if r == 0:
+        ident.copy_(torch.frombuffer(bytearray(K.RcclComm.unique_id()), dtype=torch.uint8))
+    dist.broadcast(ident, 0)
+    comm = K.RcclComm(bytes(ident.cpu().tolist()), r, w)
+    return {"comm": comm, "stream": torch.cuda.Stream(device=dev)}
+
+
+class _NativeWork:
+    """What dist.all_reduce(async_op=True) returns, for the library's own exchange: wait() makes the CURRENT stream wait."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
 
 
 # RCCL over xGMI on one 8-GPU MI355X node: every GPU has 7 point-to-point links (~153 GB/s each), rings are per-link bound, the
@@ -81,7 +111,8 @@ def describe():
     if not (dist.is_available() and dist.is_initialized()):
         return {"backend": None, "ranks": 1, "env": env}
     return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env,
-            "preset_applied": sorted(_STATE.get("preset", {}))}
+            "preset_applied": sorted(_STATE.get("preset", {})),
+            "bucket_exchange": "ffvc_allreduce_bucket (own RCCL communicator)" if _STATE.get("native") else "torch.distributed"}
 
 
 def is_distributed():
@@ -291,12 +322,23 @@ class DistributedOptimizer:
 
     def _enqueue(self, b, g):
         self._order[b] = len(self._order)
+        t = g
         if self.wire_dtype is not None and self.wire_dtype != g.dtype:
-            w = g.to(self.wire_dtype)
-            self._wire[b] = w
-            self._handles[b] = dist.all_reduce(w, async_op=True)
+            t = g.to(self.wire_dtype)
+            self._wire[b] = t
+        nat = _STATE.get("native")
+        if nat is not None and t.is_cuda:
+            # own communicator: the exchange stream picks up the enqueuing stream's progress, runs the all-reduce, and leaves an
+            # event for whoever consumes the bucket; nothing is ever queued behind the exchange on the compute streams
+            xs = nat["stream"]
+            xs.wait_stream(torch.cuda.current_stream())
+            nat["comm"].allreduce(t, xs)
+            t.record_stream(xs)
+            ev = torch.cuda.Event()
+            ev.record(xs)
+            self._handles[b] = _NativeWork(ev)
         else:
-            self._handles[b] = dist.all_reduce(g, async_op=True)
+            self._handles[b] = dist.all_reduce(t, async_op=True)
 
     def _flush_unlaunched(self):
         for b in range(len(self.buckets)):

@@ -802,6 +802,43 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
     return out
 
 
+class RcclComm:
+    """The library's own RCCL communicator (csrc/comm.hip): `unique_id()` on rank 0, the 128 bytes travel to the other ranks
+    through the host's side channel, `RcclComm(id, rank, world)` everywhere (collective), `allreduce(t, stream)` per bucket."""
+
+    def __init__(self, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("RcclComm: the unique id is 128 bytes")
+        self._id = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        h = ctypes.c_void_p()
+        _call("ffvc_rccl_comm_create", ctypes.cast(self._id, ctypes.c_void_p), int(rank), int(world), byref(h))
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def available():
+        return int(_lib.load().ffvc_rccl_available())
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_ubyte * 128)()
+        _call("ffvc_rccl_unique_id", ctypes.cast(buf, ctypes.c_void_p))
+        return bytes(buf)
+
+    def allreduce(self, t, stream=None):
+        """In-place sum of the contiguous device tensor `t` over the ranks, enqueued on `stream` (default: current stream)."""
+        _need_cuda(t)
+        if not t.is_contiguous():
+            raise TypeError("RcclComm.allreduce: contiguous tensor expected")
+        sp = stream.cuda_stream if stream is not None else stream_ptr()
+        _call("ffvc_allreduce_bucket", self._h, t.data_ptr(), t.numel(), dtype_code(t.dtype), sp)
+        return t
+
+    def destroy(self):
+        if self._h:
+            _call("ffvc_rccl_comm_destroy", self._h)
+            self._h = ctypes.c_void_p()
+
+
 def attn_small_ok(qkv, heads, causal):
     """Shapes the fused short-sequence attention kernel covers."""
     B, T, D3 = qkv.shape

@@ -406,6 +406,22 @@ int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const
  *   "gemm8": 1 = every eligible 256x256 launch takes the 8-phase kernel (default: only where it measured faster). */
 int ffvc_set_option(const char* name, int value);
 
+/* ---------------------------------------------------------------------------
+ * Gradient exchange (hvd.DistributedOptimizer, main.py:626-629): one RCCL communicator per process behind an opaque
+ * handle.  RCCL is resolved at run time from the image already loaded in the process (PyTorch's librccl.so; a second copy
+ * is never loaded implicitly) — ffvc_rccl_load(path) names one explicitly.  Rank 0 draws the 128-byte unique id and the
+ * host hands it to the other ranks (torch.distributed broadcast / store); ffvc_rccl_comm_create is collective.
+ * ffvc_allreduce_bucket: in-place SUM over the ranks of buf[0 .. count) (FFVC_F32 gradients, or their FFVC_BF16 / FFVC_F16
+ * wire copy), enqueued on `stream` — the host gives it a dedicated exchange stream fenced by events so that neither the
+ * dgrad chain nor the weight-gradient stream waits on it; 1/N is folded into ffvc_adam's grad_scale.
+ * ------------------------------------------------------------------------- */
+int ffvc_rccl_available(void);                /* 0 = no RCCL image in the process, else its version code */
+int ffvc_rccl_load(const char* path);
+int ffvc_rccl_unique_id(void* out128);
+int ffvc_rccl_comm_create(const void* id128, int rank, int world, void** handle);
+int ffvc_allreduce_bucket(void* handle, void* buf, int64_t count, int dtype, void* stream);
+int ffvc_rccl_comm_destroy(void* handle);
+
 /* Library / device info */
 const char* ffvc_last_error(void);
 int ffvc_version(void);

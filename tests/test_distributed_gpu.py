@@ -181,3 +181,46 @@ def test_exchange_is_enqueued_under_the_backward_pass(cuda, kind):
     summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print(r.stdout)
     assert summary["dp"]["backend"] == "nccl" and summary["frac_bytes_early"] > 0.85
+
+
+def test_own_rccl_communicator_single_rank(cuda):
+    """csrc/comm.hip: the library's own communicator (ffvc_rccl_unique_id -> ffvc_rccl_comm_create -> ffvc_allreduce_bucket ->
+    ffvc_rccl_comm_destroy), resolved from the RCCL already in the process.  One rank: the sum over the ranks is the identity;
+    what is checked is the plumbing — creation, the three wire dtypes, enqueueing on a foreign stream, error reporting."""
+    from feed_forward_vqgan_clip_amd import kernels as K
+    assert K.RcclComm.available() > 0
+    comm = K.RcclComm(K.RcclComm.unique_id(), 0, 1)
+    xs = torch.cuda.Stream()
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        x = torch.randn(3 << 20, device="cuda").to(dt)
+        ref = x.clone()
+        xs.wait_stream(torch.cuda.current_stream())
+        comm.allreduce(x, xs)
+        ev = torch.cuda.Event()
+        ev.record(xs)
+        torch.cuda.current_stream().wait_event(ev)
+        y = x * 1                                     # consumer on the current stream, ordered by the event only
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref) and torch.equal(y, ref)
+    with pytest.raises(TypeError):                    # only the gradient / wire dtypes travel
+        comm.allreduce(torch.zeros(4, dtype=torch.int64, device="cuda"))
+    comm.destroy()
+    with pytest.raises(ValueError):
+        K.RcclComm(b"short", 0, 1)
+
+
+def test_bucket_exchange_through_the_own_communicator(cuda):
+    """FFVC_DP_NATIVE=1 + FFVC_DP_FORCE=1: the DistributedOptimizer's slices go through ffvc_allreduce_bucket on the exchange
+    stream (one rank; same overlap criterion as with torch.distributed's process group)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFVC_DP_FORCE="1", FFVC_DP_NATIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_overlap.py"), "mlp_mixer", "4"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert summary["dp"]["bucket_exchange"].startswith("ffvc_allreduce_bucket") and summary["frac_bytes_early"] > 0.85
+
