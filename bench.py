@@ -331,13 +331,17 @@ def main():
         it += 1
     sync()
     clk0 = K.clock_sample()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU time (diagnostic only)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss, _ = stepper(batches[it], next_inp=batches[it + 1] if args.prefetch_text else None)
+        marks[i + 1].record()
         it += 1
     clk1 = K.clock_sample()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
     sclk_mhz = K.effective_clock_mhz(clk0, clk1)     # engine clock averaged over the timed region (and over the XCDs)
     if hvd.is_distributed():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -352,7 +356,7 @@ def main():
         "lib_sha256": hashlib.sha256(open(_flib.LIB_PATH, "rb").read()).hexdigest(),   # which libffvc_hip.so produced the line
         "metric": "train-step images/sec (whole node), ViT-B/32 + VQGAN-f16 256x256, bs=64, 1/2/4/8 GPU",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step": ms_per_step, "step_ms_main_stream": step_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.dtype + ("+fp8(clip image tower linears)" if args.clip_fp8 else ""), "data": "synthetic seeded token batches, random-init weights (no network)",
         "precision_recipe": {"bf16": "bf16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
                                      "fp32 text tower, VQ distances and loss",

@@ -25,6 +25,7 @@ F_UPSAMPLE2X = 128
 F_ACCUM_OUT = 256
 F_GN_SUMS = 512
 F_COLSUM = 1024
+F_SPLITK_INKERNEL = 4096
 F_AUX_ACTGRAD = 2048
 
 

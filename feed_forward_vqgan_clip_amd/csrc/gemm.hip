@@ -494,14 +494,17 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   if (d.batch_inner < 1) d.batch_inner = 1;
   FFVC_CHECK_ARG(d.batch <= 65535, "ffvc_gemm: batch %d > 65535", d.batch);
   if (d.split_k < 1) d.split_k = 1;
-  FFVC_CHECK_ARG(d.split_k == 1 || (d.flags & FFVC_F_ATOMIC_OUT) || d.slab_stride > 0,
-                 "ffvc_gemm: split_k>1 needs FFVC_F_ATOMIC_OUT or slab_stride (partial slabs)");
+  FFVC_CHECK_ARG(d.split_k == 1 || (d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_SPLITK_INKERNEL)) || d.slab_stride > 0,
+                 "ffvc_gemm: split_k>1 needs FFVC_F_ATOMIC_OUT, FFVC_F_SPLITK_INKERNEL or slab_stride (partial slabs)");
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_SPLITK_INKERNEL) || (d.slab_stride == 0 && !(d.flags & FFVC_F_ATOMIC_OUT) && d.in_dtype != FFVC_F32),
+                 "ffvc_gemm: FFVC_F_SPLITK_INKERNEL excludes slabs / atomics and needs a 16-bit dtype");
   FFVC_CHECK_ARG(d.slab_stride == 0 || ((d.flags & FFVC_F_OUT_F32) && !d.bias && !d.residual && d.act == FFVC_ACT_NONE &&
                                         !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) && mult(d.slab_stride, 4)),
                  "ffvc_gemm: slab output must be a plain fp32 store (no bias/residual/activation)");
   FFVC_CHECK_ARG(!(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) || (d.flags & FFVC_F_OUT_F32),
                  "ffvc_gemm: atomic / accumulating output must be fp32");
-  FFVC_CHECK_ARG(!(d.flags & FFVC_F_ACCUM_OUT) || d.split_k == 1, "ffvc_gemm: FFVC_F_ACCUM_OUT needs split_k == 1");
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_ACCUM_OUT) || d.split_k == 1 || (d.flags & FFVC_F_SPLITK_INKERNEL),
+                 "ffvc_gemm: FFVC_F_ACCUM_OUT needs split_k == 1 (or FFVC_F_SPLITK_INKERNEL: one owner per tile)");
   FFVC_CHECK_ARG(!((d.flags & (FFVC_F_WRITE_PREACT | FFVC_F_MUL_ACT_GRAD)) && !d.aux),
                  "ffvc_gemm: aux pointer required by flags");
   const int es = ffvc_dtype_size(d.in_dtype);
@@ -566,6 +569,8 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
     if (r2 == 1) return fixup();
     if (r2 < 0) return r2;
   }
+  FFVC_CHECK_ARG(!(d.flags & FFVC_F_SPLITK_INKERNEL) || d.split_k == 1,
+                 "ffvc_gemm: FFVC_F_SPLITK_INKERNEL: this shape / alignment does not take an LDS-DMA kernel that implements it");
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_GN_SUMS), "ffvc_gemm: FFVC_F_GN_SUMS is only available on the bf16 LDS-DMA path");
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_COLSUM), "ffvc_gemm: FFVC_F_COLSUM is only available on the 16-bit LDS-DMA path");
   int rc;

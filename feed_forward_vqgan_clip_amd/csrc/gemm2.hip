@@ -649,6 +649,10 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     // round 2 (profiles/r02_wgrad_ab.txt): with 256x256 tiles and a 4-way slab split-K the DMA path passes it on the big
     // square-ish weight gradients (4096x1024x16384: 856 vs 640 TFLOP/s); narrow outputs / short reductions stay on v1.
     if (env_bm == 128 || env_bm == 256 || env_bm == 512) return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, cfg);
+    // FFVC_F_SPLITK_INKERNEL: the caller asked for the kernel that combines its K slices itself — the 256x256 tile, whatever the
+    // fill heuristic below thinks of the grid
+    if ((d.flags & FFVC_F_SPLITK_INKERNEL) && d.split_k > 1 && env_bm == 1 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.batch == 1)
+      return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
     if (env_bm == 1 && d.M >= 1024 && d.N >= 1024 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.K >= 8192 && d.batch == 1 &&
         (int64_t)(d.M / 256) * (d.N / 256) * (d.split_k < 1 ? 1 : d.split_k) >= 192)
       return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);

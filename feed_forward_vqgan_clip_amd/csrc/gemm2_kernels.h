@@ -578,7 +578,8 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // in-kernel split-K (see the combine in front of the epilogue): uniform mode = blockIdx.z is the K slice of every tile;
   // tail mode (p.sk_slices > 1, 1-D grid) = work items below p.sk_full are whole tiles, the rest are K slices of the tiles of
   // the last, partly filled round
-  constexpr bool SKFIX = FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256));
+  constexpr bool SKFIX = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256))) ||
+                         (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS && BM == 256 && BN == 256);        // + weight gradients
   int wl = blockIdx.x, sk_slice = blockIdx.z, sk_n = gridDim.z;
   if constexpr (SKFIX) {
     if (p.sk_slices > 1) {
@@ -802,23 +803,28 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // ticket is a device-scope atomic taken after the stores have retired.  Measured alternatives: a release fence
   // (buffer_wbl2 = write back the XCD's whole L2) made the split launch slower than the under-filled one (cfg3 78.3 vs
   // 72.4 ms); `volatile` accesses are followed by a full vmcnt(0) each (16 serial round trips per slice, +25 us per launch).
-  if constexpr (SKFIX && M16) {
+  if constexpr (SKFIX) {
     if (p.sk_ws != nullptr && sk_n > 1) {
-      constexpr int NT = 64 * NW, TILE = BM * BN, NP = 4 * 2 * MT * 2;       // 8-byte pieces per thread
+      constexpr int NT = 64 * NW, TILE = BM * BN, NP = 16 * MT;              // 8-byte pieces per thread (32 MT accumulator floats)
+      // piece pc of the thread's accumulators, whichever MFMA shape filled them
+      // (element access by value: a reference cannot bind to a vector element)
+      auto piece_get = [&](int pc, int e) -> float {
+        if constexpr (M16) return acc16[pc / (2 * MT * 2)][(pc / 2) % (2 * MT)][2 * (pc % 2) + e];
+        else return acc[pc / (MT * 8)][(pc / 8) % MT][2 * (pc % 8) + e];
+      };
+      auto piece_set = [&](int pc, int e, float v) {
+        if constexpr (M16) acc16[pc / (2 * MT * 2)][(pc / 2) % (2 * MT)][2 * (pc % 2) + e] = v;
+        else acc[pc / (MT * 8)][(pc / 8) % MT][2 * (pc % 8) + e] = v;
+      };
       const int nz = sk_n;
       const int64_t tile_id = p.sk_slices > 1 ? (int64_t)(wl - p.sk_full) : (int64_t)blockIdx.y * n_tiles + tile;
       uint64_t* base = (uint64_t*)(p.sk_ws + tile_id * nz * TILE);
       uint64_t* mine = base + (int64_t)sk_slice * (TILE / 2);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2 * MT; ++b)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const f32x2_t v = {acc16[a][b][2 * h], acc16[a][b][2 * h + 1]};
-            __hip_atomic_store(mine + (((a * 2 * MT + b) * 2 + h) * NT + tid), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-          }
+      for (int pc = 0; pc < NP; ++pc) {
+        const f32x2_t v = {piece_get(pc, 0), piece_get(pc, 1)};
+        __hip_atomic_store(mine + (pc * NT + tid), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial tile has left this CU before the ticket is taken
       __syncthreads();
       if (tid == 0) *(volatile unsigned*)smem = atomicAdd(p.sk_cnt + tile_id, 1u);
@@ -850,11 +856,8 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
           }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int pc = c0 + i, a = pc / (2 * MT * 2), b = (pc / 2) % (2 * MT), h = pc % 2;
-          acc16[a][b][2 * h] = sum[i][0];
-          acc16[a][b][2 * h + 1] = sum[i][1];
+          piece_set(c0 + i, 0, sum[i][0]);
+          piece_set(c0 + i, 1, sum[i][1]);
         }
       }
       __syncthreads();
@@ -1340,6 +1343,28 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
           d.sk_cnt = cnt;
         }
       }
+    }
+  }
+  if (d.flags & FFVC_F_SPLITK_INKERNEL) {
+    // the caller's explicit form: d.split_k K slices per tile, combined inside the launch (weight gradients: 64 tiles x 4)
+    constexpr bool CAP = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256))) ||
+                         (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS && BM == 256 && BN == 256);
+    constexpr int SMAXH = (BM == 256) ? 8 : 16;
+    if (split > 1) {
+      if (!CAP || split > SMAXH || split > ksteps) {
+        ffvc_set_error("ffvc_gemm: FFVC_F_SPLITK_INKERNEL: split_k=%d not available for this kernel (%dx%d tile, modes %d/%d)", split, BM, BN,
+                       XMODE, WMODE);
+        return FFVC_E_BADARG;
+      }
+      const int64_t wgs = (int64_t)n_tiles * d.batch;
+      float* ws = nullptr;
+      uint32_t* cnt = nullptr;
+      if (!skfix_scratch(st, (size_t)wgs * split * BM * BN * sizeof(float), (size_t)wgs, &ws, &cnt)) {
+        ffvc_set_error("ffvc_gemm: FFVC_F_SPLITK_INKERNEL: scratch allocation failed");
+        return FFVC_E_BADARG;
+      }
+      d.sk_ws = ws;
+      d.sk_cnt = cnt;
     }
   }
   if (split > ksteps) split = ksteps < 1 ? 1 : ksteps;

@@ -791,11 +791,15 @@ def mul_dev_scalar(x, s):
     return y
 
 
-def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, **kw):
+def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, in_kernel=False, **kw):
     """out[M,N] (fp32, contiguous) += X W^T with the K range cut into `split_k` slices whose partial tiles go to
-    slabs (plain stores) and are combined by one ffvc_slab_reduce pass."""
+    slabs (plain stores) and are combined by one ffvc_slab_reduce pass — or, with in_kernel=True, are combined inside the
+    launch by the last slice to arrive on each tile (FFVC_F_SPLITK_INKERNEL: no slabs, no reduce launch; the caller must know
+    the shape takes a kernel that implements it)."""
     if split_k <= 1:
         return gemm(x, w, out, M, N, K, flags=kw.pop("flags", 0) | F_ACCUM_OUT, **kw)
+    if in_kernel:
+        return gemm(x, w, out, M, N, K, split_k=split_k, flags=kw.pop("flags", 0) | F_ACCUM_OUT | _lib.F_SPLITK_INKERNEL, **kw)
     slabs = torch.empty(split_k, M, N, dtype=torch.float32, device=out.device)
     gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
     _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())

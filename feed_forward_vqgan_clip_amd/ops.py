@@ -143,6 +143,10 @@ def _grad_buf(p):
     return p.grad
 
 
+# A/B: channel-MLP weight gradients combine their K slices inside the launch (FFVC_F_SPLITK_INKERNEL) instead of fp32 slabs + one
+# ffvc_slab_reduce.  Measured neutral on cfg2 (135.5 vs 135.6 ms: the reduce launches leave the side stream, the combine joins the
+# GEMM: TN class 13.5 -> 14.4 ms), so the slab form stays the default.
+_WGRAD_INKERNEL = os.environ.get("FFVC_WGRAD_INKERNEL", "0") != "0"
 _TM_WGRAD_INKERNEL = os.environ.get("FFVC_TOKMIX_WGRAD_INKERNEL", "0") != "0"   # A/B: one launch with the in-kernel split-K instead of slabs + reduce
 _SK_TARGET = int(os.environ.get("FFVC_SK_TARGET", "768"))  # A/B: workgroups a small-output weight gradient is split into
 _WGRAD_SK = int(os.environ.get("FFVC_WGRAD_SK", "0"))     # A/B: cap of the split-K factor of the 256x256-tile wgrads
@@ -170,9 +174,14 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
     # the master's own shape: W.N / W.K are the (possibly zero-padded) row strides of dy / x (ParamArena.make_weights)
     Nr = W.weight.shape[0]
     Kr = W.weight.numel() // Nr
-    sk = _split_k(Nr, Kr, rows, bk, big_tiles=dy2d.dtype in K.LOWP and (ldy or W.N) == Nr and W.K == Kr)
+    big = dy2d.dtype in K.LOWP and (ldy or W.N) == Nr and W.K == Kr
+    sk = _split_k(Nr, Kr, rows, bk, big_tiles=big)
+    # the 256x256-tile weight-gradient kernel (same conditions as csrc/gemm2.hip's dispatch) combines its K slices inside the
+    # launch: no fp32 slabs, no ffvc_slab_reduce pass
+    inker = (_WGRAD_INKERNEL and big and 1 < sk <= 8 and Nr >= 1024 and Kr >= 1024 and Nr % 256 == 0 and Kr % 256 == 0 and rows >= 8192 and
+             (Nr // 256) * (Kr // 256) * sk >= 192)
     with _on_side(dy2d, x2d):
-        K.gemm_splitk_accumulate(dy2d, x2d, wg, Nr, Kr, rows, sk, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
+        K.gemm_splitk_accumulate(dy2d, x2d, wg, Nr, Kr, rows, sk, in_kernel=inker, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
                                  w_mode=K.OP_TRANS)
         if bg is not None:
             K.colsum(dy2d, bg, accumulate=True, ld=ldy)

@@ -65,6 +65,12 @@ extern "C" {
                                  * pass), with FFVC_F_MUL_ACT_GRAD the backward epilogue is a plain multiply.  16-bit dtypes,
                                  * batch 1. */
 #define FFVC_F_ACCUM_OUT 256    /* y += acc with plain read-modify-write (fp32 y, split_k == 1: one owner per element) */
+#define FFVC_F_SPLITK_INKERNEL 4096 /* split_k > 1 handled INSIDE the launch: every K slice parks its fp32 partial tile in library
+                                  * scratch, the last slice to arrive on a tile sums them in slice order and runs the ordinary
+                                  * epilogue (any epilogue, FFVC_F_ACCUM_OUT included): no slabs, no reduce launch.  16-bit LDS-DMA
+                                  * kernels only (K-major x K-major 128x128 / 256x256 tiles, weight gradients on 256x256 tiles);
+                                  * ffvc_gemm fails with FFVC_E_BADARG when the shape cannot take that path; split_k <= 8 (16 for
+                                  * the 128x128 tile) */
 
 /*
  * ffvc_gemm — y[m,n] (+)= act( alpha * sum_k X[m,k] * W[n,k] + bias ) (+ residual)

@@ -556,3 +556,27 @@ def test_partly_filled_last_round_is_split_along_k(cuda, dt, M, N, K_):
     assert _rel(aux, pre) < LOTOL[dt] and _rel(h, F.gelu(pre)) < LOTOL[dt]
     # the tail rows (last tile row) against the head rows of the same launch: both must be right
     assert _rel(y[-64:], ref[-64:]) < 3e-5 and _rel(y[:256], ref[:256]) < 3e-5
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,Kred,sk", [(1024, 4096, 16384, 4), (4096, 1024, 16384, 4), (1024, 1024, 8192, 3), (2048, 1024, 32768, 8)])
+def test_weight_gradient_split_k_combined_inside_the_launch(cuda, dt, M, N, Kred, sk):
+    """FFVC_F_SPLITK_INKERNEL on the 256x256-tile weight-gradient kernel (both operands reduction-major): out += dy^T x with the K
+    slices combined by the last workgroup per tile — against fp64, against the slab + reduce form, and bit-repeatable."""
+    dy, x = _mk((Kred, M), dt, cuda, 1, 0.5), _mk((Kred, N), dt, cuda, 2, 0.5)
+    base = _mk((M, N), torch.float32, cuda, 3)
+    ref = base.double() + dy.double().T @ x.double()
+
+    def run(in_kernel):
+        out = base.clone()
+        K.gemm_splitk_accumulate(dy, x, out, M, N, Kred, sk, in_kernel=in_kernel, ldx=M, ldw=N, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
+        return out
+
+    a, b = run(True), run(False)
+    assert _rel(a, ref) < 2e-5 and _rel(b, ref) < 2e-5
+    assert torch.equal(a, run(True))
+    # a shape that does not take the 256x256 kernel refuses the flag instead of silently splitting some other way
+    with pytest.raises(RuntimeError):
+        small = torch.zeros(128, 128, dtype=torch.float32, device=cuda)
+        K.gemm_splitk_accumulate(dy[:512, :128].contiguous(), x[:512, :128].contiguous(), small, 128, 128, 512, 2, in_kernel=True, ldx=128,
+                                 ldw=128, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
