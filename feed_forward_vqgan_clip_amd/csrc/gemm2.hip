@@ -560,7 +560,12 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       rule = e ? atoi(e) : 1;
     }
     if (rule && d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) {
-      if (d.N > 128 && t512 >= 96) cfg = 512;
+      // 70+ big tiles: the 256x256 kernel even with a third of the CUs idle (6400x768x3072, 75 tiles: 68 vs 102 us; at 64 tiles and a
+      // short reduction the small tile still wins: 8192x512x512 12 vs 17 us); 24..69 of
+      // them with a long reduction: still the 256x256 kernel, launch2 splits it along K inside the launch (4928x512x6144, 40 tiles:
+      // 60 vs 94 us; 3200x768x3072: 46 vs 50)
+      const bool longk = d.K >= 2048 && d.batch == 1 && (d.split_k <= 1) && d.slab_stride == 0;
+      if (d.N > 128 && (t512 >= 70 || (t512 >= 24 && longk))) cfg = 512;
       else if (t256 >= 192) cfg = 256;
       else cfg = 128;
     }

@@ -1345,6 +1345,33 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
       }
     }
   }
+  if constexpr (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM == 256 && BN == 256) {
+    // A 256x256-tile grid that fills a fraction of the chip with a long reduction (ViT linears at 16-32 samples per GPU, the text
+    // tower): 2-4 K slices per tile, combined inside the launch (6400x768x3072, 75 tiles: 68 -> 55 us; 4928x512x6144, 40 tiles:
+    // 123 -> 60 us; 8192x1024x4096, 128 tiles: 85 -> 76 us).  FFVC_SK_FIXUP=0 off.
+    static int fix256 = -1;
+    if (fix256 < 0) {
+      const char* e = getenv("FFVC_SK_FIXUP");
+      fix256 = e ? atoi(e) : 1;
+    }
+    if (fix256 && split == 1 && !(d.flags & FFVC_F_SPLITK_INKERNEL) && d.slab_stride == 0 && d.batch == 1 && n_tiles >= 24 && n_tiles <= 100 &&
+        ksteps >= 32 && dma_operand_ok<XMODE>(d, true) && dma_operand_ok<WMODE>(d, false)) {
+      int want = 200 / n_tiles;
+      if (want > 4) want = 4;
+      if (want > ksteps / 12) want = ksteps / 12;
+      if (want >= 2) {
+        const int len = ceil_div(ksteps, want);
+        const int nz = ceil_div(ksteps, len);
+        float* ws = nullptr;
+        uint32_t* cnt = nullptr;
+        if (nz >= 2 && skfix_scratch(st, (size_t)n_tiles * nz * BM * BN * sizeof(float), (size_t)n_tiles, &ws, &cnt)) {
+          split = nz;
+          d.sk_ws = ws;
+          d.sk_cnt = cnt;
+        }
+      }
+    }
+  }
   if (d.flags & FFVC_F_SPLITK_INKERNEL) {
     // the caller's explicit form: d.split_k K slices per tile, combined inside the launch (weight gradients: 64 tiles x 4)
     constexpr bool CAP = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256))) ||

@@ -495,7 +495,8 @@ def test_gemm_actgrad_storage(cuda, M, N, Kd, act, ldt):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K_", [(512, 1024, 4096), (512, 1024, 1024), (300, 200, 2048), (616, 768, 9216), (64, 128, 8192)])
+@pytest.mark.parametrize("M,N,K_", [(512, 1024, 4096), (512, 1024, 1024), (300, 200, 2048), (616, 768, 9216), (64, 128, 8192),
+                                    (6400, 768, 3072), (4928, 512, 6144), (3200, 768, 2048)])      # the last three: 256x256 tiles, 2-4 slices
 def test_underfilled_grid_in_kernel_split_k(cuda, dt, M, N, K_):
     """Few output tiles x long reduction (VitGAN / x-transformer linears at a per-GPU batch of 16-32 samples): the launch is split
     along K inside the kernel and the last workgroup per tile runs the fused epilogue on the summed tile.  Same answers as the
