@@ -357,10 +357,13 @@ class XTransformer(_MapperBase):
         else:
             # token 0 = the input, n zero tokens behind it (:38-40); the zero rows go through project_in like any other
             # row (one use of the weight pack per step keeps the fused wgrad / all-reduce bookkeeping simple)
-            xin = torch.cat((xc.view(B, 1, -1), torch.zeros(B, n, xc.shape[1], dtype=cdt, device=xc.device)), dim=1)
+            xin = ops.copy2d(xc, B, xc.shape[1], xc.shape[1], (n + 1) * xc.shape[1]).view(B, n + 1, -1)   # [x | 0 ... 0] per sample
             h = ops.linear(xin, self._w_in, out_dtype=f32)
             L = n + 1
-        h = (h + t.pos_emb.emb.weight[:L] * (dim ** -0.5)).contiguous()                     # scaled abs. pos. emb.
+        if h.is_contiguous():                                                               # scaled abs. pos. emb.: own kernels
+            h = ops.broadcast_rows(t.pos_emb.emb.weight[:L], B, h, dim ** -0.5)
+        else:                                                                               # (the expanded add_input branch)
+            h = (h + t.pos_emb.emb.weight[:L] * (dim ** -0.5)).contiguous()
         for (n1, Wq, Wk, Wv, Wo, n2, W1, W2) in self._xl:
             hn, hid = ops.layernorm_fork(h, n1.weight, n1.bias, cdt)                        # pre-norm
             o = ops.attention(ops.qkv3(hn, Wq, Wk, Wv), self.heads, 64 ** -0.5, True)       # causal, dim_head 64

@@ -925,14 +925,16 @@ class _BroadcastRowsFn(Function):
     (vitgan.py:255,300).  One row-broadcast copy (+ one axpby); backward: column sums over the batch into the table's gradient."""
 
     @staticmethod
-    def forward(ctx, p, x, B):
+    def forward(ctx, p, x, B, scale):
         p = _contig(p)
         n = p.numel()
         out = torch.empty(B, *p.shape, dtype=torch.float32, device=p.device)
         K.copy_rows(p.view(1, n), 0, out.view(B, n), n, B, n)
         if x is not None:
-            K.axpby(_contig(x), out, 1.0, 1.0)
-        ctx.has_x = x is not None
+            K.axpby(_contig(x), out, 1.0, float(scale))          # out = x + scale * p
+        elif scale != 1.0:
+            raise ValueError("broadcast_rows: a scale needs an x to add to")
+        ctx.has_x, ctx.scale = x is not None, float(scale)
         return out
 
     @staticmethod
@@ -942,12 +944,14 @@ class _BroadcastRowsFn(Function):
         n = g.numel() // B
         dp = torch.empty(n, dtype=torch.float32, device=g.device)
         K.colsum(g.view(B, n), dp)
-        return dp.view(g.shape[1:]), (g if ctx.has_x else None), None
+        if ctx.scale != 1.0:
+            K.axpby(dp, dp, ctx.scale, 0.0)
+        return dp.view(g.shape[1:]), (g if ctx.has_x else None), None, None
 
 
-def broadcast_rows(p, B, x=None):
-    """[T, D] -> [B, T, D] copies of p, plus x if given (fp32)."""
-    return _BroadcastRowsFn.apply(p, x, B)
+def broadcast_rows(p, B, x=None, scale=1.0):
+    """[T, D] -> [B, T, D]: x + scale * p with p broadcast over the batch (fp32); without x, B copies of p."""
+    return _BroadcastRowsFn.apply(p, x, B, scale)
 
 
 class _TransposeFn(Function):
