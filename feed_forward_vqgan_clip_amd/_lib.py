@@ -87,6 +87,8 @@ class GemmDesc(Structure):
         ("sk_cnt", c_void_p),
         ("sk_full", c_int32),
         ("sk_slices", c_int32),
+        ("y8_state", c_void_p),
+        ("y8_fmt", c_int32),
     ]
 
 

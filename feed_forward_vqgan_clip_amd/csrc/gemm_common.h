@@ -237,6 +237,9 @@ constexpr int EPI_K_ANY = EPI_K_ANY_FWD | EPI_K_ANY_BWD;
 // Output classes of the lean kernels (again launcher-checked): 16-bit plain store without residual (dgrads, qkv), fp32 store
 // with an fp32 residual (the projections back into the fp32 residual stream), plain fp32 store (weight-gradient slabs).
 constexpr int EPI_O_T = 512, EPI_O_F32R = 1024, EPI_O_F32 = 2048;
+// fp8 output of the MLP kinds (frozen towers, ffvc_gemm_fp8): y gets e4m3 / e5m2 bytes scaled by p.y8_state[0]; the running amax goes
+// to p.y8_state[1] (desc fields y8_state / y8_fmt)
+constexpr int EPI_O_F8E4 = 4096, EPI_O_F8E5 = 8192, EPI_O_F8 = EPI_O_F8E4 | EPI_O_F8E5;
 
 template <typename T, int EPI = EPI_ALL>
 __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,
@@ -312,7 +315,7 @@ __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, 
     }
   }
   if constexpr ((EPI & (EPI_K_ANY | EPI_O_T)) != 0) {
-    store8((T*)p.y + yrow + n, v);
+    if constexpr ((EPI & EPI_O_F8) == 0) store8((T*)p.y + yrow + n, v);      // (fp8 output: the caller converts and stores v)
     return;
   } else if constexpr ((EPI & EPI_O_F32R) != 0) {
     const f32x8 r = load8((const float*)p.residual + rrow + n);
@@ -362,6 +365,10 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const ffvc_gemm_desc& p,
   (void)h;
   const bool gn = (EPI & EPI_GN) && (flags & FFVC_F_GN_SUMS);
   float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [nt][4-channel half]
+  float f8_amax = 0.0f, f8_scale = 1.0f;
+  if constexpr ((EPI & EPI_O_F8) != 0) f8_scale = p.y8_state[0];
+  (void)f8_amax;
+  (void)f8_scale;
   const bool cs_on = (EPI & (EPI_ACT | EPI_K_BWD | EPI_K_MULAUX)) && (flags & FFVC_F_COLSUM);
   float cs[2][8];                                                                      // [nt][column of this lane]
 #pragma unroll
@@ -403,6 +410,29 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const ffvc_gemm_desc& p,
         }
         if (mok[i] && n < p.N) {
           epilogue_oct<T, EPI>(p, v, n, yrow[i], rrow[i], arow[i], flags);
+          if constexpr ((EPI & EPI_O_F8) != 0) {
+            constexpr float LIM = (EPI & EPI_O_F8E4) ? 448.0f : 57344.0f;
+            float q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              f8_amax = fmaxf(f8_amax, fabsf(v.v[j]));
+              const float s = v.v[j] * f8_scale;
+              q[j] = s != s ? s : fminf(fmaxf(s, -LIM), LIM);                 // saturate, keep NaN a NaN
+            }
+            int lo = 0, hi = 0;
+            if constexpr ((EPI & EPI_O_F8E4) != 0) {
+              lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], lo, false);
+              lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+              hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], hi, false);
+              hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+            } else {
+              lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], lo, false);
+              lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], lo, true);
+              hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], hi, false);
+              hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], hi, true);
+            }
+            *(u32x2_t*)((unsigned char*)p.y + yrow[i] + n) = u32x2_t{(uint32_t)lo, (uint32_t)hi};
+          }
           if (gn) {   // moments of the fp32 values before the bf16 store (the rounding noise adds ~1e-6 of E[x^2])
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -420,6 +450,13 @@ __device__ __forceinline__ void gemm_epilogue_rows_impl(const ffvc_gemm_desc& p,
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+  }
+  if constexpr ((EPI & EPI_O_F8) != 0) {
+    // running amax of the tensor just written (sets the scale of the NEXT step): one atomic per wave; values >= 0, so the
+    // unsigned order of the bit patterns is the float order
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) f8_amax = fmaxf(f8_amax, __shfl_xor(f8_amax, o, 64));
+    if (lane == 0 && f8_amax > 0.0f) atomicMax((unsigned int*)(p.y8_state + 1), __float_as_uint(f8_amax));
   }
   if (cs_on) {
     // column sums of everything this wave stored: fold the 16 row-lanes, one fp32 atomic per column and wave

@@ -161,6 +161,23 @@ int launch_f8(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, c
     // backward (e5m2 gradients): plain 16-bit dgrads and the aux-multiply
     const bool wants_act = d.act != FFVC_ACT_NONE || (d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM));
     const bool plain_store = !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_BIAS_ALONG_M)) && vec_ok == 2;
+    if (d.y8_state) {
+      // fp8 OUTPUT: the hidden activation (forward, e4m3) / hidden gradient (backward, e5m2) of a frozen MLP leaves the epilogue as
+      // the next fp8 GEMM's operand — no 16-bit tensor, no separate quantisation pass
+      const bool bwd = d.flags & FFVC_F_MUL_ACT_GRAD;
+      const bool plain_out8 = plain_store && !d.residual && !(d.flags & FFVC_F_OUT_F32);
+      const bool ok = plain_out8 && (d.flags & FFVC_F_AUX_ACTGRAD) && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU);
+      if (ok && x_fmt && bwd && !d.bias && !(d.flags & FFVC_F_WRITE_PREACT) && d.y8_fmt == 1)
+        return go(I1{}, std::integral_constant<int, EPI_K_MULAUX | EPI_O_F8E5>{});
+      if (ok && !x_fmt && !bwd && d.bias && (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & FFVC_F_COLSUM) && d.y8_fmt == 0) {
+        const int r = d.act == FFVC_ACT_GELU ? go(I0{}, std::integral_constant<int, EPI_K_GELU_FWDG | EPI_O_F8E4>{})
+                                             : go(I0{}, std::integral_constant<int, EPI_K_QGELU_FWDG | EPI_O_F8E4>{});
+        return r == 0 ? 2 : r;
+      }
+      ffvc_set_error("ffvc_gemm_fp8: fp8 output (y8_state) is available with the activation forward that stores act'(pre) (e4m3) and "
+                     "the aux-multiply backward (e5m2) on the 256x256 tile with 8-aligned rows only");
+      return FFVC_E_BADARG;
+    }
     if (plain_store && !wants_act) {
       if (!d.residual && !(d.flags & FFVC_F_OUT_F32))
         return x_fmt ? go(I1{}, std::integral_constant<int, EPI_LEAN | EPI_O_T>{}) : go(I0{}, std::integral_constant<int, EPI_LEAN | EPI_O_T>{});
@@ -177,6 +194,10 @@ int launch_f8(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, c
         return r == 0 ? 2 : r;
       }
     }
+  }
+  if (d.y8_state) {
+    ffvc_set_error("ffvc_gemm_fp8: fp8 output (y8_state) needs the 256x256 tile");
+    return FFVC_E_BADARG;
   }
   return x_fmt ? go(I1{}, std::integral_constant<int, EPI_ALL>{}) : go(I0{}, std::integral_constant<int, EPI_ALL>{});
 }
@@ -319,6 +340,10 @@ extern "C" int ffvc_gemm_fp8(const ffvc_gemm_desc* dp, int x_fmt, int lo_dtype, 
     const double e256 = t256 >= 256 ? eff(t256, 512) * 1.07 : 0.0;
     const double e128 = eff(t128, 512);
     cfg = (e512 >= e256 && e512 >= e128) ? 512 : (e256 >= e128 ? 256 : 128);
+  }
+  if (d.y8_state) {
+    FFVC_CHECK_ARG(vec_ok == 2 && (d.y8_fmt == 0 || d.y8_fmt == 1), "ffvc_gemm_fp8: fp8 output needs 8-aligned rows and y8_fmt 0 | 1");
+    cfg = 512;                               // the specialised MLP kinds exist on the 256x256 tile
   }
   hipStream_t st = (hipStream_t)stream;
   if (d.flags & FFVC_F_AUX_ACTGRAD)

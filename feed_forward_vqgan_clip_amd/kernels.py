@@ -305,8 +305,11 @@ def fp8_next_scale(sc):
 
 
 def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0,
-             colsum=None):
-    """y[M,N] = act(sx.inv * sw.inv * X8 W8^T + bias) (+ residual): x8 [M,K], w8 [N,K] uint8 fp8 bytes (x in sx.fmt)."""
+             colsum=None, out_scale=None):
+    """y[M,N] = act(sx.inv * sw.inv * X8 W8^T + bias) (+ residual): x8 [M,K], w8 [N,K] uint8 fp8 bytes (x in sx.fmt).
+    out_scale (an initialised Fp8Scale): y is a uint8 tensor that receives the result as fp8 bytes in out_scale.fmt, scaled by its
+    current scale, and out_scale's running amax is updated — the operand of the next fp8 GEMM straight from the epilogue (the two
+    MLP kinds of the frozen towers only, see include/ffvc.h y8_state)."""
     _need_cuda(x8, w8, y, bias, residual, aux)
     if x8.dtype != torch.uint8 or w8.dtype != torch.uint8:
         raise TypeError("gemm_fp8: operands must be uint8 tensors of fp8 bytes")
@@ -315,7 +318,11 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
     d.bias, d.residual, d.aux = _ptr(bias), _ptr(residual), _ptr(aux)
     d.M, d.N, d.K = M, N, K
     d.x_mode, d.w_mode = OP_KMAJOR, OP_KMAJOR
-    if y.dtype == torch.float32:
+    if out_scale is not None:
+        if y.dtype != torch.uint8 or not out_scale.ready:
+            raise TypeError("gemm_fp8: fp8 output needs a uint8 y and an initialised Fp8Scale")
+        d.y8_state, d.y8_fmt = out_scale.state.data_ptr(), out_scale.fmt
+    elif y.dtype == torch.float32:
         flags |= F_OUT_F32
     elif y.dtype != lo_dtype:
         raise TypeError("gemm_fp8: y must be fp32 or lo_dtype")

@@ -147,6 +147,7 @@ def _grad_buf(p):
 # ffvc_slab_reduce.  Measured neutral on cfg2 (135.5 vs 135.6 ms: the reduce launches leave the side stream, the combine joins the
 # GEMM: TN class 13.5 -> 14.4 ms), so the slab form stays the default.
 _WGRAD_INKERNEL = os.environ.get("FFVC_WGRAD_INKERNEL", "0") != "0"
+_FP8_FUSE = os.environ.get("FFVC_FP8_FUSE", "1") != "0"                   # A/B: fp8 operands straight from the producing GEMM's epilogue
 _TM_WGRAD_INKERNEL = os.environ.get("FFVC_TOKMIX_WGRAD_INKERNEL", "0") != "0"   # A/B: one launch with the in-kernel split-K instead of slabs + reduce
 _SK_TARGET = int(os.environ.get("FFVC_SK_TARGET", "768"))  # A/B: workgroups a small-output weight gradient is split into
 _WGRAD_SK = int(os.environ.get("FFVC_WGRAD_SK", "0"))     # A/B: cap of the split-K factor of the 256x256-tile wgrads
@@ -299,11 +300,21 @@ class _MLPFn(Function):
         # evaluates anyway and the backward epilogue becomes a plain multiply (FFVC_F_AUX_ACTGRAD; the fp32 parity mode keeps
         # the textbook form)
         ctx.ag = K.F_AUX_ACTGRAD if (cdt in K.LOWP and _ACTGRAD and act in (ACT_GELU, ACT_QUICKGELU)) else 0
+        # frozen fp8 MLP: once the hidden activation's scale exists (second step on) the first GEMM's epilogue writes it as e4m3
+        # itself — no 16-bit h, no quantisation pass (csrc/gemm_common.h EPI_O_F8; FFVC_FP8_FUSE=0: separate passes)
+        h8 = None
+        fuse = (ctx.fp8 and _FP8_FUSE and ctx.ag and (w1 is None or not w1.requires_grad) and W1.bias is not None and
+                W2.fp8["x"].ready and W1.N % 8 == 0)
         if ctx.fp8:
             f1 = W1.fp8
             x8 = K.fp8_quant(x, f1["x"])
-            K.gemm_fp8(x8, f1["sh"], h, rows, W1.N, W1.K, f1["x"], f1["w"], lo_dtype=cdt, bias=W1.bias, act=act, aux=h_pre,
-                       ldaux=W1.N, flags=K.F_WRITE_PREACT | ctx.ag)
+            if fuse:
+                h8 = torch.empty(h_pre.shape, dtype=torch.uint8, device=x.device)
+                K.gemm_fp8(x8, f1["sh"], h8, rows, W1.N, W1.K, f1["x"], f1["w"], lo_dtype=cdt, bias=W1.bias, act=act, aux=h_pre,
+                           ldaux=W1.N, flags=K.F_WRITE_PREACT | ctx.ag, out_scale=W2.fp8["x"])
+            else:
+                K.gemm_fp8(x8, f1["sh"], h, rows, W1.N, W1.K, f1["x"], f1["w"], lo_dtype=cdt, bias=W1.bias, act=act, aux=h_pre,
+                           ldaux=W1.N, flags=K.F_WRITE_PREACT | ctx.ag)
             K.fp8_next_scale(f1["x"])
         else:
             K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
@@ -312,7 +323,8 @@ class _MLPFn(Function):
         ctx.drop = (float(drop),) + tuple(_drop_seeds(2)) if drop else None
         if ctx.fp8:
             f2 = W2.fp8
-            h8 = K.fp8_quant(h, f2["x"])
+            if h8 is None:
+                h8 = K.fp8_quant(h, f2["x"])
             K.gemm_fp8(h8, f2["sh"], y, rows, W2.N, W2.K, f2["x"], f2["w"], lo_dtype=cdt, bias=W2.bias, residual=residual)
             K.fp8_next_scale(f2["x"])
         elif ctx.drop:    # Linear, act, Dropout, Linear, Dropout (mlp_mixer_pytorch.py:16-23, vitgan.py:36-41), then + residual
@@ -344,12 +356,21 @@ class _MLPFn(Function):
         if ctx.fp8 and W2.fp8["sht"] is not None and W1.fp8["sht"] is not None:
             f1, f2 = W1.fp8, W2.fp8
             dy8 = K.fp8_quant(dyt, f2["g"])
-            K.gemm_fp8(dy8, f2["sht"], dh, rows, W2.K, W2.N, f2["g"], f2["w"], lo_dtype=cdt, aux=h_pre, ldaux=W2.K,
-                       act=ctx.act, flags=K.F_MUL_ACT_GRAD | ctx.ag)
+            # the hidden gradient leaves the aux-multiply epilogue as e5m2 once its scale exists (nothing else reads it: frozen layer)
+            fuse = _FP8_FUSE and ctx.ag and not ctx.train and ctx.needs_input_grad[0] and f1["g"].ready and W2.K % 8 == 0
+            dh8 = None
+            if fuse:
+                dh8 = torch.empty(h_pre.shape, dtype=torch.uint8, device=dy.device)
+                K.gemm_fp8(dy8, f2["sht"], dh8, rows, W2.K, W2.N, f2["g"], f2["w"], lo_dtype=cdt, aux=h_pre, ldaux=W2.K,
+                           act=ctx.act, flags=K.F_MUL_ACT_GRAD | ctx.ag, out_scale=f1["g"])
+            else:
+                K.gemm_fp8(dy8, f2["sht"], dh, rows, W2.K, W2.N, f2["g"], f2["w"], lo_dtype=cdt, aux=h_pre, ldaux=W2.K,
+                           act=ctx.act, flags=K.F_MUL_ACT_GRAD | ctx.ag)
             K.fp8_next_scale(f2["g"])
             dx = None
             if ctx.needs_input_grad[0]:
-                dh8 = K.fp8_quant(dh, f1["g"])
+                if dh8 is None:
+                    dh8 = K.fp8_quant(dh, f1["g"])
                 dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
                 K.gemm_fp8(dh8, f1["sht"], dx, rows, W1.K, W1.N, f1["g"], f1["w"], lo_dtype=cdt)
                 K.fp8_next_scale(f1["g"])

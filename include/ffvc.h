@@ -149,6 +149,13 @@ typedef struct ffvc_gemm_desc {
   /* RESERVED, leave 0: tail mode of the same machinery — work items >= sk_full are the tiles of the last, partly filled round of
    * a 256x256-tile launch, each cut into sk_slices K slices (260 tiles on 256 CUs would otherwise run two full rounds). */
   int32_t sk_full, sk_slices;
+  /* fp8 OUTPUT (ffvc_gemm_fp8 only; NULL = off): y receives fp8 bytes (y8_fmt 0 = e4m3 | 1 = e5m2) = saturate(value * y8_state[0])
+   * instead of 16-bit values, and y8_state[1] = max(y8_state[1], max |value|) (delayed per-tensor scaling, as ffvc_fp8_quant keeps
+   * it): the producer of the next fp8 GEMM's operand writes the operand itself.  Available with the two MLP kinds of the frozen
+   * towers — the activation forward that stores act'(pre) (e4m3 hidden activation) and the aux-multiply backward (e5m2 hidden
+   * gradient) — on the 256x256 tile; y rows are N bytes. */
+  float* y8_state;
+  int32_t y8_fmt;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);

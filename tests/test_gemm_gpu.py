@@ -581,3 +581,58 @@ def test_weight_gradient_split_k_combined_inside_the_launch(cuda, dt, M, N, Kred
         small = torch.zeros(128, 128, dtype=torch.float32, device=cuda)
         K.gemm_splitk_accumulate(dy[:512, :128].contiguous(), x[:512, :128].contiguous(), small, 128, 128, 512, 2, in_kernel=True, ldx=128,
                                  ldw=128, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
+
+
+@pytest.mark.parametrize("ldt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "quickgelu"])
+def test_fp8_gemm_writes_the_next_operand_itself(cuda, ldt, act):
+    """fp8 OUTPUT of the two frozen-MLP kinds (include/ffvc.h y8_state): the activation forward leaves the hidden activation as
+    e4m3 bytes (+ act'(pre) in aux), the aux-multiply backward leaves the hidden gradient as e5m2 bytes — each equal to what
+    the 16-bit output followed by ffvc_fp8_quant would hold up to the double rounding of that path (<= one fp8 step on a small
+    fraction of the elements), with the running amax updated the same way."""
+    code = K.ACT_GELU if act == "gelu" else K.ACT_QUICKGELU
+    M, N, Kd = 1024, 1024, 256
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(M, Kd, generator=g).to(ldt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.05).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    sx, sw = K.Fp8Scale(K.E4M3, x.device), K.Fp8Scale(K.E4M3, x.device)
+    x8, w8 = K.fp8_quant(x, sx), K.fp8_quant(w, sw, frozen=True)
+    flags = K.F_WRITE_PREACT | K.F_AUX_ACTGRAD
+    # reference path: 16-bit output, then the separate quantisation pass (which also initialises the output scale)
+    h, dact = torch.empty(M, N, dtype=ldt, device=x.device), torch.empty(M, N, dtype=ldt, device=x.device)
+    K.gemm_fp8(x8, w8, h, M, N, Kd, sx, sw, lo_dtype=ldt, bias=bias, act=code, aux=dact, ldaux=N, flags=flags)
+    so = K.Fp8Scale(K.E4M3, x.device)
+    h8_ref = K.fp8_quant(h, so)
+    amax_ref = so.state[1].item()
+    so.state[1] = 0.0
+    # fused path
+    h8, dact2 = torch.empty(M, N, dtype=torch.uint8, device=x.device), torch.empty(M, N, dtype=ldt, device=x.device)
+    K.gemm_fp8(x8, w8, h8, M, N, Kd, sx, sw, lo_dtype=ldt, bias=bias, act=code, aux=dact2, ldaux=N, flags=flags, out_scale=so)
+    # (the reference launch may have taken a kernel without the specialised epilogue: pre-activation stored in 16 bits, converted
+    #  to act' by a second pass — same quantity, one more rounding)
+    assert _rel(dact2, dact.double()) < (2e-3 if ldt == torch.float16 else 1.6e-2)
+    a, b = _f8_ref(h8, K.E4M3), _f8_ref(h8_ref, K.E4M3)
+    differ = (a != b).float().mean().item()
+    assert differ < 0.05 and (a - b).abs().max().item() <= 0.13 * b.abs().max().item()      # one e4m3 step at the top binade = 1/8
+    assert abs(so.state[1].item() - amax_ref) <= 2e-2 * amax_ref
+    # backward kind: dy (e5m2) x W^T * act'(pre) -> e5m2
+    dy = (torch.randn(M, Kd, generator=g) * 1e-3).to(ldt).cuda()
+    sg = K.Fp8Scale(K.E5M2, x.device)
+    dy8 = K.fp8_quant(dy, sg)
+    dh = torch.empty(M, N, dtype=ldt, device=x.device)
+    K.gemm_fp8(dy8, w8, dh, M, N, Kd, sg, sw, lo_dtype=ldt, act=code, aux=dact, ldaux=N, flags=K.F_MUL_ACT_GRAD | K.F_AUX_ACTGRAD)
+    sd = K.Fp8Scale(K.E5M2, x.device)
+    dh8_ref = K.fp8_quant(dh, sd)
+    amax_ref = sd.state[1].item()
+    sd.state[1] = 0.0
+    dh8 = torch.empty(M, N, dtype=torch.uint8, device=x.device)
+    K.gemm_fp8(dy8, w8, dh8, M, N, Kd, sg, sw, lo_dtype=ldt, act=code, aux=dact, ldaux=N, flags=K.F_MUL_ACT_GRAD | K.F_AUX_ACTGRAD,
+               out_scale=sd)
+    a, b = _f8_ref(dh8, K.E5M2), _f8_ref(dh8_ref, K.E5M2)
+    assert (a != b).float().mean().item() < 0.05 and (a - b).abs().max().item() <= 0.26 * b.abs().max().item()
+    assert abs(sd.state[1].item() - amax_ref) <= 2e-2 * amax_ref
+    # anything but those two kinds refuses an fp8 output
+    from feed_forward_vqgan_clip_amd._lib import FFVCError
+    with pytest.raises(FFVCError, match="fp8 output"):
+        K.gemm_fp8(x8, w8, h8, M, N, Kd, sx, sw, lo_dtype=ldt, out_scale=so)
