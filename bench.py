@@ -101,7 +101,7 @@ def effective_cores():
 
 def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     """The oracle (CPU restatement, fp32) timed on this box's host cores on a bounded sample of the same
-    workload: full train steps (fwd + loss + bwd + Adam) at batch 1 of the cfg2 models."""
+    workload: full train steps (fwd + loss + bwd + Adam) at batch 4 of the cfg2 models."""
     from feed_forward_vqgan_clip_amd import main as fmain
     from feed_forward_vqgan_clip_amd import vqgan as fvq
     from oracle import mappers as omap
@@ -110,7 +110,7 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     mixer_sd, vq_sd, clip_sd = sds
     cores = effective_cores()
     torch.set_num_threads(cores)
-    B = 1
+    B = 4
     tok = fmain.synthetic_tokens(B, seed=99)
     params = {k: v.clone().requires_grad_(True) for k, v in mixer_sd.items()}
     plist = list(params.values())
@@ -478,7 +478,7 @@ def main():
         torch.cuda.empty_cache()
         out["cpu_baseline"], ref = cpu_baseline(sds, args.cutn, augs=args.augs)
         out["parity_full_size"] = full_size_parity(args, sds, ref)
-        out["parity_full_size"]["loss_oracle_fp32_batch1"] = ref["loss"]
+        out["parity_full_size"]["loss_oracle_fp32_cpu_baseline_step"] = ref["loss"]      # first (batch-4) step of the CPU baseline
     if rank == 0:
         # libraries that write to C stdio (RCCL's NCCL_DEBUG=VERSION banner) flush at exit, i.e. AFTER Python's own buffer:
         # push their text out first so that the JSON line is the last line of stdout
