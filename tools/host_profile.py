@@ -13,7 +13,8 @@ from feed_forward_vqgan_clip_amd import main as fmain  # noqa: E402
 
 class A:
     dtype, dim, depth, cutn, batch, model_type, vq_image_size, augs, grad_wire, keep_cpu_weights = \
-        "bf16", 1024, 32, 8, 64, "mlp_mixer", 16, "default", "fp32", False
+        "f16", 1024, 32, 8, 64, "mlp_mixer", 16, "default", "fp32", False
+    clip_model, clip_fp8, loss_scale, prefetch_text = "ViT-B/32", False, 4096.0, True
 
 
 dev = torch.device("cuda:0")
