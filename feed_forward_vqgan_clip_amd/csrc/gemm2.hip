@@ -568,12 +568,6 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       if (d.N > 128 && (t512 >= 70 || (t512 >= 24 && longk))) cfg = 512;
       else if (t256 >= 192) cfg = 256;
       else cfg = 128;
-      // the activation forward that also stores act'(pre) writes two full-size tensors: with two 256x128 workgroups per CU one's stores
-      // overlap the other's K loop (16384x4096x1024: 176 vs 206 us; the aux-multiply backward prefers the 256x256 tile: 172 vs 183)
-      const bool fwd_kind = (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU) && (d.flags & FFVC_F_AUX_ACTGRAD) &&
-                            (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_COLSUM | FFVC_F_OUT_F32)) && d.bias &&
-                            !(d.flags & FFVC_F_BIAS_ALONG_M) && !d.residual && d.batch == 1;
-      if (cfg == 512 && fwd_kind && t512 >= 512 && (d.N % 128) == 0) cfg = 256;
     }
     // short reductions are epilogue-dominated: keep two (smaller) workgroups per CU so one's epilogue overlaps the
     // other's K loop (threshold via FFVC_SHORTK for A/B runs)

@@ -1579,7 +1579,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
           }
         }
         if (lean_opt && !wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
-        if constexpr (WMODE == FFVC_OP_KMAJOR && BM == 256 && (BN == 256 || BN == 128)) {
+        if constexpr (WMODE == FFVC_OP_KMAJOR && BM == 256 && BN == 256) {
           // the MLP launches of the Mixer / ViT blocks: one activation, fixed at compile time
           // the kinds fix the rest of the epilogue too: 16-bit plain output, no residual, column bias (forward) / none (backward)
           const bool plain_out = !d.residual && !(d.flags & (FFVC_F_OUT_F32 | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT)) &&
