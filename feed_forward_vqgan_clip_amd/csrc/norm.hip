@@ -767,19 +767,25 @@ extern "C" int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma
   return 0;
 }
 
-static int ln_rows_per_block() {
+// Rows per workgroup (4 waves, one row per wave and trip) of the LayerNorm / SLN backward kernels.  32 suits the 16384-row
+// streams of the Mixer; with a few hundred rows (VitGAN at 32 samples per GPU: 512) that leaves 16 workgroups on 256 CUs walking
+// 8 rows per wave one after the other (55 us for a 2 MB tensor), so small problems get as few rows per workgroup as it takes to
+// put ~256 of them on the chip (never fewer than 4: one per wave).  FFVC_LN_RPB overrides the 32.
+static int ln_rows_per_block(int64_t rows) {
   static int rpb = -1;
   if (rpb < 0) {
     const char* e = getenv("FFVC_LN_RPB");
     rpb = e ? atoi(e) : 32;
     if (rpb < 4) rpb = 4;
   }
-  return rpb;
+  int r = rpb;
+  while (r > 4 && (rows + r - 1) / r < 256) r >>= 1;
+  return r < 4 ? 4 : r;
 }
 
 extern "C" int ffvc_layernorm_bwd_blocks(int64_t rows) {
   // number of partial rows ffvc_layernorm_bwd writes into part_g / part_b
-  const int rpb = ln_rows_per_block();
+  const int rpb = ln_rows_per_block(rows);
   int64_t nb = (rows + rpb - 1) / rpb;
   return (int)(nb < 1 ? 1 : nb);
 }
@@ -857,7 +863,7 @@ static int ln_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtyp
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd: dim=%d unsupported", dim);
   FFVC_CHECK_ARG((part_g == nullptr) == (part_b == nullptr), "ffvc_layernorm_bwd: need both partial buffers or none");
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = ln_rows_per_block();
+  const int rpb = ln_rows_per_block(rows);
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   static int plain_opt = -1;
   if (plain_opt < 0) {
@@ -1053,7 +1059,7 @@ static int sln_bwd_launch(const void* dy, int dy_dtype, const float* hl, const f
                      part_s, "ffvc_sln_bwd: null pointer");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_sln_bwd: dim=%d unsupported", dim);
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = ln_rows_per_block();
+  const int rpb = ln_rows_per_block(rows);
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = (2 * (size_t)dim + 2) * sizeof(float);
   DISPATCH_DT(dy_dtype, DYT, {
