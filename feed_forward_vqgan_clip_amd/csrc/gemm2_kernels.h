@@ -1444,7 +1444,10 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
   constexpr bool ring = !(BM == 256 && BN == 128);
   if constexpr (ring) {
     const bool interior = (d.M % BM) == 0 && (d.N % BN) == 0 && vec_ok == 2 && !(d.flags & (FFVC_F_OUT_F32 | FFVC_F_ACCUM_OUT | FFVC_F_ATOMIC_OUT));
-    if (persist == 1 || (persist == 2 && d.K <= 512 && interior && (int64_t)n_tiles * d.batch * split > n_cu)) {
+    // gemm2p_kernel has no in-kernel split-K combine: a launch whose K slices meet through sk_ws (or that would store unsynchronised
+    // partial tiles) stays on gemm2_kernel
+    const bool p_split_ok = d.sk_ws == nullptr && !(split > 1 && d.slab_stride == 0 && !(d.flags & FFVC_F_ATOMIC_OUT));
+    if (p_split_ok && (persist == 1 || (persist == 2 && d.K <= 512 && interior && (int64_t)n_tiles * d.batch * split > n_cu))) {
       const int64_t total = (int64_t)n_tiles * d.batch * split;
       const int slots = n_cu * ((BM == 256) ? 1 : 2);
       int pgrid = total < slots ? (int)total : slots;
@@ -1479,7 +1482,9 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
       use8 = e ? atoi(e) : 0;
     }
     const bool pays = XMODE == FFVC_OP_KMAJOR && d.K >= 2048;
-    if ((use8 == 2 || (use8 == 1 && pays) || g_force_gemm8) && d.kseg == 0 && d.x_mi == 0 && g8_offsets_ok<XMODE>(d)) {
+    // gemm8_kernel has no ticket / combine either: the auto split-K above (24..100 tiles, K >= 2048) must not reach it
+    const bool g8_split_ok = d.sk_ws == nullptr && !(split > 1 && d.slab_stride == 0 && !(d.flags & FFVC_F_ATOMIC_OUT));
+    if (g8_split_ok && (use8 == 2 || (use8 == 1 && pays) || g_force_gemm8) && d.kseg == 0 && d.x_mi == 0 && g8_offsets_ok<XMODE>(d)) {
       static bool attr8 = false;
       if (!attr8) {
         (void)hipFuncSetAttribute((const void*)gemm8_kernel<L, XMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

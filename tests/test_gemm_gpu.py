@@ -380,6 +380,30 @@ def test_forced_tiles_nt_and_conv(cuda, tile, dt):
         K.set_option("conv_row", 1)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_forced_gemm8_with_auto_split_k_shape(cuda, dt):
+    """A 256x256-tile launch with 24..100 tiles and K >= 2048 gets its K split inside the launch (ticket + combine, gemm2_kernel
+    only).  With the 8-phase kernel forced the same launch must not end up on a kernel without the combine (every K slice would
+    store its partial tile straight into y): 6400x768x3072 = 75 tiles, split 2."""
+    M, N, K_ = 6400, 768, 3072
+    x, w = _mk((M, K_), dt, cuda, 21, 0.3), _mk((N, K_), dt, cuda, 22, 0.3)
+    b = _mk((N,), torch.float32, cuda, 23)
+    ref = x.double() @ w.double().T + b.double()
+    K.set_option("gemm2_tile", 512)
+    K.set_option("gemm8", 1)
+    try:
+        outs = []
+        for _ in range(2):
+            y = torch.empty(M, N, dtype=torch.float32, device=cuda)
+            K.gemm(x, w, y, M, N, K_, ldx=K_, ldw=K_, bias=b)
+            outs.append(y)
+    finally:
+        K.set_option("gemm2_tile", 1)
+        K.set_option("gemm8", 0)
+    assert _rel(outs[0], ref) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
 # ----------------------------------------------------------------------------- fp8 path (cfg5)
 def _f8_ref(t8, fmt):
     """uint8 fp8 bytes -> fp32 values through torch's own OCP float8 dtypes (the independent decoder)."""
