@@ -125,3 +125,121 @@ def test_oracle_vqgan_decoder_matches_the_taming_derived_decoder_in_transformers
         got = ovq.decoder_forward(sd, z, cfg)
     assert got.shape == want.shape == (2, 3, 32, 32)
     assert ((got - want).norm() / want.norm()).item() < 1e-5
+
+
+# ----------------------------------------------------------------------------- x-transformer mapper (transformer.py:5-46)
+def _xt_state_dict(input_dim, image_size, channels, dim, depth, heads, initial_proj, extra_pos=0, seed=0):
+    """Random weights in the key layout of ContinuousTransformerWrapper(Decoder) 0.19.1 as oracle/mappers.py reads it."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.08     # noqa: E731
+    n, inner, t = image_size * image_size + extra_pos, heads * 64, "transformer"
+    sd = {}
+    if initial_proj:
+        sd["proj.weight"], sd["proj.bias"] = r(image_size * image_size * dim, input_dim), r(image_size * image_size * dim)
+    din = dim if initial_proj else input_dim
+    sd[t + ".project_in.weight"], sd[t + ".project_in.bias"] = r(dim, din), r(dim)
+    sd[t + ".pos_emb.emb.weight"] = r(n, dim)
+    for j in range(depth):
+        a, f = f"{t}.attn_layers.layers.{2 * j}", f"{t}.attn_layers.layers.{2 * j + 1}"
+        for p in (a, f):
+            sd[p + ".0.weight"], sd[p + ".0.bias"] = 1.0 + r(dim), r(dim)
+        for q in ("to_q", "to_k", "to_v"):
+            sd[f"{a}.1.{q}.weight"] = r(inner, dim)
+        sd[a + ".1.to_out.weight"], sd[a + ".1.to_out.bias"] = r(dim, inner), r(dim)
+        sd[f + ".1.net.0.0.weight"], sd[f + ".1.net.0.0.bias"] = r(4 * dim, dim), r(4 * dim)
+        sd[f + ".1.net.2.weight"], sd[f + ".1.net.2.bias"] = r(dim, 4 * dim), r(dim)
+    sd[t + ".norm.weight"], sd[t + ".norm.bias"] = 1.0 + r(dim), r(dim)
+    sd[t + ".project_out.weight"], sd[t + ".project_out.bias"] = r(channels, dim), r(channels)
+    return sd
+
+
+def test_oracle_xtransformer_matches_hf_gpt2_blocks():
+    """Witness for oracle/mappers.py::xtransformer_forward (x-transformers 0.19.1 is absent): the Decoder of that release is a stack of
+    pre-norm causal self-attention + GELU feed-forward blocks with a final LayerNorm — the GPT-2 block.  HuggingFace's GPT2Model
+    (an independently written implementation: fused c_attn Conv1D, its own causal masking / softmax path, erf-GELU via
+    `activation_function="gelu"`) is loaded with the same weights (q/k/v bias-free -> zero c_attn bias; learned positions scaled by
+    dim^-0.5 as AbsolutePositionalEmbedding does) at dim = heads * 64, where the two architectures coincide, and fed the oracle's
+    own `project_in` output through `inputs_embeds`.  Everything between project_in and project_out is then GPT-2's code."""
+    from transformers import GPT2Config, GPT2Model
+    from oracle import mappers as omap
+    S, C, dim, depth, heads, idim = 4, 16, 128, 3, 2, 40
+    n = S * S
+    sd = _xt_state_dict(idim, S, C, dim, depth, heads, initial_proj=True, seed=3)
+    cfg = GPT2Config(vocab_size=8, n_positions=n, n_embd=dim, n_layer=depth, n_head=heads, n_inner=4 * dim, activation_function="gelu",
+                     resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0, layer_norm_epsilon=1e-5, scale_attn_weights=True,
+                     scale_attn_by_inverse_layer_idx=False, reorder_and_upcast_attn=False)
+    gpt = GPT2Model(cfg).eval()
+    t = "transformer"
+    with torch.no_grad():
+        gpt.wpe.weight.copy_(sd[t + ".pos_emb.emb.weight"] * dim ** -0.5)
+        for j, blk in enumerate(gpt.h):
+            a, f = f"{t}.attn_layers.layers.{2 * j}", f"{t}.attn_layers.layers.{2 * j + 1}"
+            blk.ln_1.weight.copy_(sd[a + ".0.weight"]); blk.ln_1.bias.copy_(sd[a + ".0.bias"])
+            blk.ln_2.weight.copy_(sd[f + ".0.weight"]); blk.ln_2.bias.copy_(sd[f + ".0.bias"])
+            blk.attn.c_attn.weight.copy_(torch.cat([sd[f"{a}.1.to_{x}.weight"].t() for x in "qkv"], dim=1))   # Conv1D: [in, out]
+            blk.attn.c_attn.bias.zero_()
+            blk.attn.c_proj.weight.copy_(sd[a + ".1.to_out.weight"].t()); blk.attn.c_proj.bias.copy_(sd[a + ".1.to_out.bias"])
+            blk.mlp.c_fc.weight.copy_(sd[f + ".1.net.0.0.weight"].t()); blk.mlp.c_fc.bias.copy_(sd[f + ".1.net.0.0.bias"])
+            blk.mlp.c_proj.weight.copy_(sd[f + ".1.net.2.weight"].t()); blk.mlp.c_proj.bias.copy_(sd[f + ".1.net.2.bias"])
+        gpt.ln_f.weight.copy_(sd[t + ".norm.weight"]); gpt.ln_f.bias.copy_(sd[t + ".norm.bias"])
+    x = torch.randn(3, idim, generator=torch.Generator().manual_seed(4))
+    F = torch.nn.functional
+    with torch.no_grad():
+        got = omap.xtransformer_forward(sd, x, image_size=S, channels=C, dim=dim, depth=depth, heads=heads)
+        h = F.linear(x, sd["proj.weight"], sd["proj.bias"]).view(3, n, dim)
+        h = F.linear(h, sd[t + ".project_in.weight"], sd[t + ".project_in.bias"])
+        hid = gpt(inputs_embeds=h).last_hidden_state
+        want = F.linear(hid, sd[t + ".project_out.weight"], sd[t + ".project_out.bias"]).view(3, S, S, C).permute(0, 3, 1, 2)
+    assert got.shape == want.shape == (3, C, S, S)
+    assert ((got - want).norm() / want.norm()).item() < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["initial_proj", "add_input", "prefix_token"])
+def test_oracle_xtransformer_matches_a_module_built_restatement(mode):
+    """Second, differently built restatement for the case GPT-2 cannot express (inner width heads*64 != dim: cfg4 runs dim 256 with
+    6 heads) and for the three input modes of transformer.py:29-43: torch.nn modules (nn.LayerNorm / nn.Linear / nn.GELU) and
+    torch's fused `scaled_dot_product_attention(is_causal=True)` instead of the oracle's explicit einsum / masked_fill / softmax."""
+    from torch import nn
+    from oracle import mappers as omap
+    S, C, dim, depth, heads, idim = 3, 8, 48, 2, 3, 20
+    initial_proj, add_input = mode == "initial_proj", mode != "prefix_token"
+    n = S * S
+    L = n + (0 if (initial_proj or add_input) else 1)
+    sd = _xt_state_dict(idim, S, C, dim, depth, heads, initial_proj, extra_pos=L - n, seed=5)
+    t = "transformer"
+
+    def lin(prefix, bias=True):
+        w = sd[prefix + ".weight"]
+        m = nn.Linear(w.shape[1], w.shape[0], bias=bias)
+        m.weight.data.copy_(w)
+        if bias:
+            m.bias.data.copy_(sd[prefix + ".bias"])
+        return m
+
+    def ln(prefix):
+        m = nn.LayerNorm(dim)
+        m.weight.data.copy_(sd[prefix + ".weight"]); m.bias.data.copy_(sd[prefix + ".bias"])
+        return m
+
+    x = torch.randn(2, idim, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        got = omap.xtransformer_forward(sd, x, image_size=S, channels=C, dim=dim, depth=depth, heads=heads, initial_proj=initial_proj,
+                                        add_input=add_input)
+        if initial_proj:
+            h = lin("proj")(x).view(2, n, dim)
+        elif add_input:
+            h = x[:, None, :].expand(2, n, idim)
+        else:
+            h = torch.cat([x[:, None, :], x.new_zeros(2, n, idim)], dim=1)
+        h = lin(t + ".project_in")(h) + sd[t + ".pos_emb.emb.weight"][:L] / dim ** 0.5
+        for j in range(depth):
+            a, f = f"{t}.attn_layers.layers.{2 * j}", f"{t}.attn_layers.layers.{2 * j + 1}"
+            y = ln(a + ".0")(h)
+            q, k, v = (lin(f"{a}.1.to_{c}", bias=False)(y).view(2, L, heads, 64).permute(0, 2, 1, 3) for c in "qkv")
+            o = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True)       # default scale = 64^-0.5
+            h = h + lin(a + ".1.to_out")(o.permute(0, 2, 1, 3).reshape(2, L, heads * 64))
+            h = h + nn.Sequential(ln(f + ".0"), lin(f + ".1.net.0.0"), nn.GELU(), lin(f + ".1.net.2"))(h)
+        out = lin(t + ".project_out")(ln(t + ".norm")(h))
+        want = out[:, L - n:].reshape(2, S, S, C).permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    assert ((got - want).norm() / want.norm()).item() < 2e-5
