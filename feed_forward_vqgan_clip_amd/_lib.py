@@ -157,11 +157,17 @@ _SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "ffvc_cutouts_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                  c_float, c_float, c_void_p]),
-    "ffvc_augment_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
+    "ffvc_augment_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
     "ffvc_avgpool_patches_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
     "ffvc_avgpool_patches_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int] + [c_float] * 3 + [c_void_p]),
-    "ffvc_augment_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+    "ffvc_augment_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                  c_float, c_void_p]),
+    "ffvc_sharpness_fwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "ffvc_sharpness_bwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "ffvc_warp_grid_fwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "ffvc_warp_grid_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "ffvc_tps_grid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ffvc_elastic_grid": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "ffvc_spherical_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                     c_void_p]),
     "ffvc_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float,

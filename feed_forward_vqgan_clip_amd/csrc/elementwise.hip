@@ -4,6 +4,7 @@
 // fused Adam.  All arithmetic fp32; coalesced 8/16-byte accesses; grid-stride loops capped at
 // ~8 workgroups per CU.
 #include "common.h"
+#include "augment_cj.h"
 
 namespace {
 
@@ -724,7 +725,14 @@ __device__ __forceinline__ AugSample aug_coords(const float* __restrict__ pinv, 
   const float x1 = (pinv[0] * x2 + pinv[1] * y2 + pinv[2]) * iw;
   const float y1 = (pinv[3] * x2 + pinv[4] * y2 + pinv[5]) * iw;
   AugSample a;
-  a.m = (x1 >= -0.5f && x1 <= (float)S - 0.5f && y1 >= -0.5f && y1 <= (float)S - 0.5f) ? 1.0f : 0.0f;   // zeros padding
+  // zeros padding of the homography slot as grid_sample(padding_mode='zeros', align_corners=False) applies it (kornia's
+  // RandomPerspective / RandomRotation): each bilinear tap outside the frame counts as zero, i.e. the image fades out linearly
+  // over the pixel around its border: weight (t + 1) on [-1, 0], (S - t) on [S - 1, S], per axis
+  const float rx = fminf(fmaxf(x1 + 1.0f, 0.0f), 1.0f) * fminf(fmaxf((float)S - x1, 0.0f), 1.0f);
+  const float ry = fminf(fmaxf(y1 + 1.0f, 0.0f), 1.0f) * fminf(fmaxf((float)S - y1, 0.0f), 1.0f);
+  // a homography slot that only scales / shifts (resize, crop, identity) has no zero-padded warp in it: coordinates are clamped
+  const bool zero_pad = pinv[1] != 0.0f || pinv[3] != 0.0f || pinv[6] != 0.0f || pinv[7] != 0.0f;
+  a.m = zero_pad ? rx * ry : 1.0f;
   float x0 = ainv[0] * x1 + ainv[1] * y1 + ainv[2];
   float y0 = ainv[3] * x1 + ainv[4] * y1 + ainv[5];
   x0 = fminf(fmaxf(x0, 0.0f), (float)(S - 1));                                                            // border padding
@@ -741,8 +749,9 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                           const int* __restrict__ erase, const float* __restrict__ noise,
                                                           const float* __restrict__ facs, const float* __restrict__ coff,
-                                                          OT* __restrict__ out, int B, int S, int Ss, int cutn, int P,
-                                                          float m0, float m1, float m2, float s0, float s1, float s2) {
+                                                          const float* __restrict__ cj, OT* __restrict__ out, int B, int S,
+                                                          int Ss, int cutn, int P, float m0, float m1, float m2, float s0,
+                                                          float s1, float s2) {
   const int gw = S / P;
   const int64_t n_px = (int64_t)cutn * B * S * S;
   const int64_t per_img = (int64_t)3 * S * S;
@@ -765,9 +774,19 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
     }
     const float* cm = cmat + n * 9;
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+    float col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) col[c] = cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
+    if (cj && cj[n * 8] != 0.0f && !erased) {      // kornia ColorJitter (hsv round trips, clamps, random order): augment_cj.h
+      float J[3][3], o[3];
+      ffvc_cj::color_jitter(cj + n * 8, col, o, J);
+      col[0] = o[0];
+      col[1] = o[1];
+      col[2] = o[2];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float v = erased ? 0.0f : cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
+      float v = erased ? 0.0f : col[c];
       if (noise) v += facs[n] * noise[(int64_t)n * per_img + ((int64_t)c * S + oy) * S + ox];
       const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)c * P * P + ky * P + kx;
       ElemTraits<OT>::store(out + (int64_t)n * per_img + prow, (v - mean[c]) * istd[c]);
@@ -779,7 +798,9 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
 template <typename GT>
 __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__ gout, const float* __restrict__ pinv,
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
-                                                          const int* __restrict__ erase, float* __restrict__ dpooled, int B,
+                                                          const int* __restrict__ erase, const float* __restrict__ pooled,
+                                                          const float* __restrict__ coff, const float* __restrict__ cj,
+                                                          float* __restrict__ dpooled, int B,
                                                           int S, int Ss, int cutn, int P, float s0, float s1, float s2) {
   const int gw = S / P;
   const int64_t n_px = (int64_t)cutn * B * S * S;
@@ -803,7 +824,24 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
       g[c] = ElemTraits<GT>::load(gout + (int64_t)n * per_img + prow) * istd[c];
     }
     const float* cm = cmat + n * 9;
-    const float w00 = (1.f - a.wy) * (1.f - a.wx), w01 = (1.f - a.wy) * a.wx, w10 = a.wy * (1.f - a.wx), w11 = a.wy * a.wx;
+    const float w00 = a.m * (1.f - a.wy) * (1.f - a.wx), w01 = a.m * (1.f - a.wy) * a.wx, w10 = a.m * a.wy * (1.f - a.wx),
+                w11 = a.m * a.wy * a.wx;
+    if (cj && cj[n * 8] != 0.0f) {
+      // the jitter is not linear: recompute this pixel's forward value up to the jitter's input, then g <- J^T g
+      float rgb[3], col[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* src = pooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
+        rgb[c] = w00 * src[0] + w01 * src[1] + w10 * src[Ss] + w11 * src[Ss + 1];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] = cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
+      float J[3][3], o[3];
+      ffvc_cj::color_jitter(cj + n * 8, col, o, J);
+      const float g0 = g[0], g1 = g[1], g2 = g[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = J[0][c] * g0 + J[1][c] * g1 + J[2][c] * g2;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float gc = cm[c] * g[0] + cm[3 + c] * g[1] + cm[6 + c] * g[2];          // transpose of the colour matrix
@@ -1279,7 +1317,7 @@ extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nsl
 }
 
 extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
-                                const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
+                                const float* cj, const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
                                 int S, int S_src, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
                                 float std_g, float std_b, void* stream) {
   FFVC_CHECK_ARG(pooled && pinv && ainv && cmat && erase && out, "ffvc_augment_fwd: null pointer");
@@ -1288,16 +1326,18 @@ extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const fl
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)cutn * B * S * S;
   DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
-                                                pinv, ainv, cmat, erase, noise, facs, coff, (OT*)out, B, S, S_src, cutn, patch, mean_r,
+                                                pinv, ainv, cmat, erase, noise, facs, coff, cj, (OT*)out, B, S, S_src, cutn, patch, mean_r,
                                                 mean_g, mean_b, std_r, std_g, std_b));
   FFVC_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
-                                const int32_t* erase, float* dpooled, int B, int S, int S_src, int cutn, int patch,
-                                float std_r, float std_g, float std_b, void* stream) {
+                                const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled,
+                                int B, int S, int S_src, int cutn, int patch, float std_r, float std_g, float std_b,
+                                void* stream) {
   FFVC_CHECK_ARG(gout && pinv && ainv && cmat && erase && dpooled, "ffvc_augment_bwd: null pointer");
+  FFVC_CHECK_ARG(cj == nullptr || pooled != nullptr, "ffvc_augment_bwd: the colour jitter's backward needs the forward's source image");
   FFVC_CHECK_ARG(B > 0 && S > 1 && S_src > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_bwd: bad geometry");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(dpooled, 0, (size_t)B * 3 * S_src * S_src * sizeof(float), st);
@@ -1307,7 +1347,7 @@ extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv
   }
   const int64_t n = (int64_t)cutn * B * S * S;
   DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
-                                              (const GT*)gout, pinv, ainv, cmat, erase, dpooled, B, S, S_src, cutn, patch, std_r,
+                                              (const GT*)gout, pinv, ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, cutn, patch, std_r,
                                               std_g, std_b));
   FFVC_LAUNCH_CHECK();
   return 0;

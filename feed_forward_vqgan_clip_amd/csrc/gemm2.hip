@@ -47,7 +47,11 @@ __device__ unsigned long long cr_stamps[4][6][8];     // [wave][step - 3][event]
 #else
 #define CR_STAMP(ev)
 #endif
-template <typename L, bool BUF, int EPI = ffvc_gemm_detail::EPI_GN>
+// WPF (round 4): the filter tile is double-buffered (the second stage takes the place of the row-store pads, which alias the X
+// tile during the epilogue: same 65 KiB, still two workgroups per CU).  The W tile of step s+1 is issued right after the barrier
+// that opens step s, so the kw = 1, 2 steps find their operands already in LDS (one barrier per step instead of two); only the
+// X reload of a kw = 0 step (every third) still waits on the memory side, covered by the partner workgroup as before.
+template <typename L, bool BUF, int EPI = ffvc_gemm_detail::EPI_GN, bool WPF = false>
 __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
                                                           const uint16_t* zero) {
   constexpr int MT = 4, BM = 256, BN = 128;
@@ -105,18 +109,37 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
   const int nblk = Cin / 64;
   int cr_step = 0;
   (void)cr_step;
+  if constexpr (WPF) {
+    sx.issue(sX, 0, 0, zero, tid);
+    sw.issue(sW, 0, p.K, zero, tid);
+  }
   for (int kh = 0; kh < 3; ++kh) {
     for (int cb = 0; cb < nblk; ++cb) {
 #pragma unroll 1
       for (int kw = 0; kw < 3; ++kw, ++cr_step) {
         CR_STAMP(0);
-        if (kw == 0) sx.issue(sX, kh, cb * 64, zero, tid);
-        sw.issue(sW, (kh * 3 + kw) * Cin + cb * 64, p.K, zero, tid);
+        if constexpr (!WPF) {
+          if (kw == 0) sx.issue(sX, kh, cb * 64, zero, tid);
+          sw.issue(sW, (kh * 3 + kw) * Cin + cb * 64, p.K, zero, tid);
+        }
         CR_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CR_STAMP(2);
         __syncthreads();
         CR_STAMP(3);
+        if constexpr (WPF) {
+          // everyone has finished step s-1 (the last reader of the other W stage): stage the next step's filter tile now
+          sW = smem + XTILE + (cr_step & 1) * WTILE;
+          int kw2 = kw + 1, cb2 = cb, kh2 = kh;
+          if (kw2 == 3) {
+            kw2 = 0;
+            if (++cb2 == nblk) {
+              cb2 = 0;
+              ++kh2;
+            }
+          }
+          if (kh2 < 3) sw.issue(smem + XTILE + ((cr_step + 1) & 1) * WTILE, (kh2 * 3 + kw2) * Cin + cb2 * 64, p.K, zero, tid);
+        }
         if constexpr (M16) {
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub) {
@@ -154,10 +177,37 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
               for (int b = 0; b < MT; ++b) mma_lo<L>(acc[a][b], fa[a], fb[b]);
           }
         }
-        __syncthreads();
+        if constexpr (WPF) {
+          if (kw == 2) {                      // the X tile is single-buffered: reload it once every wave is done with it
+            __syncthreads();
+            int cb2 = cb + 1, kh2 = kh;
+            if (cb2 == nblk) {
+              cb2 = 0;
+              ++kh2;
+            }
+            if (kh2 < 3) sx.issue(sX, kh2, cb2 * 64, zero, tid);
+          }
+        } else {
+          __syncthreads();
+        }
         CR_STAMP(6);
       }
     }
+  }
+  if constexpr (WPF) {
+    // the row-store pads alias the X tile (all X / W reads retired behind the barrier that closed the last step)
+    if constexpr (M16) {
+      if (vec_ok == 2)
+        ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
+      else
+        ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc16, m0, n0, wm, wn, lane, 0, 0, 1);
+    } else {
+      if (vec_ok == 2)
+        ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
+      else
+        ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
+    }
+    return;
   }
   if constexpr (M16) {
     if (vec_ok == 2)
@@ -610,6 +660,15 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
         (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, true, EL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr2 = true;
       }
+      static int wpf = -1;
+      if (wpf < 0) {
+        const char* e = getenv("FFVC_CR_WPF");
+        wpf = e ? atoi(e) : 0;
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t, true, EL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, true, EL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<uint16_t, true, EG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_row_kernel<f16_t, true, EG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      }
       static int row2 = -1;
       if (row2 < 0) {
         const char* e = getenv("FFVC_CONV_ROW2");
@@ -629,6 +688,14 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
         } else {
           if (!gnv) hipLaunchKernelGGL((conv_row2_kernel<uint16_t, EL>), dim3(n_tiles), dim3(256), lds2, st, d, tiles_n, n_tiles, vec_ok);
           else hipLaunchKernelGGL((conv_row2_kernel<uint16_t, EG>), dim3(n_tiles), dim3(256), lds2, st, d, tiles_n, n_tiles, vec_ok);
+        }
+      } else if (wpf && buf) {     // double-buffered filter tile (FFVC_CR_WPF)
+        if (d.in_dtype == FFVC_F16) {
+          if (!gnv) hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EL, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+          else hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EG, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+        } else {
+          if (!gnv) hipLaunchKernelGGL((conv_row_kernel<uint16_t, true, EL, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
+          else hipLaunchKernelGGL((conv_row_kernel<uint16_t, true, EG, true>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);
         }
       } else if (d.in_dtype == FFVC_F16) {
         if (buf && !gnv) hipLaunchKernelGGL((conv_row_kernel<f16_t, true, EL>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, zero);

@@ -12,6 +12,7 @@
 #include "common.h"
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace {
@@ -678,6 +679,177 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// Backward in ONE pass over HBM (round 4): 2 reads (dy, x) + 1 write (dx) (+ dres) instead of the 4 + 1 of the two kernels above.
+// A group of `wg_per_img` workgroups owns one image at a time; every workgroup keeps its share of dy and x — NL 16-byte chunks of
+// each per thread, 128 KiB per workgroup, two workgroups per CU: the 33.5 MB of a 256 x 256 x 128 image fit the register files of
+// the chip — while the group meets at a counter to learn the image's sums:
+//   load (dy, x) -> dxh = dy * swish'(u) * gamma and xh, partial sums (LDS, then one fp64 atomic pair per group and workgroup)
+//   -> arrive / poll on cnt[image] -> dx = rstd * (dxh - S1/n - xh * S2/n) (+ dres) from the registers.
+// dxh and xh are parked in the registers of dy / x in the 16-bit storage type (dx is stored in that type anyway).
+// Inter-workgroup hand-off (MI355X_MICROARCH.md, "8-byte agent atomics both sides"): the sums travel as fp64 atomic adds and are
+// read back with 8-byte agent-scope atomic loads, the counter is an agent-scope atomic; `s_waitcnt vmcnt(0)` + barrier between the
+// sums and the counter.  All workgroups of the launch are co-resident (the launcher sizes the grid from the occupancy query), so
+// the poll cannot deadlock; with several groups in flight (and two workgroups per CU) one group's wait is another's streaming.
+constexpr int GNF_NL = 16;
+constexpr int GNF_REP = 32, GNF_CNT = 16;      // replicas of the per-image sums / sub-counters of the arrival count
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gn_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const T* __restrict__ dres, T* __restrict__ dx,
+                                                              double* __restrict__ sums, unsigned* __restrict__ cnt, int B,
+                                                              int HW, int C, int G, int swish, int wg_per_img, int ngroups) {
+  static_assert(sizeof(T) == 2, "16-bit storage types only");
+  __shared__ float s_1[1024], s_2[1024];
+  const int grp = blockIdx.x / wg_per_img, idx = blockIdx.x - grp * wg_per_img;
+  if (grp >= ngroups) return;
+  const int tid = threadIdx.x;
+  const int cpg = C / G, cpr = C / 8, rpp = 256 / cpr;
+  const int cc = tid % cpr, rr = tid / cpr;
+  const int px_per_wg = GNF_NL * rpp;
+  const int p0 = idx * px_per_wg;
+  const double inv_n = 1.0 / ((double)HW * cpg);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gm[j] = gamma[cc * 8 + j];
+    bt[j] = beta[cc * 8 + j];
+  }
+  for (int b = grp; b < B; b += ngroups) {
+    float rs[8], murs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (cc * 8 + j) / cpg;
+      rs[j] = rstd[b * G + g];
+      murs[j] = mean[b * G + g] * rs[j];
+    }
+    u32x4_t xr[GNF_NL], dr[GNF_NL];
+    const int64_t base = ((int64_t)b * HW + p0 + rr) * C + cc * 8;
+#pragma unroll
+    for (int k = 0; k < GNF_NL; ++k) {
+      const bool ok = p0 + rr + k * rpp < HW;
+      const int64_t off = base + (int64_t)k * rpp * C;
+      xr[k] = ok ? __builtin_nontemporal_load((const u32x4_t*)(x + off)) : u32x4_t{0, 0, 0, 0};
+      dr[k] = ok ? __builtin_nontemporal_load((const u32x4_t*)(dy + off)) : u32x4_t{0, 0, 0, 0};
+    }
+    for (int i = tid; i < C; i += 256) s_1[i] = s_2[i] = 0.f;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNF_NL; ++k) {
+      if (p0 + rr + k * rpp < HW) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float xv[2], dv[2];
+          if constexpr (std::is_same<T, f16_t>::value) {
+            const f32pair_t a = unpack_f16x2(xr[k][i]), c2 = unpack_f16x2(dr[k][i]);
+            xv[0] = a[0]; xv[1] = a[1]; dv[0] = c2[0]; dv[1] = c2[1];
+          } else {
+            xv[0] = __uint_as_float(xr[k][i] << 16); xv[1] = __uint_as_float(xr[k][i] & 0xffff0000u);
+            dv[0] = __uint_as_float(dr[k][i] << 16); dv[1] = __uint_as_float(dr[k][i] & 0xffff0000u);
+          }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int j = 2 * i + e;
+            const float xh = xv[e] * rs[j] - murs[j];
+            float d = dv[e];
+            if (swish) d *= act_swish_grad_t<T>(xh * gm[j] + bt[j]);
+            d *= gm[j];
+            a1[j] += d;
+            a2[j] += d * xh;
+            xv[e] = xh;
+            dv[e] = d;
+          }
+          xr[k][i] = lo_pack2<T>(xv[0], xv[1]);
+          dr[k][i] = lo_pack2<T>(dv[0], dv[1]);
+        }
+      }
+    }
+    __syncthreads();                      // s_1 / s_2 zeroed
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&s_1[cc * 8 + j], a1[j]);
+      atomicAdd(&s_2[cc * 8 + j], a2[j]);
+    }
+    __syncthreads();
+    // same-address atomics from hundreds of workgroups serialise at the memory side (measured: the first version, one slot per
+    // group and one counter per image, ran 1564 us against the two-pass form's 1165): the sums are spread over GNF_REP replicas
+    // (workgroup idx adds into replica idx % GNF_REP), the arrivals over GNF_CNT sub-counters
+    if (tid < G) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int c = 0; c < cpg; ++c) {
+        t1 += (double)s_1[tid * cpg + c];
+        t2 += (double)s_2[tid * cpg + c];
+      }
+      double* sp = sums + (((int64_t)b * GNF_REP + (idx % GNF_REP)) * G + tid) * 2;
+      atomicAdd(sp, t1);
+      atomicAdd(sp + 1, t2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's contributions have left the CU ...
+    __syncthreads();
+    if (tid < 64) {                                          // ... before it is counted
+      unsigned* cb = cnt + (int64_t)b * GNF_CNT;
+      if (tid == 0) atomicAdd(cb + (idx % GNF_CNT), 1u);
+      for (;;) {
+        unsigned tot = tid < GNF_CNT ? __hip_atomic_load(cb + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int o = 1; o < GNF_CNT; o <<= 1) tot += __shfl_xor(tot, o, 64);
+        if (__shfl(tot, 0, 64) >= (unsigned)wg_per_img) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    // totals: thread t < 2 G folds the replicas of one sum into LDS (s_1 is free again)
+    if (tid < 2 * G) {
+      const unsigned long long* sp = (const unsigned long long*)(sums + (int64_t)b * GNF_REP * G * 2) + tid;
+      double t = 0.0;
+      const int nrep = wg_per_img < GNF_REP ? wg_per_img : GNF_REP;
+      for (int r = 0; r < nrep; ++r)
+        t += __longlong_as_double((long long)__hip_atomic_load(sp + (int64_t)r * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      s_1[tid] = (float)(t * inv_n);
+    }
+    __syncthreads();
+    float m1[8], m2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (cc * 8 + j) / cpg;
+      m1[j] = s_1[2 * g];
+      m2[j] = s_1[2 * g + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < GNF_NL; ++k) {
+      if (p0 + rr + k * rpp < HW) {
+        const int64_t off = base + (int64_t)k * rpp * C;
+        u32x4_t rv = {0, 0, 0, 0};
+        if (dres) rv = __builtin_nontemporal_load((const u32x4_t*)(dres + off));
+        u32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float xh[2], d[2], r[2];
+          if constexpr (std::is_same<T, f16_t>::value) {
+            const f32pair_t a = unpack_f16x2(xr[k][i]), c2 = unpack_f16x2(dr[k][i]), c3 = unpack_f16x2(rv[i]);
+            xh[0] = a[0]; xh[1] = a[1]; d[0] = c2[0]; d[1] = c2[1]; r[0] = c3[0]; r[1] = c3[1];
+          } else {
+            xh[0] = __uint_as_float(xr[k][i] << 16); xh[1] = __uint_as_float(xr[k][i] & 0xffff0000u);
+            d[0] = __uint_as_float(dr[k][i] << 16); d[1] = __uint_as_float(dr[k][i] & 0xffff0000u);
+            r[0] = __uint_as_float(rv[i] << 16); r[1] = __uint_as_float(rv[i] & 0xffff0000u);
+          }
+          float w[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int j = 2 * i + e;
+            w[e] = rs[j] * (d[e] - m1[j] - xh[e] * m2[j]) + r[e];
+          }
+          o[i] = lo_pack2<T>(w[0], w[1]);
+        }
+        __builtin_nontemporal_store(o, (u32x4_t*)(dx + off));
+      }
+    }
+    __syncthreads();                      // s_1 / s_2 are re-zeroed by the next image
+  }
+}
+
 // ------------------------------- softmax -----------------------------------
 // p[r, :cols] = softmax(scale * s[r, :cols] (+ causal mask)), columns [cols, ldp) zero-filled.
 // Causal: key j is visible to query i = r % q_len iff j <= i (cloob.py:510-516; x-transformers Decoder).
@@ -925,7 +1097,10 @@ static int gn_chunks(int B, int HW, int* rows_per_chunk) {
 extern "C" int64_t ffvc_groupnorm_ws_bytes(int B, int HW, int G) {
   int rpc;
   const int nch = gn_chunks(B, HW, &rpc);
-  return (int64_t)B * nch * G * 2 * (int64_t)sizeof(double);
+  // + the arrival counters of the one-pass backward ([B][G][2] sums, then B counters)
+  const int64_t two_pass = (int64_t)B * nch * G * 2 * (int64_t)sizeof(double);
+  const int64_t one_pass = (int64_t)B * GNF_REP * G * 2 * (int64_t)sizeof(double) + (int64_t)B * GNF_CNT * (int64_t)sizeof(unsigned);
+  return (two_pass > one_pass ? two_pass : one_pass) + 8;
 }
 
 static int gn_check(int B, int HW, int C, int G, int dtype, const char* who) {
@@ -986,6 +1161,47 @@ extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* ga
   FFVC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && ws, "ffvc_groupnorm_bwd: null pointer");
   if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_bwd")) return e;
   hipStream_t st = (hipStream_t)stream;
+  // one-pass form (gn_bwd_fused_kernel): 16-bit tensors whose image fits the registers of the co-resident workgroups
+  {
+    static int fused_opt = -1, cap_f16 = 0, cap_bf16 = 0;
+    if (fused_opt < 0) {
+      const char* e = getenv("FFVC_GN_BWD_FUSED");
+      fused_opt = e ? atoi(e) : 0;   // measured (profiles/r04_gn_bwd_onepass.txt): slower than the two-pass form at every level -> opt-in
+      int dev = 0, ncu = 0, occ = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gn_bwd_fused_kernel<f16_t>, 256, 0) == hipSuccess && occ > 0)
+        cap_f16 = ncu * (occ > 2 ? 2 : occ);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gn_bwd_fused_kernel<uint16_t>, 256, 0) == hipSuccess && occ > 0)
+        cap_bf16 = ncu * (occ > 2 ? 2 : occ);
+    }
+    const int cap = dtype == FFVC_F16 ? cap_f16 : (dtype == FFVC_BF16 ? cap_bf16 : 0);
+    const int cpr = C / 8;
+    if (fused_opt && cap > 0 && dtype != FFVC_F32 && C % 8 == 0 && cpr <= 256 && 256 % cpr == 0 && C <= 1024) {
+      const int px_per_wg = GNF_NL * (256 / cpr);
+      const int wg_per_img = (HW + px_per_wg - 1) / px_per_wg;
+      if (wg_per_img <= cap) {
+        int ngroups = cap / wg_per_img;
+        if (ngroups > B) ngroups = B;
+        double* sums = (double*)ws;
+        unsigned* cnt = (unsigned*)(sums + (size_t)B * GNF_REP * G * 2);
+        hipError_t me = hipMemsetAsync(ws, 0, (size_t)B * GNF_REP * G * 2 * sizeof(double) + (size_t)B * GNF_CNT * sizeof(unsigned), st);
+        if (me != hipSuccess) {
+          ffvc_set_error("ffvc_groupnorm_bwd: memset failed: %s", hipGetErrorString(me));
+          return (int)me;
+        }
+        if (dtype == FFVC_F16)
+          hipLaunchKernelGGL((gn_bwd_fused_kernel<f16_t>), dim3(ngroups * wg_per_img), dim3(256), 0, st, (const f16_t*)dy, (const f16_t*)x,
+                             gamma, beta, mean, rstd, (const f16_t*)dres, (f16_t*)dx, sums, cnt, B, HW, C, G, swish, wg_per_img, ngroups);
+        else
+          hipLaunchKernelGGL((gn_bwd_fused_kernel<uint16_t>), dim3(ngroups * wg_per_img), dim3(256), 0, st, (const uint16_t*)dy,
+                             (const uint16_t*)x, gamma, beta, mean, rstd, (const uint16_t*)dres, (uint16_t*)dx, sums, cnt, B, HW, C, G,
+                             swish, wg_per_img, ngroups);
+        FFVC_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+  }
   int rpc;
   const int nch = gn_chunks(B, HW, &rpc);
   // ~4096 workgroups in total (each one re-derives the group statistics from the chunk partials, so tiny

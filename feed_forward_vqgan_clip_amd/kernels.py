@@ -798,7 +798,7 @@ def mul_dev_scalar(x, s):
     return y
 
 
-def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, in_kernel=False, **kw):
+def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, in_kernel=False, atomic=False, **kw):
     """out[M,N] (fp32, contiguous) += X W^T with the K range cut into `split_k` slices whose partial tiles go to
     slabs (plain stores) and are combined by one ffvc_slab_reduce pass — or, with in_kernel=True, are combined inside the
     launch by the last slice to arrive on each tile (FFVC_F_SPLITK_INKERNEL: no slabs, no reduce launch; the caller must know
@@ -807,6 +807,8 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, in_kernel=False, **kw):
         return gemm(x, w, out, M, N, K, flags=kw.pop("flags", 0) | F_ACCUM_OUT, **kw)
     if in_kernel:
         return gemm(x, w, out, M, N, K, split_k=split_k, flags=kw.pop("flags", 0) | F_ACCUM_OUT | _lib.F_SPLITK_INKERNEL, **kw)
+    if atomic:           # every K slice adds its partial tile straight into `out` with fp32 atomics: no slabs, no reduce pass
+        return gemm(x, w, out, M, N, K, split_k=split_k, flags=kw.pop("flags", 0) | F_ATOMIC_OUT, **kw)
     slabs = torch.empty(split_k, M, N, dtype=torch.float32, device=out.device)
     gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
     _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
@@ -999,29 +1001,85 @@ def set_option(name, value):
 
 
 def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None, coff=None,
-                out_size=None):
-    """pooled (B,3,Ss,Ss) fp32 -> patch rows of cutn*B cutouts of side out_size (default Ss)."""
-    _req_f32(pooled, pinv, ainv, cmat, noise, facs, coff)
+                out_size=None, cj=None):
+    """pooled (B,3,Ss,Ss) fp32 -> patch rows of cutn*B cutouts of side out_size (default Ss).  cj (N,8): kornia ColorJitter
+    parameters per cutout (augment.py), applied after cmat / coff."""
+    _req_f32(pooled, pinv, ainv, cmat, noise, facs, coff, cj)
     _req(torch.int32, erase)
     B, _, Ss, _ = pooled.shape
     S = out_size or Ss
     g = S // patch
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
-    _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), erase.data_ptr(),
-          _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, Ss, cutn, patch, mean[0], mean[1], mean[2],
-          std[0], std[1], std[2], stream_ptr())
+    _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), _ptr(cj),
+          erase.data_ptr(), _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, Ss, cutn, patch, mean[0], mean[1],
+          mean[2], std[0], std[1], std[2], stream_ptr())
     return out
 
 
-def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=None):
-    _req_f32(pinv, ainv, cmat)
+def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=None, pooled=None, coff=None, cj=None):
+    _req_f32(pinv, ainv, cmat, pooled, coff, cj)
     _req(torch.int32, erase)
     _need_cuda(gout)
     Ss = src_size or S
     dpooled = torch.empty(B, 3, Ss, Ss, dtype=torch.float32, device=gout.device)
     _call("ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
-          erase.data_ptr(), dpooled.data_ptr(), B, S, Ss, cutn, patch, std[0], std[1], std[2], stream_ptr())
+          erase.data_ptr(), _ptr(pooled), _ptr(coff), _ptr(cj), dpooled.data_ptr(), B, S, Ss, cutn, patch, std[0], std[1], std[2],
+          stream_ptr())
     return dpooled
+
+
+def sharpness_fwd(x, factor, on):
+    """kornia sharpness on x (N,3,S,S) fp32 with per-sample factor / on flags (fp32 (N,))."""
+    _req_f32(x, factor, on)
+    N, _, S, _ = x.shape
+    y = torch.empty_like(x)
+    _call("ffvc_sharpness_fwd", x.data_ptr(), factor.data_ptr(), on.data_ptr(), y.data_ptr(), N, S, stream_ptr())
+    return y
+
+
+def sharpness_bwd(g, x, factor, on):
+    _req_f32(g, x, factor, on)
+    N, _, S, _ = x.shape
+    dx = torch.empty_like(x)
+    _call("ffvc_sharpness_bwd", g.data_ptr(), x.data_ptr(), factor.data_ptr(), on.data_ptr(), dx.data_ptr(), N, S, stream_ptr())
+    return dx
+
+
+def warp_grid_fwd(x, grid, on):
+    """bilinear grid_sample(align_corners=False, zeros) of x (N,3,S,S) at the normalised coordinates grid (N,S,S,2)."""
+    _req_f32(x, grid, on)
+    N, _, S, _ = x.shape
+    y = torch.empty_like(x)
+    _call("ffvc_warp_grid_fwd", x.data_ptr(), grid.data_ptr(), on.data_ptr(), y.data_ptr(), N, S, stream_ptr())
+    return y
+
+
+def warp_grid_bwd(g, grid, on):
+    _req_f32(g, grid, on)
+    N, _, S, _ = g.shape
+    dx = torch.empty_like(g)
+    _call("ffvc_warp_grid_bwd", g.data_ptr(), grid.data_ptr(), on.data_ptr(), dx.data_ptr(), N, S, stream_ptr())
+    return dx
+
+
+def tps_grid(tps, S):
+    """tps (N,26) fp32 (augment.tps_params) -> sampling grid (N,S,S,2)."""
+    _req_f32(tps)
+    N = tps.shape[0]
+    grid = torch.empty(N, S, S, 2, dtype=torch.float32, device=tps.device)
+    _call("ffvc_tps_grid", tps.data_ptr(), grid.data_ptr(), N, S, stream_ptr())
+    return grid
+
+
+def elastic_grid(noise, ksize=63, sigma=32.0, alpha=(1.0, 1.0)):
+    """noise (N,2,S,S) fp32 in [-1,1] -> sampling grid (N,S,S,2) of kornia's elastic_transform2d."""
+    _req_f32(noise)
+    N, _, S, _ = noise.shape
+    tmp, disp = torch.empty_like(noise), torch.empty_like(noise)
+    grid = torch.empty(N, S, S, 2, dtype=torch.float32, device=noise.device)
+    _call("ffvc_elastic_grid", noise.data_ptr(), tmp.data_ptr(), disp.data_ptr(), grid.data_ptr(), N, S, int(ksize), float(sigma),
+          float(alpha[0]), float(alpha[1]), stream_ptr())
+    return grid
 
 
 def avgpool_patches_fwd(x, out_size, patch, mean, std, out_dtype):

@@ -84,27 +84,29 @@ replace_grad = _ReplaceGrad.apply
 
 class MakeCutouts(nn.Module):
     """main.py:154-229.  Source image = (AdaptiveAvg+AdaptiveMax)/2 pooling to pool_size (pool=True, :213-215) or the
-    decoded image itself (pool=False, :216-217), repeated cutn times; then the augmentation list as ONE fused resampling
-    kernel (ffvc_augment_fwd/bwd) driven by per-cutout parameters (augment.py): 'R' (bilinear resize to cut_size),
-    'Af','Pe','Ji','Er' (the default set), 'Ro','Re','Re2','Cr','Cc','Ji2','Er2','Gn'; the additive noise
+    decoded image itself (pool=False, :216-217), repeated cutn times; then the augmentation list driven by per-cutout parameters
+    (augment.py): every name of main.py:166-198 — 'Af','Pe','Ji','Er' (the default set), 'Ro','Re','Re2','Cr','Cc','Ji2','Er2','Gn',
+    'R' as fused resampling launches (ffvc_augment_fwd/bwd: one launch for the default set), 'Sh','Et','Ts' (sharpness / elastic /
+    thin-plate spline) as their own image -> image kernels in between (augment.plan()); the additive noise
     `U(0,noise_fac)*N(0,1)` (:222-225); with interpolate=True adaptive average pooling to interp_size (:226-228).
-    'Sh','Et','Ts' (sharpness / elastic / thin-plate spline: 3x3 and displacement-field operators that do not compose into
-    one homography) are not built and raise."""
+    `sequential=True` (config `augment_sequential`): every resampling operator gets its own pass, as kornia's nn.Sequential
+    resamples (two bilinear interpolations for Af -> Pe instead of one); default: fused."""
 
     def __init__(self, cut_size, cutn, cut_pow=1.0, pool_size=None, interp_size=None, augs=None, pool=True,
-                 interpolate=False):
+                 interpolate=False, sequential=False):
         super().__init__()
         augs = tuple(augs) if augs else ("Af", "Pe", "Ji", "Er")      # main.py:164-165 (empty list -> defaults)
         for a in augs:
             if a not in _augment.SUPPORTED:
-                raise NotImplementedError(f"augs={list(augs)}: '{a}' is not built on the HIP path (built: "
-                                          f"{list(_augment.SUPPORTED)})")
+                raise NotImplementedError(f"augs={list(augs)}: '{a}' is not one of main.py:166-198's names "
+                                          f"({list(_augment.SUPPORTED)})")
         self.all_augs = augs
         self.augs = tuple(a for a in augs if a != "R")                # what is left when 'R' is the identity
         self.pool, self.interpolate = bool(pool), bool(interpolate)
         self.pool_size = pool_size or cut_size                         # main.py:200-201
         self.interp_size = interp_size or self.pool_size              # main.py:202-203
         self.cut_size, self.cutn, self.noise_fac = cut_size, cutn, 0.1
+        self.sequential = bool(sequential)
         self.generator = None                                         # torch.Generator for reproducible parameter draws
 
     def _plain(self, H):
@@ -123,20 +125,23 @@ class MakeCutouts(nn.Module):
         return self.interp_size if self.interpolate else self.batch_size_px(H)
 
     def draw_aug_params(self, n, device, H=None):
-        """Per-cutout augmentation parameters (None when the configuration needs no resampling)."""
+        """Per-cutout augmentation parameters (None when the configuration needs no resampling): the parameter dict of ONE fused
+        launch, or the list of segments augment.plan() returns when the chain needs several."""
         src = self.source_size(H if H is not None else self.cut_size)
         if not self.augs and src == self.cut_size:
             return None
-        prm = _augment.draw_params(n, self.cut_size, self.all_augs if src != self.cut_size else self.augs,
-                                   generator=self.generator, src_size=src)
-        if torch.device(device).type != "cuda":
-            return prm
-        # pinned staging (caching host allocator) keeps the upload asynchronous: a pageable copy would stall the host
-        # until everything already queued on the stream (mapper + decoder) has run
-        return {k: v.pin_memory().to(device, non_blocking=True) for k, v in prm.items()}
+        chain = _augment.draw_chain(n, self.cut_size, self.all_augs if src != self.cut_size else self.augs,
+                                    generator=self.generator, src_size=src, device=device)
+        segs = _augment.plan(chain, n, self.cut_size, src, sequential=self.sequential)
+        if torch.device(device).type == "cuda":
+            # pinned staging (caching host allocator) keeps the upload asynchronous: a pageable copy would stall the host
+            # until everything already queued on the stream (mapper + decoder) has run
+            up = lambda v: v if (not torch.is_tensor(v) or v.is_cuda) else v.pin_memory().to(device, non_blocking=True)  # noqa: E731
+            segs = [(kind, {k: up(v) for k, v in prm.items()}) for kind, prm in segs]
+        return segs[0][1] if len(segs) == 1 else segs
 
     def patches(self, xr_nhwc, patch, mean, std, out_dtype, facs=None, noise=None, aug_params=None):
-        """NHWC fp32 image batch -> normalised ViT patch rows with the configured augmentations (fused path)."""
+        """NHWC fp32 image batch -> normalised ViT patch rows with the configured augmentations."""
         B, H = xr_nhwc.shape[0], xr_nhwc.shape[1]
         n = self.cutn * B
         size = self.batch_size_px(H)
@@ -150,19 +155,38 @@ class MakeCutouts(nn.Module):
         if aug_params is None:                                        # identity chain: still goes through the resampler
             aug_params = _augment.draw_params(n, self.cut_size, (), src_size=src)
             aug_params = {k: v.to(xr_nhwc.device) for k, v in aug_params.items()}
-        gn = aug_params.get("gn")
-        if gn is not None and "Gn" in self.augs:       # 'Gn' N(0,1) noise + the U(0,noise_fac)*N(0,1) term = one Gaussian
+        segs = [("fused", aug_params)] if isinstance(aug_params, dict) else list(aug_params)
+        gn = None
+        for kind, prm in segs:
+            if kind == "fused" and prm.get("gn") is not None and "Gn" in self.augs:
+                gn = prm["gn"] if gn is None else torch.maximum(gn, prm["gn"])
+        if gn is not None:                              # 'Gn' N(0,1) noise + the U(0,noise_fac)*N(0,1) term = one Gaussian
             if noise is None:
                 noise = torch.randn(n, 3, size, size, device=xr_nhwc.device)
             facs = gn.to(xr_nhwc.device) if facs is None else torch.sqrt(facs * facs + gn.to(facs.device) ** 2)
         # pool=False: the same kernel at cut == H is the identity pooling, i.e. a NHWC -> NCHW copy of the decoded image
-        pooled = ops.cutouts(xr_nhwc, src, 1, src, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32).view(B, 3, src, src)
-        if not self.interpolate or self.interp_size == size:
-            return ops.augment(pooled, aug_params, self.cutn, patch, mean, std, out_dtype, noise=noise, facs=facs,
-                               out_size=size)
-        batch = ops.augment(pooled, aug_params, self.cutn, size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32, noise=noise,
-                            facs=facs, out_size=size).view(n, 3, size, size)
-        return ops.avgpool_patches(batch, self.interp_size, patch, mean, std, out_dtype)          # main.py:226-228
+        x = ops.cutouts(xr_nhwc, src, 1, src, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32).view(B, 3, src, src)
+        zero3, one3 = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+        cutn = self.cutn                                  # the first fused launch repeats the pooled image cutn times
+        for i, (kind, prm) in enumerate(segs):
+            last = i == len(segs) - 1
+            if kind == "Sh":
+                x = ops.sharpness(x, prm["factor"], prm["on"])
+            elif kind == "Et":
+                x = ops.warp_grid(x, K.elastic_grid(prm["noise"]), prm["on"])
+            elif kind == "Ts":
+                x = ops.warp_grid(x, K.tps_grid(prm["tps"], x.shape[-1]), prm["on"])
+            elif not last:                                # intermediate fused launch: a plain fp32 image batch, no noise
+                so = prm.get("out", size)
+                x = ops.augment(x, prm, cutn, so, zero3, one3, torch.float32, out_size=so).view(n, 3, so, so)
+                cutn = 1
+            elif not self.interpolate or self.interp_size == size:
+                return ops.augment(x, prm, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs, out_size=size)
+            else:
+                batch = ops.augment(x, prm, cutn, size, zero3, one3, torch.float32, noise=noise, facs=facs,
+                                    out_size=size).view(n, 3, size, size)
+                return ops.avgpool_patches(batch, self.interp_size, patch, mean, std, out_dtype)          # main.py:226-228
+        raise RuntimeError("MakeCutouts: the augmentation plan did not end in a fused launch")
 
     def draw_noise(self, n, device, size=None):
         if not self.noise_fac:
@@ -400,7 +424,8 @@ class TrainStep:
                                         augs=config.get("augs"), pool=config.get("pool", True),
                                         pool_size=config.get("pool_size", self.clip_size),
                                         interpolate=config.get("interpolate", False),
-                                        interp_size=config.get("interp_size", self.clip_size))
+                                        interp_size=config.get("interp_size", self.clip_size),
+                                        sequential=config.get("augment_sequential", False))
         if config.get("noise_fac") is not None:
             self.make_cutouts.noise_fac = config.get("noise_fac")
         if config.diversity_coef:

@@ -151,6 +151,7 @@ _FP8_FUSE = os.environ.get("FFVC_FP8_FUSE", "1") != "0"                   # A/B:
 _TM_WGRAD_INKERNEL = os.environ.get("FFVC_TOKMIX_WGRAD_INKERNEL", "0") != "0"   # A/B: one launch with the in-kernel split-K instead of slabs + reduce
 _SK_TARGET = int(os.environ.get("FFVC_SK_TARGET", "768"))  # A/B: workgroups a small-output weight gradient is split into
 _WGRAD_SK = int(os.environ.get("FFVC_WGRAD_SK", "0"))     # A/B: cap of the split-K factor of the 256x256-tile wgrads
+_WGRAD_ATOMIC = os.environ.get("FFVC_WGRAD_ATOMIC", "0") != "0"   # A/B: K slices of the big weight gradients meet through fp32 atomics
 
 
 def _split_k(n_out, k_out, red, bk, big_tiles=False):
@@ -182,8 +183,8 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
     inker = (_WGRAD_INKERNEL and big and 1 < sk <= 8 and Nr >= 1024 and Kr >= 1024 and Nr % 256 == 0 and Kr % 256 == 0 and rows >= 8192 and
              (Nr // 256) * (Kr // 256) * sk >= 192)
     with _on_side(dy2d, x2d):
-        K.gemm_splitk_accumulate(dy2d, x2d, wg, Nr, Kr, rows, sk, in_kernel=inker, ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS,
-                                 w_mode=K.OP_TRANS)
+        K.gemm_splitk_accumulate(dy2d, x2d, wg, Nr, Kr, rows, sk, in_kernel=inker, atomic=_WGRAD_ATOMIC and big and sk > 1,
+                                 ldx=ldy or W.N, ldw=W.K, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS)
         if bg is not None:
             K.colsum(dy2d, bg, accumulate=True, ld=ldy)
     if W.on_grad is not None:
@@ -760,16 +761,24 @@ def clamp_with_grad(x, lo, hi, mul=1.0, add=0.0, out_dtype=None):
     return _ClampFn.apply(x, float(mul), float(add), float(lo), float(hi), out_dtype)
 
 
+_VQ_SPLIT = os.environ.get("FFVC_VQ_SPLIT", "1") != "0"   # A/B: 16-bit modes take the z . codebook^T products through split-precision f16
+
+
 class _VQFn(Function):
     @staticmethod
-    def forward(ctx, z, codebook, cnorm, out_dtype, force_idx):
+    def forward(ctx, z, codebook, cnorm, out_dtype, force_idx, cb3=None):
         z = _contig(z)
         C = z.shape[-1]
         rows = z.numel() // C
         n = codebook.shape[0]
         if force_idx is None:
             dot = torch.empty(rows, n, dtype=torch.float32, device=z.device)
-            K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
+            if cb3 is not None and _VQ_SPLIT:
+                # fp32-grade products on the f16 matrix pipes (ffvc_split3: [hi|lo|hi] . [hi|hi|lo], every term but lo x lo,
+                # ~2^-22 relative): 16384 x 16384 x 256 in exact-fp32 MFMA is 1.4 ms of the step, this form a third of it
+                K.gemm(K.split3(z.view(rows, C)), cb3, dot, rows, n, 3 * C, ldx=3 * C, ldw=3 * C)
+            else:
+                K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
             idx = K.vq_argmin(dot, K.rownorm_sq(z), cnorm)
         else:
             idx = force_idx.reshape(rows).to(torch.int64).contiguous()
@@ -779,14 +788,15 @@ class _VQFn(Function):
 
     @staticmethod
     def backward(ctx, g, _):
-        return _as(_contig(g), ctx.zdtype), None, None, None, None      # straight-through (main.py:105-116,138)
+        return _as(_contig(g), ctx.zdtype), None, None, None, None, None   # straight-through (main.py:105-116,138)
 
 
-def vector_quantize(z, codebook, cnorm, out_dtype, force_idx=None):
+def vector_quantize(z, codebook, cnorm, out_dtype, force_idx=None, cb3=None):
     """z: (..., C) fp32 -> (z_q in out_dtype, indices). Nearest code, STE gradient (main.py:134-138).
     force_idx: take these codes instead of the argmin (parity instrumentation: the argmin is a discontinuity, so
-    stage-wise precision checks hand the reference's codes to the low-precision decoder)."""
-    return _VQFn.apply(z, codebook, cnorm, out_dtype, force_idx)
+    stage-wise precision checks hand the reference's codes to the low-precision decoder).
+    cb3: K.split3(codebook, weight_order=True) — the 16-bit modes' split-precision distance GEMM (None: exact fp32 MFMA)."""
+    return _VQFn.apply(z, codebook, cnorm, out_dtype, force_idx, cb3)
 
 
 class _CutoutsFn(Function):
@@ -812,25 +822,65 @@ class _AugmentFn(Function):
     """Fused augmentation chain on the pooled image (kernels.augment_fwd / augment_bwd)."""
 
     @staticmethod
-    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None, out_size=None):
+    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None, out_size=None, cj=None):
         pooled = _contig(pooled)
-        ctx.save_for_backward(pinv, ainv, cmat, erase)
+        # the colour jitter is not linear: its backward re-evaluates the forward up to the jitter (needs the source image)
+        ctx.save_for_backward(pinv, ainv, cmat, erase, pooled if cj is not None else None, coff if cj is not None else None, cj)
         ctx.cfg = (pooled.shape[0], out_size or pooled.shape[2], pooled.shape[2], cutn, patch, std)
         return K.augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs,
-                             coff=coff, out_size=out_size)
+                             coff=coff, out_size=out_size, cj=cj)
 
     @staticmethod
     def backward(ctx, g):
-        pinv, ainv, cmat, erase = ctx.saved_tensors
+        pinv, ainv, cmat, erase, pooled, coff, cj = ctx.saved_tensors
         B, S, Ss, cutn, patch, std = ctx.cfg
-        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=Ss),) + (None,) * 13
+        return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=Ss, pooled=pooled, coff=coff,
+                              cj=cj),) + (None,) * 14
 
 
 def augment(pooled, params, cutn, patch, mean, std, out_dtype, noise=None, facs=None, out_size=None):
     """pooled: (B,3,Ss,Ss) fp32 -> ViT patch rows (cutn*B, (S/patch)^2, 3*patch^2), S = out_size or Ss; params from
-    augment.draw_params (drawn for that source / output size pair)."""
+    augment.draw_params / augment.plan (drawn for that source / output size pair)."""
     return _AugmentFn.apply(pooled, noise, facs, params["pinv"], params["ainv"], params["cmat"], params["erase"], cutn,
-                            patch, mean, std, out_dtype, params.get("coff"), out_size)
+                            patch, mean, std, out_dtype, params.get("coff"), out_size, params.get("cj"))
+
+
+class _SharpnessFn(Function):
+    """kornia RandomSharpness on the cutout batch (N,3,S,S) fp32 (main.py:169), per-sample factor / on flags."""
+
+    @staticmethod
+    def forward(ctx, x, factor, on):
+        x = _contig(x)
+        ctx.save_for_backward(x, factor, on)
+        return K.sharpness_fwd(x, factor, on)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, factor, on = ctx.saved_tensors
+        return K.sharpness_bwd(_contig(g), x, factor, on), None, None
+
+
+def sharpness(x, factor, on):
+    return _SharpnessFn.apply(x, factor, on)
+
+
+class _WarpGridFn(Function):
+    """Bilinear resampling of the cutout batch at a dense coordinate field (RandomElasticTransform / RandomThinPlateSpline,
+    main.py:179,181); the field does not depend on the image, so only the image gets a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, grid, on):
+        ctx.save_for_backward(grid, on)
+        return K.warp_grid_fwd(_contig(x), grid, on)
+
+    @staticmethod
+    def backward(ctx, g):
+        grid, on = ctx.saved_tensors
+        return K.warp_grid_bwd(_contig(g), grid, on), None, None
+
+
+def warp_grid(x, grid, on):
+    return _WarpGridFn.apply(x, grid, on)
 
 
 class _AvgPoolPatchesFn(Function):

@@ -125,6 +125,10 @@ class VQGAN:
         self.quantize = types.SimpleNamespace(embedding=types.SimpleNamespace(weight=cb))
         self.codebook = cb
         self.cnorm = K.rownorm_sq(cb)
+        # 16-bit modes: the distance GEMM runs split-precision on the f16 pipes (ops._VQFn); the parity mode keeps exact fp32 MFMA.
+        # |c| must fit f16's range for the hi part (a real f16-16384 codebook is O(1))
+        self.cb3 = K.split3(cb, torch.float16, weight_order=True) if (cdt != torch.float32 and cb.shape[1] % 8 == 0 and
+                                                                     float(cb.abs().max()) < 6e4) else None
         self.post_quant = ops.Weights.frozen(sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], cdt)
         d = "decoder"
         self.conv_in = ops.ConvWeights(sd[d + ".conv_in.weight"], sd[d + ".conv_in.bias"], cdt)
@@ -165,7 +169,7 @@ class VQGAN:
 
     def quantize_nhwc(self, z_nhwc, force_idx=None):
         """(B,S,S,C) fp32 -> (z_q compute dtype with straight-through grad, indices)."""
-        return ops.vector_quantize(z_nhwc, self.codebook, self.cnorm, self.cdt, force_idx)
+        return ops.vector_quantize(z_nhwc, self.codebook, self.cnorm, self.cdt, force_idx, self.cb3)
 
     # -- reference-shaped API ---------------------------------------------------
     def decode(self, z_q):

@@ -339,12 +339,16 @@ int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr,
  * pinv [N,9] inverse perspective homography, ainv [N,6] inverse affine (pixel units), cmat [N,9] RGB colour matrix,
  * erase [N,4] int32 rectangle x0,y0,x1,y1 (x1 <= x0: none).  kornia 0.5.10 itself is absent: parity unpinned.
  * The backward scatters into dpooled [B,3,S,S] (zeroed inside); chain it with ffvc_cutouts_bwd(cutn 1, patch S). */
-int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff /* (N,3) colour offset added after cmat, may be NULL */, const int32_t* erase,
-                     const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int S_src, int cutn,
+int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff /* (N,3) colour offset added after cmat, may be NULL */,
+                     const float* cj /* (N,8) kornia ColorJitter parameters [on, brightness, contrast, saturation, hue (turns), order code, -, -] applied after cmat, may be NULL */,
+                     const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int S_src, int cutn,
                      int patch, float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+/* padding of the homography slot pinv: zeros with grid_sample's one-pixel linear fade when the matrix rotates / shears / projects
+ * (RandomPerspective, RandomRotation), plain coordinate clamping when it only scales and shifts (resize, crop, identity) */
+/* pooled / coff / cj: the forward's inputs, needed only when cj != NULL (the jitter is not linear; its Jacobian is re-evaluated) */
 int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
-                     const int32_t* erase, float* dpooled, int B, int S, int S_src, int cutn, int patch, float std_r,
-                     float std_g, float std_b, void* stream);
+                     const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled, int B, int S,
+                     int S_src, int cutn, int patch, float std_r, float std_g, float std_b, void* stream);
 /* S = side of the cutouts written, S_src = side of the source image `pooled` [B,3,S_src,S_src]: they differ when the chain
  * holds a resize / crop ('R','Re','Cr','Cc' on a pool_size != cut_size or pool=False source, main.py:203-221), which is then
  * part of pinv.  MakeCutouts(interpolate=True) (main.py:226-228): adaptive average pooling of the augmented batch
@@ -353,6 +357,19 @@ int ffvc_avgpool_patches_fwd(const float* x, void* out, int out_dtype, int N, in
                              float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 int ffvc_avgpool_patches_bwd(const void* gout, int g_dtype, float* dx, int N, int S, int So, int patch, float std_r,
                              float std_g, float std_b, void* stream);
+/* MakeCutouts augmentations that are not one homography (main.py:169,179,181: 'Sh' RandomSharpness, 'Et' RandomElasticTransform,
+ * 'Ts' RandomThinPlateSpline; kornia 0.5.10 semantics, csrc/augment_ops.hip): image -> image on the cutout batch x [N,3,S,S] fp32.
+ * on[n] == 0 passes sample n through.  grid [N,S,S,2]: NORMALISED sampling coordinates (x, y) of
+ * grid_sample(align_corners=False, padding_mode='zeros').  ffvc_tps_grid: tps [N,26] = 5 centres (x,y), 5 kernel weight pairs,
+ * affine a0 (2), coefficients of p.x (2), of p.y (2).  ffvc_elastic_grid: noise [N,2,S,S] in [-1,1] -> Gaussian(ksize, sigma,
+ * reflect) per component (tmp, disp: [N,2,S,S] scratch) -> grid = clamp(identity + alpha * disp, -1, 1). */
+int ffvc_sharpness_fwd(const float* x, const float* factor, const float* on, float* y, int N, int S, void* stream);
+int ffvc_sharpness_bwd(const float* g, const float* x, const float* factor, const float* on, float* dx, int N, int S, void* stream);
+int ffvc_warp_grid_fwd(const float* x, const float* grid, const float* on, float* y, int N, int S, void* stream);
+int ffvc_warp_grid_bwd(const float* g, const float* grid, const float* on, float* dx, int N, int S, void* stream);
+int ffvc_tps_grid(const float* tps, float* grid, int N, int S, void* stream);
+int ffvc_elastic_grid(const float* noise, float* tmp, float* disp, float* grid, int N, int S, int ksize, float sigma,
+                      float alpha_x, float alpha_y, void* stream);
 /* Spherical distance loss (main.py:801-811), repeat=1: loss = coef*mean_n 2*asin(|H-E|/2)^2 with
  * H = normalize(feats[n % B]), E = normalize(embed[n]); dembed (may be NULL) <- d loss / d embed. */
 int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, float* loss, float* dembed, int N,

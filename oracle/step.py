@@ -107,7 +107,7 @@ def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_s
     else:                                                                               # default augs, explicit parameters
         pooled = (F.adaptive_avg_pool2d(xr, cut_size) + F.adaptive_max_pool2d(xr, cut_size)) / 2   # :217
         x = augment_reference(pooled, aug_params["pinv"], aug_params["ainv"], aug_params["cmat"], aug_params["erase"], cutn,
-                              facs, noise, coff=aug_params.get("coff"))
+                              facs, noise, coff=aug_params.get("coff"), cj=aug_params.get("cj"))
     mean = torch.tensor(CLIP_MEAN, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     std = torch.tensor(CLIP_STD, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
     x = (x - mean) / std                                                                # :797
@@ -127,10 +127,12 @@ def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-8):
         p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None, out_size=None):
+def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None, out_size=None, cj=None):
     """Plain-PyTorch statement of ffvc_augment_fwd (the fused Af -> Pe -> Ji -> Er chain of main.py:164-198 with
-    explicit per-cutout parameters): returns (cutn*B, 3, S, S) BEFORE mean/std normalisation.  kornia itself is not
-    restated (absent offline, parity unpinned); this pins the HIP kernel to the documented resampling formula."""
+    explicit per-cutout parameters): returns (cutn*B, 3, S, S) BEFORE mean/std normalisation.  This pins the HIP kernel to
+    its documented single-resample formula; kornia's own sequential form is restated in oracle/kornia_aug.py, and
+    tools/augment_deviation.py measures one against the other.  cj (N,8): ColorJitter parameters as augment.plan() lays them
+    out ([on, brightness, contrast, saturation, hue, order code]), applied with oracle/kornia_aug.color_jitter."""
     B, _, S, _ = pooled.shape                      # S: side of the source frame; So: side of the cutouts (a resize / crop in
     So = out_size or S                             # the chain is part of pinv)
     N = cutn * B
@@ -143,7 +145,11 @@ def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=No
     w = torch.where(w.abs() > 1e-8, w, torch.full_like(w, 1e-8))
     x1 = (pe(0) * x2 + pe(1) * y2 + pe(2)) / w
     y1 = (pe(3) * x2 + pe(4) * y2 + pe(5)) / w
-    m = ((x1 >= -0.5) & (x1 <= S - 0.5) & (y1 >= -0.5) & (y1 <= S - 0.5)).to(pooled.dtype)
+    # zero padding as grid_sample applies it: every tap outside the frame is zero -> linear fade over one pixel
+    m = ((x1 + 1).clamp(0, 1) * (S - x1).clamp(0, 1)) * ((y1 + 1).clamp(0, 1) * (S - y1).clamp(0, 1))
+    # a homography slot that only scales / shifts (resize, crop, identity) holds no zero-padded warp: coordinates are clamped only
+    zp = ((P[:, 1] != 0) | (P[:, 3] != 0) | (P[:, 6] != 0) | (P[:, 7] != 0)).view(N, 1, 1)
+    m = torch.where(zp, m, torch.ones_like(m))
     x0 = (ae(0) * x1 + ae(1) * y1 + ae(2)).clamp(0, S - 1)
     y0 = (ae(3) * x1 + ae(4) * y1 + ae(5)).clamp(0, S - 1)
     xi = x0.floor().clamp(max=max(S - 2, 0)).long()
@@ -159,6 +165,15 @@ def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=No
     out = torch.einsum("nij,njhw->nihw", cmat.view(N, 3, 3).to(pooled.dtype), val)
     if coff is not None:
         out = out + coff.view(N, 3, 1, 1).to(pooled.dtype)
+    if cj is not None:
+        from . import kornia_aug as ka
+        c = cj.view(N, 8).to(pooled.dtype)
+        on = c[:, 0] != 0
+        if bool(on.any()):
+            idx = on.nonzero().squeeze(1)
+            code = int(c[idx[0], 5])
+            order = [(code >> (2 * k)) & 3 for k in range(4)]
+            out = out.index_copy(0, idx, ka.color_jitter(out[idx], c[idx, 1], c[idx, 2], c[idx, 3], c[idx, 4], order))
     e = erase.view(N, 4)
     er = (xs[None] >= e[:, 0].view(N, 1, 1)) & (xs[None] < e[:, 2].view(N, 1, 1)) & \
          (ys[None] >= e[:, 1].view(N, 1, 1)) & (ys[None] < e[:, 3].view(N, 1, 1))

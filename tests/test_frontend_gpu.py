@@ -106,17 +106,30 @@ def test_encode_text_and_images_pairs(cuda, tmp_path):
 
 # ----------------------------------------------------------------------------- MakeCutouts: the non-default branches
 def _cut_oracle(x, mc, prm, facs, noise):
-    """main.py:203-229 restated with the oracle's resampling formula: source (pooled or raw) -> chain -> noise -> interpolate."""
+    """main.py:203-229 restated with the oracle's resampling formula: source (pooled or raw) -> chain -> noise -> interpolate.
+    prm: the parameter dict of one fused launch, or augment.plan()'s list of fused launches."""
     import torch.nn.functional as F
     from oracle import step as ostep
     B, H = x.shape[0], x.shape[2]
-    src = (F.adaptive_avg_pool2d(x, mc.pool_size) + F.adaptive_max_pool2d(x, mc.pool_size)) / 2 if mc.pool else x
+    batch = (F.adaptive_avg_pool2d(x, mc.pool_size) + F.adaptive_max_pool2d(x, mc.pool_size)) / 2 if mc.pool else x
     size = mc.batch_size_px(H)
-    batch = ostep.augment_reference(src, prm["pinv"], prm["ainv"], prm["cmat"], prm["erase"], mc.cutn, facs=facs, noise=noise,
-                                    coff=prm.get("coff"), out_size=size)
+    segs = [("fused", prm)] if isinstance(prm, dict) else prm
+    cutn = mc.cutn
+    for i, (kind, q) in enumerate(segs):
+        assert kind == "fused"
+        last = i == len(segs) - 1
+        batch = ostep.augment_reference(batch, q["pinv"], q["ainv"], q["cmat"], q["erase"], cutn, facs=facs if last else None,
+                                        noise=noise if last else None, coff=q.get("coff"), out_size=size if last else q.get("out"),
+                                        cj=q.get("cj"))
+        cutn = 1
     if mc.interpolate:
         batch = F.adaptive_avg_pool2d(batch, mc.interp_size)
     return batch
+
+
+def _to_cuda(prm):
+    up = lambda d: {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}    # noqa: E731
+    return up(prm) if isinstance(prm, dict) else [(k, up(d)) for k, d in prm]
 
 
 @pytest.mark.parametrize("kw", [
@@ -147,7 +160,7 @@ def test_makecutouts_branches_match_oracle(cuda, kw):
     gw = torch.randn(ref.shape, generator=g)
     (ref * gw).sum().backward()
     xh = x.cuda().requires_grad_(True)
-    out = mc(xh, facs=facs.cuda(), noise=noise.cuda(), aug_params={k: v.cuda() for k, v in prm.items()})
+    out = mc(xh, facs=facs.cuda(), noise=noise.cuda(), aug_params=_to_cuda(prm))
     assert tuple(out.shape) == tuple(ref.shape)
     assert _relmax(out, ref.detach()) < 1e-4
     (out * gw.cuda()).sum().backward()
@@ -170,7 +183,41 @@ def test_resize_only_cutouts_equal_torch_interpolate(cuda):
     assert _relmax(up(x.cuda()), F.interpolate(x, (64, 64), mode="bilinear")) < 1e-5
 
 
-def test_unbuilt_augmentations_raise():
-    for a in ("Sh", "Et", "Ts"):
-        with pytest.raises(NotImplementedError):
-            fmain.MakeCutouts(32, 2, augs=[a])
+@pytest.mark.parametrize("augs", [["Sh"], ["Af", "Sh", "Pe"], ["Et"], ["Ts"], ["Af", "Pe", "Ji", "Er", "Sh", "Et", "Ts"], ["Ji2", "Ts", "Er2"]])
+def test_sharpness_elastic_tps_match_the_kornia_restatement(cuda, augs):
+    """'Sh' / 'Et' / 'Ts' (main.py:169,179,181) run as their own kernels between fused launches.  With one warp per launch
+    (`sequential=True`) the whole chain is, operator by operator, what kornia's nn.Sequential computes: checked against
+    oracle/kornia_aug.apply_chain on the SAME raw draws, forward and gradient."""
+    from feed_forward_vqgan_clip_amd import augment as A
+    from oracle import kornia_aug as ka
+    B, cut, cutn = 2, 32, 3
+    n = cutn * B
+    mc = fmain.MakeCutouts(cut, cutn, augs=augs, pool=True, sequential=True)
+    mc.noise_fac = 0
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 3, 64, 64, generator=g)
+    chain = A.draw_chain(n, cut, tuple(augs), g, p=0.8)
+    segs = A.plan(chain, n, cut, cut, sequential=True)
+    xo = x.double().requires_grad_(True)
+    import torch.nn.functional as F
+    pooled = (F.adaptive_avg_pool2d(xo, cut) + F.adaptive_max_pool2d(xo, cut)) / 2
+    ref = ka.apply_chain(pooled.repeat(cutn, 1, 1, 1), chain)
+    gw = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * gw).sum().backward()
+    xh = x.cuda().requires_grad_(True)
+    out = mc(xh, aug_params=_to_cuda(segs))
+    assert tuple(out.shape) == tuple(ref.shape)
+    err = (out.double().cpu() - ref.detach()).abs()
+    assert (err > 2e-4).float().mean().item() < 2e-3, (err.max().item(), (err > 2e-4).float().mean().item())   # floor() ties in fp32
+    (out * gw.float().cuda()).sum().backward()
+    assert _relmax(xh.grad, xo.grad.float()) < 2e-2
+
+
+def test_every_reference_augmentation_name_is_built(cuda):
+    """main.py:166-198: the full name list constructs, draws and runs (default fused plan)."""
+    for a in ("Ji2", "Ji", "Sh", "Gn", "Pe", "Ro", "Af", "Et", "Ts", "Cr", "Er", "Er2", "Re", "Re2", "Cc", "R"):
+        mc = fmain.MakeCutouts(32, 2, augs=[a])
+        out = mc(torch.rand(2, 3, 48, 48).cuda())
+        assert tuple(out.shape) == (4, 3, 32, 32) and torch.isfinite(out).all()
+    with pytest.raises(NotImplementedError):
+        fmain.MakeCutouts(32, 2, augs=["Xx"])

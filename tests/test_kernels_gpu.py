@@ -236,11 +236,12 @@ def test_augment_matches_oracle_reference(cuda, odt):
     facs = torch.rand(cutn * B, generator=g) * 0.1
     mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
     dev = {k: v.to(cuda) for k, v in prm.items()}
+    assert prm["cj"][:, 0].sum() > 0                                            # the kornia ColorJitter path is exercised
     out = K.augment_fwd(pooled.to(cuda), dev["pinv"], dev["ainv"], dev["cmat"], dev["erase"], cutn, P, mean, std, odt,
-                        noise=noise.to(cuda), facs=facs.to(cuda))
+                        noise=noise.to(cuda), facs=facs.to(cuda), coff=dev["coff"], cj=dev["cj"])
     pd = pooled.double().requires_grad_(True)
     ref = ostep.augment_reference(pd, prm["pinv"].double(), prm["ainv"].double(), prm["cmat"].double(), prm["erase"], cutn,
-                                  facs.double(), noise.double())
+                                  facs.double(), noise.double(), coff=prm["coff"].double(), cj=prm["cj"])
     m = torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)
     s = torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
     refn = (ref - m) / s
@@ -251,7 +252,8 @@ def test_augment_matches_oracle_reference(cuda, odt):
     tol = {torch.bfloat16: 3e-2, torch.float16: 4e-3}.get(odt, 1e-3)
     assert (err > tol).float().mean().item() < 2e-3, f"mismatching fraction {(err > tol).float().mean().item()}"
     gout = _mk(tuple(out.shape), odt, cuda, 5)
-    dp = K.augment_bwd(gout, dev["pinv"], dev["ainv"], dev["cmat"], dev["erase"], B, S, cutn, P, std)
+    dp = K.augment_bwd(gout, dev["pinv"], dev["ainv"], dev["cmat"], dev["erase"], B, S, cutn, P, std, pooled=pooled.to(cuda),
+                       coff=dev["coff"], cj=dev["cj"])
     ref_p.backward(gout.double().cpu())
     rel = ((dp.double().cpu() - pd.grad).abs().max() / pd.grad.abs().max()).item()
     assert rel < 2e-2, rel

@@ -315,7 +315,7 @@ def test_step_with_wider_augmentation_set_matches_oracle(cuda):
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
     assert stepper.make_cutouts.augs == tuple(augs)
     prm = A.draw_params(16, 32, augs=tuple(augs), generator=torch.Generator().manual_seed(8))
-    assert prm["coff"].abs().max() > 0 and prm["gn"].max() == 1 and (prm["erase"][:, 2] > prm["erase"][:, 0]).any()
+    assert prm["cj"][:, 0].max() == 1 and prm["gn"].max() == 1 and (prm["erase"][:, 2] > prm["erase"][:, 0]).any()
     msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(),
                                      aug_params={k: v.cuda() for k, v in prm.items()})
@@ -331,9 +331,9 @@ def test_step_with_wider_augmentation_set_matches_oracle(cuda):
     oloss.backward()
     assert abs(loss.item() - oloss.item()) / oloss.item() < 1e-4
     _check_grads(net, osd, tol=5e-3)
-    # unsupported names fail loudly at construction
+    # names outside main.py:166-198 fail loudly at construction
     with pytest.raises(NotImplementedError):
-        fmain.MakeCutouts(32, 4, augs=["Sh"])
+        fmain.MakeCutouts(32, 4, augs=["Xx"])
 
 
 # ----------------------------------------------------------------------------- dropout in the mappers
