@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--no-prefetch-text", dest="prefetch_text", action="store_false",
                     help="encode each step's prompts inside the step instead of one step ahead on a side stream")
     ap.add_argument("--no-side-stream", action="store_true", help="A/B: weight gradients on the main stream (no second HIP stream)")
+    ap.add_argument("--graph", action="store_true", help="replay the step behind the text tower as ONE captured hipGraph (TrainStep.enable_graph): "
+                    "for the launch-bound mappers (VitGAN / x-transformer: ~2400 launches per step); single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second timing in the other 16-bit format")
     ap.add_argument("--no-roofline", action="store_true")
@@ -329,6 +331,10 @@ def main():
     for _ in range(args.warmup):
         stepper(batches[it], next_inp=batches[it + 1] if args.prefetch_text else None)
         it += 1
+    if args.graph:
+        if args.warmup < 1:
+            raise SystemExit("--graph needs at least one eager warm-up step (scratch allocations happen there)")
+        stepper.enable_graph(B, batches[it])          # one more (eager) warm-up step on the capture stream, then the capture
     sync()
     clk0 = K.clock_sample()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU time (diagnostic only)
@@ -369,7 +375,7 @@ def main():
                                f" mapper + VQGAN f16-16384 decoder {16 * args.vq_image_size}x{16 * args.vq_image_size} + CLIP "
                                f"{args.clip_model}, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire, "hip_graph": bool(args.graph),
                    "dp": hvd.describe()},
         "final_loss": float(loss.item()),
         # average engine clock over the timed steps (s_memtime / s_memrealtime): the chip clocks to its power budget, so the
@@ -420,7 +426,7 @@ def main():
         try:
             import hashlib
             from feed_forward_vqgan_clip_amd import _lib as flib
-            pmc_name = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
+            pmc_name = next((n for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_pmc_traffic.json")
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             cls = name.rsplit("_", 1)[0]
             if cls in pmc:
@@ -437,6 +443,12 @@ def main():
                            "traffic_source": traffic_src, "traffic_stale": traffic_stale, "flop_per_launch": flops / n,
                            # the same fraction against the peak at the clock the chip actually held during the timed steps
                            "frac_at_effective_clock": flops / secs / 1e12 / (peak * sclk_mhz / 2400.0) if sclk_mhz > 0 else None}
+        # the five most expensive GEMM shapes of the step (what actually directs kernel work; the class above averages ~20 shapes)
+        out["roofline"]["shapes"] = [
+            {"class": k[0], "M": k[1], "N": k[2], "K": k[3], "batch": k[4], "split_k": k[5], "launches": v[0], "ms": round(v[1], 3),
+             "avg_launch_us": round(v[1] / v[0] * 1e3, 1), "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 1),
+             "frac": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12 / (157.3 if k[0].endswith("f32") else PEAK_BF16_TFLOPS), 4)}
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:5]]
         out["kernel_classes"] = {k: {"launches": v[0], "ms": v[2] * 1e3, "tflops": v[1] / max(v[2], 1e-12) / 1e12}
                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
         out["gemm_ms_per_step"] = sum(v[2] for v in agg.values()) * 1e3

@@ -171,7 +171,7 @@ _SIGNATURES = {
     "ffvc_spherical_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                     c_void_p]),
     "ffvc_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_float, c_float,
-                          c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+                          c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ffvc_clock_sample": (c_int, [c_void_p, c_void_p]),
     "ffvc_clip_coef": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "ffvc_dropout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_float, ctypes.c_uint32, c_void_p]),
@@ -189,6 +189,7 @@ _SIGNATURES = {
     "ffvc_tokmix_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "ffvc_tokmix_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_tokmix_bwd_hidden": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_tokmix_fwd_save": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_set_option": (c_int, [c_char_p, c_int]),
     "ffvc_last_error": (c_char_p, []),
     "ffvc_version": (c_int, []),

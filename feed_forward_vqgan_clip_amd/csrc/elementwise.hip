@@ -460,7 +460,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, ST* __restrict__ shadow,
                                                    int64_t n, float lr, float b1, float b2, float eps, float bc1,
                                                    float bc2_sqrt, float gscale, float* __restrict__ ema, float ema_w,
-                                                   const float* __restrict__ dev_scale, unsigned int* __restrict__ bad_count) {
+                                                   const float* __restrict__ dev_scale, unsigned int* __restrict__ bad_count,
+                                                   const float* __restrict__ dev_hyper) {
+  if (dev_hyper) {   // per-step scalars from device memory: a captured hipGraph replays this launch with fresh values
+    lr = dev_hyper[0];
+    bc1 = dev_hyper[1];
+    bc2_sqrt = dev_hyper[2];
+    gscale = dev_hyper[3];
+    ema_w = dev_hyper[4];
+  }
   if (dev_scale) gscale *= dev_scale[0];      // global-norm clip coefficient computed on the device (no host sync)
   // Non-finite gradients (an overflowing f16 backward, or inf x the clip coefficient 0 = NaN) must never reach p / m / v / ema:
   // such an element keeps its state (no update), and the launch counts the waves that saw one in bad_count, which the host
@@ -1121,7 +1129,8 @@ extern "C" int ffvc_spherical_loss(const float* embed, const float* feats, float
 
 extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n,
                          float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* ema,
-                         float ema_weight, const float* dev_scale, uint32_t* nonfinite_count, void* stream) {
+                         float ema_weight, const float* dev_scale, uint32_t* nonfinite_count, const float* dev_hyper,
+                         void* stream) {
   FFVC_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "ffvc_adam: bad args");
   FFVC_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0 && ((uintptr_t)shadow % 16) == 0 && ((uintptr_t)ema % 16) == 0,
@@ -1132,13 +1141,13 @@ extern "C" int ffvc_adam(float* p, const float* g, float* m, float* v, void* sha
   const int grid = ew_grid(n / 4 + 1, 256);
   if (shadow && shadow_dtype == FFVC_BF16)
     hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (uint16_t*)shadow, n, lr, beta1,
-                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count);
+                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count, dev_hyper);
   else if (shadow && shadow_dtype == FFVC_F16)
     hipLaunchKernelGGL((adam_kernel<f16_t>), dim3(grid), dim3(256), 0, st, p, g, m, v, (f16_t*)shadow, n, lr, beta1,
-                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count);
+                       beta2, eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count, dev_hyper);
   else
     hipLaunchKernelGGL((adam_kernel<float>), dim3(grid), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2,
-                       eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count);
+                       eps, bc1, bc2s, grad_scale, ema, ema_weight, dev_scale, nonfinite_count, dev_hyper);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -556,8 +556,9 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   // into the derivative so that the backward's plain multiply sees the same thing on every path
   const bool actgrad_fwd = (d.flags & FFVC_F_AUX_ACTGRAD) && (d.flags & FFVC_F_WRITE_PREACT) && !(d.flags & FFVC_F_MUL_ACT_GRAD);
   if (d.flags & FFVC_F_AUX_ACTGRAD) {
-    FFVC_CHECK_ARG(d.in_dtype != FFVC_F32 && d.aux && d.batch <= 1 && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU),
-                   "ffvc_gemm: FFVC_F_AUX_ACTGRAD needs a 16-bit dtype, aux, batch 1 and GELU / QuickGELU");
+    // (batch 1 only for the FORWARD form: its in-place conversion pass walks one [M, N] tensor; the backward multiply is batch-agnostic)
+    FFVC_CHECK_ARG(d.in_dtype != FFVC_F32 && d.aux && (d.batch <= 1 || !actgrad_fwd) && (d.act == FFVC_ACT_GELU || d.act == FFVC_ACT_QUICKGELU),
+                   "ffvc_gemm: FFVC_F_AUX_ACTGRAD needs a 16-bit dtype, aux, GELU / QuickGELU (and batch 1 in the forward form)");
   }
   auto fixup = [&]() -> int {
     if (!actgrad_fwd) return 0;

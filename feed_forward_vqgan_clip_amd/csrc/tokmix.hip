@@ -114,25 +114,37 @@ __device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
   b = r[1];
 }
 
-template <typename L, int T_>
+// SAVE (round 4): the forward also writes the hidden activation h = gelu(pre) and the derivative act'(pre) as [B][O][D] 16-bit
+// tensors (hout / gout), staged through LDS into whole 512-byte rows exactly like tokmix_bwd_hidden_kernel's output.  The
+// backward pass then needs no recomputation: dh = (W2^T dy) * act' is a plain batched GEMM with the aux-multiply epilogue and
+// the weight gradients read the saved h (the recomputing kernel spends its time in erf / pdf arithmetic: 242 us per layer against
+// ~90 for the GEMM).  LDS: 3-stage ring (96 KiB) + two 32-KiB staging buffers; the biases come through scalar loads.
+template <typename L, int T_, bool SAVE = false>
 __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ w1,
                                                             const float* __restrict__ b1, const uint16_t* __restrict__ w2,
                                                             const float* __restrict__ b2, const float* __restrict__ res,
-                                                            float* __restrict__ y, int D, int O, const uint16_t* zero) {
+                                                            float* __restrict__ y, int D, int O, const uint16_t* zero,
+                                                            uint16_t* __restrict__ hout = nullptr,
+                                                            uint16_t* __restrict__ gout = nullptr) {
   constexpr int NK1 = T_ / 16;                 // k-steps of GEMM-1
   constexpr int NTB = T_ / 32;                 // 32-row output blocks of GEMM-2
   constexpr int HALF = 64 * T_;                // bytes of one [32][T] / [T][32] chunk image
   constexpr int STAGE = 2 * HALF;
   constexpr int PPC = 2 * ChunkDma<T_>::NP;    // DMA pieces per thread per chunk
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // ring (>= xn staging) | b1 (O floats)
-  constexpr int RING = (TM_NST * STAGE > (T_ / 64) * 32768) ? TM_NST * STAGE : (T_ / 64) * 32768;
+  constexpr int NST = SAVE ? 3 : TM_NST;       // ring depth
+  constexpr int OUTB = 2 * TM_OC * TM_DT * 2;  // SAVE: h and act' tiles of one chunk: 2 x [32][256] 16-bit = 32 KiB
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // ring (>= xn staging) | b1 (O floats)  /  SAVE: ring | outb[2]
+  constexpr int RING = SAVE ? NST * STAGE : ((NST * STAGE > (T_ / 64) * 32768) ? NST * STAGE : (T_ / 64) * 32768);
   float* b1s = (float*)(smem + RING);
+  unsigned char* outb = smem + RING;           // SAVE only (the prologue's fragment staging may run into it: barrier below)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.y, d0 = blockIdx.x * TM_DT;
   const int64_t act0 = (int64_t)b * T_ * D;
+  const int64_t out0 = (int64_t)b * O * D;
 
-  for (int i = tid; i < O; i += 512) b1s[i] = b1[i];
+  if constexpr (!SAVE)
+    for (int i = tid; i < O; i += 512) b1s[i] = b1[i];
   u32x4_t xf[NK1];
   load_bfrags<L, T_>(xf, smem, xn + act0, D, d0, zero, tid);
 
@@ -141,12 +153,12 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
   const rsrc_t rs1 = make_rsrc(w1), rs2 = make_rsrc(w2);
   const int NC = O / TM_OC;
   auto issue = [&](int c) {
-    unsigned char* st = smem + (c % TM_NST) * STAGE;
+    unsigned char* st = smem + (c % NST) * STAGE;
     dm.issueA(st, rs1, (uint32_t)c * (TM_OC * T_ * 2));
     dm.issueB(st + HALF, rs2, (uint32_t)c * (TM_OC * 2));
   };
 #pragma unroll
-  for (int c = 0; c < TM_NST - 1; ++c)
+  for (int c = 0; c < NST - 1; ++c)
     if (c < NC) issue(c);
 
   f32x16_t acc2[NTB];
@@ -155,17 +167,48 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[t][i] = 0.0f;
 
+  auto flush = [&](int c) {        // SAVE: coalesced store of chunk c's staged tiles: 64 rows of 512 B, 16 B per lane
+    const unsigned char* ob = outb + (c & 1) * OUTB;
+    const int d = d0 + 8 * (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + 2 * wid + (lane >> 5);            // 0..31: h rows, 32..63: act' rows
+      const u32x4_t v = *(const u32x4_t*)(ob + row * 512 + (lane & 31) * 16);
+      uint16_t* dst = (row < 32 ? hout : gout) + out0 + (int64_t)(c * TM_OC + (row & 31)) * D + d;
+      if (d < D) *(u32x4_t*)dst = v;
+    }
+  };
+
   for (int c = 0; c < NC; ++c) {
-    // chunk c has landed when at most the pieces of the (up to two) later chunks are still in flight
-    if (c + 2 < NC)
-      wait_vm<2 * PPC>();
-    else if (c + 1 < NC)
-      wait_vm<PPC>();
-    else
-      wait_vm<0>();
+    if constexpr (SAVE) {
+      // vmcnt retires in issue order and counts the flush stores: behind chunk c's pieces were issued the flush of iteration
+      // c-3's tiles (4 stores, in iteration c-2), chunk c+1 (PPC pieces), the flush in iteration c-1 (4 stores).  Lanes beyond D
+      // skip their stores, so the counts below are upper bounds of what may stay in flight only when every lane stores: keep to
+      // the conservative side (fewer allowed outstanding) when D is ragged — D % 256 == 0 in every shipped shape
+      const bool more = c + 1 < NC;
+      if (D % TM_DT) {
+        wait_vm<0>();
+      } else if (c >= 3) {
+        if (more) wait_vm<PPC + 8>(); else wait_vm<8>();
+      } else if (c == 2) {
+        if (more) wait_vm<PPC + 4>(); else wait_vm<4>();
+      } else {
+        if (more) wait_vm<PPC>(); else wait_vm<0>();
+      }
+    } else {
+      // chunk c has landed when at most the pieces of the (up to two) later chunks are still in flight
+      if (c + 2 < NC)
+        wait_vm<2 * PPC>();
+      else if (c + 1 < NC)
+        wait_vm<PPC>();
+      else
+        wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();
-    if (c + TM_NST - 1 < NC) issue(c + TM_NST - 1);      // into the stage everyone finished reading before this barrier
-    const unsigned char* s1 = smem + (c % TM_NST) * STAGE;
+    if (c + NST - 1 < NC) issue(c + NST - 1);      // into the stage everyone finished reading before this barrier
+    if constexpr (SAVE)
+      if (c > 0) flush(c - 1);                     // staged by everyone before this barrier
+    const unsigned char* s1 = smem + (c % NST) * STAGE;
     const unsigned char* s2 = s1 + HALF;
     f32x16_t a1;
 #pragma unroll
@@ -174,6 +217,37 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
     for (int s = 0; s < NK1; ++s) mma_lo<L>(a1, fragA<T_>(s1, l31, s, hh), xf[s]);
     // bias + exact-erf GELU in registers; register r of the block is hidden row 8 (r / 4) + 4 hh + r % 4
     uint32_t P[4][2];
+    if constexpr (SAVE) {
+      // the chunk's 32 biases through scalar loads (wave-uniform address; a vector load would drain the LDS-DMA ring)
+      const const_f32p bc = (const_f32p)(b1 + __builtin_amdgcn_readfirstlane(c) * TM_OC);
+      unsigned char* ob = outb + (c & 1) * OUTB;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int r = 4 * m + 2 * q;
+          f32x2_t pre, cdf, e;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ru = r + u;
+            const float blo = bc[8 * (ru >> 2) + (ru & 3)], bhi = bc[8 * (ru >> 2) + 4 + (ru & 3)];
+            pre[u] = a1[ru] + (hh ? bhi : blo);
+          }
+          gelu_parts_fast2(pre, cdf, e);
+          const f32x2_t hv = pre * cdf;
+          const f32x2_t gv = cdf + pre * 0.39894228040143267794f * e;
+          P[m][q] = lo_pack2<L>(hv[0], hv[1]);
+          const uint32_t gp = lo_pack2<L>(gv[0], gv[1]);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ru = r + u;
+            const int ol = 8 * (ru >> 2) + 4 * hh + (ru & 3);
+            *(uint16_t*)(ob + ol * 512 + (32 * wid + l31) * 2) = (uint16_t)(u ? (P[m][q] >> 16) : (P[m][q] & 0xffffu));
+            *(uint16_t*)(ob + (32 + ol) * 512 + (32 * wid + l31) * 2) = (uint16_t)(u ? (gp >> 16) : (gp & 0xffffu));
+          }
+        }
+      }
+    } else {
     const float* bc = b1s + c * TM_OC + 4 * hh;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -183,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
         const f32x2_t g = act_gelu_fast2(f32x2_t{a1[4 * m + 2 * q] + bb[2 * q], a1[4 * m + 2 * q + 1] + bb[2 * q + 1]});
         P[m][q] = lo_pack2<L>(g[0], g[1]);
       }
+    }
     }
     // make each lane's 8 rows per k-step consecutive: half 0 keeps rows 0-3 and receives 4-7, half 1 gets 8-11 and keeps 12-15
 #pragma unroll
@@ -198,6 +273,10 @@ __global__ __launch_bounds__(512, 2) void tokmix_fwd_kernel(const uint16_t* __re
     }
   }
 
+  if constexpr (SAVE) {
+    __syncthreads();
+    flush(NC - 1);
+  }
   // epilogue: [T/2 rows][256 cols] fp32 through LDS per half, then whole 1 KiB rows: y = acc + b2[t] + res
   constexpr int RH = T_ / 2;
 #pragma unroll
@@ -461,6 +540,25 @@ const uint16_t* tm_zero_page() {
 }
 
 template <typename L, int T_>
+int launch_fwd_save(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* res, float* y,
+                    void* h, void* g, int B, int D, int O, hipStream_t st, const uint16_t* zero) {
+  constexpr int lds_main = 3 * 128 * T_ + 2 * (2 * TM_OC * TM_DT * 2);
+  constexpr int lds_stage = (T_ / 64) * 32768;
+  constexpr int lds_epi = (T_ / 2) * 1024;
+  constexpr int lds = (lds_main > lds_stage ? lds_main : lds_stage) > lds_epi ? (lds_main > lds_stage ? lds_main : lds_stage) : lds_epi;
+  static_assert(lds <= 163840, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)tokmix_fwd_kernel<L, T_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    attr = true;
+  }
+  hipLaunchKernelGGL((tokmix_fwd_kernel<L, T_, true>), dim3(ceil_div(D, TM_DT), B), dim3(512), lds, st, (const uint16_t*)xn,
+                     (const uint16_t*)w1, b1, (const uint16_t*)w2, b2, res, y, D, O, zero, (uint16_t*)h, (uint16_t*)g);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename L, int T_>
 int launch_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* res, float* y,
                int B, int D, int O, hipStream_t st, const uint16_t* zero) {
   constexpr int STAGE = 128 * T_;
@@ -525,6 +623,24 @@ extern "C" int ffvc_tokmix_fwd(const void* xn, const void* w1, const float* b1, 
                     : launch_fwd<f16_t, 128>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero);
   return T == 256 ? launch_fwd<uint16_t, 256>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero)
                   : launch_fwd<uint16_t, 128>(xn, w1, b1, w2, b2, residual, y, B, D, O, st, zero);
+}
+
+extern "C" int ffvc_tokmix_fwd_save(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2,
+                                    const float* residual, float* y, void* h, void* gact, int dtype, int B, int T, int D, int O,
+                                    void* stream) {
+  FFVC_CHECK_ARG(xn && w1 && b1 && w2 && b2 && residual && y && h && gact, "ffvc_tokmix_fwd_save: null pointer");
+  if (int e = tm_check("ffvc_tokmix_fwd_save", dtype, B, T, D, O)) return e;
+  FFVC_CHECK_ARG(((uintptr_t)xn % 16) == 0 && ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                     ((uintptr_t)y % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)gact % 16) == 0,
+                 "ffvc_tokmix_fwd_save: pointers must be 16-byte aligned");
+  const uint16_t* zero = tm_zero_page();
+  FFVC_CHECK_ARG(zero != nullptr, "ffvc_tokmix_fwd_save: zero page allocation failed");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FFVC_F16)
+    return T == 256 ? launch_fwd_save<f16_t, 256>(xn, w1, b1, w2, b2, residual, y, h, gact, B, D, O, st, zero)
+                    : launch_fwd_save<f16_t, 128>(xn, w1, b1, w2, b2, residual, y, h, gact, B, D, O, st, zero);
+  return T == 256 ? launch_fwd_save<uint16_t, 256>(xn, w1, b1, w2, b2, residual, y, h, gact, B, D, O, st, zero)
+                  : launch_fwd_save<uint16_t, 128>(xn, w1, b1, w2, b2, residual, y, h, gact, B, D, O, st, zero);
 }
 
 extern "C" int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t,

@@ -671,18 +671,18 @@ def spherical_loss(embed, feats, coef=1.0, want_grad=True):
 
 
 def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0, ema=None, ema_weight=0.0, dev_scale=None,
-         bad_count=None):
+         bad_count=None, dev_hyper=None):
     """ema (fp32, same layout as p): torch_ema update folded into the pass, ema -= ema_weight * (ema - p_new).
     dev_scale (fp32 device scalar): multiplied into grad_scale on the device (clip_grad_norm_ coefficient).
     bad_count (int32 device scalar): elements with a non-finite scaled gradient are skipped and counted (per wavefront)."""
-    _req_f32(p, g, m, v, ema, dev_scale)
+    _req_f32(p, g, m, v, ema, dev_scale, dev_hyper)
     _need_cuda(shadow, bad_count)
     if bad_count is not None and bad_count.dtype != torch.int32:
         raise TypeError("adam: bad_count must be an int32 device scalar")
     with _hbm("adam", p.numel() * (28 + (shadow.element_size() if shadow is not None else 0) + (8 if ema is not None else 0))):
         _call("ffvc_adam", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow),
               dtype_code(shadow.dtype) if shadow is not None else F32, p.numel(), lr, beta1, beta2, eps, step, grad_scale,
-              _ptr(ema), float(ema_weight), _ptr(dev_scale), _ptr(bad_count), stream_ptr())
+              _ptr(ema), float(ema_weight), _ptr(dev_scale), _ptr(bad_count), _ptr(dev_hyper), stream_ptr())
 
 
 def clip_coef(sumsq_buf, max_norm, grad_scale):
@@ -975,6 +975,22 @@ def tokmix_fwd(xn, w1, b1, w2, b2, residual):
     _call("ffvc_tokmix_fwd", xn.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), residual.data_ptr(),
           y.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
     return y
+
+
+def tokmix_fwd_save(xn, w1, b1, w2, b2, residual):
+    """tokmix_fwd that also returns h = gelu(W1 xn + b1) and gact = gelu'(W1 xn + b1), (B,O,D) in xn's dtype: -> (y, h, gact)."""
+    _req(xn.dtype, xn, w1, w2)
+    _req_f32(b1, b2, residual)
+    B, T, D = xn.shape
+    O = w1.shape[0]
+    if tuple(w1.shape) != (O, T) or tuple(w2.shape) != (T, O) or tuple(residual.shape) != (B, T, D):
+        raise ValueError("tokmix_fwd_save: shape mismatch")
+    y = torch.empty(B, T, D, dtype=torch.float32, device=xn.device)
+    h = torch.empty(B, O, D, dtype=xn.dtype, device=xn.device)
+    g = torch.empty_like(h)
+    _call("ffvc_tokmix_fwd_save", xn.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), residual.data_ptr(),
+          y.data_ptr(), h.data_ptr(), g.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
+    return y, h, g
 
 
 def tokmix_bwd_hidden(xn, dy, w1, b1, w2t, db1=None):

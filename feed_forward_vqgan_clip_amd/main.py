@@ -479,10 +479,15 @@ class TrainStep:
         """main.py:729-811 -> (loss, intermediates).  facs / noise / aug_params / noise_vec_in pin the step's random
         draws (cutout noise, augmentation parameters, the mapper's conditioning noise) for parity tests."""
         inp_feats = self.features(inp)                                          # :733
+        return self._loss_from_feats(inp_feats, None if (out is None or out is inp) else self.features(out), facs, noise, aug_params,
+                                     noise_vec_in, force_idx)
+
+    def _loss_from_feats(self, inp_feats, out_feats_in=None, facs=None, noise=None, aug_params=None, noise_vec_in=None, force_idx=None):
+        """forward_loss behind the text tower: everything from the prompt features on (the part a captured step replays)."""
+        raw = inp_feats
         if self.normalize_input:
             inp_feats = torch.nn.functional.normalize(inp_feats, dim=1)         # :734-735
-        out_feats = inp_feats if (out is None or out is inp) and not self.normalize_input else \
-            self.features(inp if out is None else out)                          # :737 (identical work skipped)
+        out_feats = raw if out_feats_in is None else out_feats_in               # :737 (out is inp: the same encoding, not repeated)
         bs = len(inp_feats)
         if self.repeat != 1:
             inp_feats = inp_feats.repeat(self.repeat, 1)                        # :739-740
@@ -520,7 +525,92 @@ class TrainStep:
         return loss, {"z": z, "xr": xr, "embed": embed, "indices": idx, "text_feats": inp_feats, "dists": dists,
                       "l2": l2, "tv": tv, "noise_vec": noise_vec}
 
+    # ---- captured step (hipGraph) --------------------------------------------------------------------------------------------
+    # The mappers with thousands of small launches per step (VitGAN, x-transformer: ~2400) are bound by the host's enqueue rate
+    # (35 ms of Python / ctypes per step against ~45 ms of kernels).  enable_graph() records everything behind the text tower —
+    # mapper, VQ, decoder, cutouts, image tower, loss, backward, weight-gradient side stream, Adam — ONCE into a hipGraph
+    # (torch.cuda.CUDAGraph: capture on a fresh stream, allocations from the graph's private pool, no synchronisation or
+    # hipMalloc inside: the library's own scratch buffers exist after the eager warm-up steps) and replays it per step.  What
+    # changes from step to step enters through device memory: the prompt features (static buffer, filled by the eager text
+    # tower / prefetch), the augmentation parameters (drawn on the host as before, copied into static device tensors), the
+    # cutout noise (torch's graph-safe Philox state), the optimizer's scalars (FusedAdam.graph_pre_step).
+    def enable_graph(self, batch_size, warmup_tokens=None):
+        """Capture the step for `batch_size` prompts per call.  Needs dropout 0, no noise bank draw on the host (nb_noise), a
+        single process (the gradient exchange stays eager) and at least one eager step before (scratch allocations)."""
+        if hvd.is_distributed():
+            raise RuntimeError("enable_graph: the captured step is single-GPU (the RCCL exchange is not captured)")
+        if float(self.config.get("dropout", 0) or 0) > 0:
+            raise RuntimeError("enable_graph: dropout seeds are host-side kernel arguments; dropout must be 0")
+        if self.noise_dim and self.nb_noise:
+            raise RuntimeError("enable_graph: the noise-bank draw (torch.randperm on the host) is not capturable")
+        dev = next(self.net.parameters()).device
+        B = int(batch_size)
+        n = self.cutn * B * self.repeat
+        self._g_B = B
+        self._g_feats = torch.zeros(B, self.clip_dim, dtype=torch.float32, device=dev)
+        H = 16 * int(self.config.vq_image_size)
+        prm = self.make_cutouts.draw_aug_params(n, dev, H)
+        self._g_aug = prm                                            # static device tensors (dict or list of segments)
+        self.opt.enable_graph_hyper()
+        # One EAGER pass on the stream the capture will use: the library keeps per-stream scratch (in-kernel split-K partial tiles)
+        # that is hipMalloc'ed on a stream's first use — inside a capture that would invalidate it — and torch's allocator
+        # warms the pool.  It is a genuine training step on `warmup_tokens`.
+        if warmup_tokens is None:
+            raise RuntimeError("enable_graph: pass one token batch for the eager warm-up step on the capture stream")
+        self._g_stream = torch.cuda.Stream()
+        self._g_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._g_stream):
+            self._g_feats.copy_(self.features(warmup_tokens))
+            self._graph_body()
+        torch.cuda.current_stream().wait_stream(self._g_stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self.opt._capturing = True
+        try:
+            with torch.cuda.graph(g, stream=self._g_stream):
+                self._g_out = self._graph_body()
+        finally:
+            self.opt._capturing = False
+        self._graph = g
+
+    def _graph_body(self):
+        loss, mid = self._loss_from_feats(self._g_feats, aug_params=self._g_aug)
+        self.opt.zero_grad()
+        ls = getattr(self.opt, "loss_scale", 1.0)
+        self._g_ls = ls
+        (loss if ls == 1.0 else loss * ls).backward()
+        if self.clip_grad_norm:
+            self.opt.clip_grad_norm_(self.clip_grad_norm)
+        self.opt.step()
+        return loss.detach(), mid
+
+    def _refresh_static_aug(self, n, H):
+        """Fresh augmentation draws into the static device tensors the captured kernels read."""
+        new = self.make_cutouts.draw_aug_params(n, "cpu", H)
+        pairs = [(self._g_aug, new)] if isinstance(new, dict) else [(a[1], b[1]) for a, b in zip(self._g_aug, new)]
+        for dst, src in pairs:
+            for k, v in src.items():
+                if torch.is_tensor(v):
+                    dst[k].copy_(v.pin_memory(), non_blocking=True)
+
+    def _graph_step(self, inp, next_inp):
+        feats = self.features(inp)
+        self._g_feats.copy_(feats, non_blocking=True)
+        self.prefetch(next_inp)
+        self._refresh_static_aug(self.cutn * self._g_B * self.repeat, 16 * int(self.config.vq_image_size))
+        if getattr(self.opt, "loss_scale", 1.0) != self._g_ls:       # the loss scale is baked into the recorded backward
+            self._graph = None
+            self.enable_graph(self._g_B, inp)
+        self.opt.graph_pre_step()
+        self._graph.replay()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return self._g_out
+
     def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None, next_inp=None, noise_vec_in=None):
+        if (getattr(self, "_graph", None) is not None and out is None and facs is None and noise is None and aug_params is None and
+                noise_vec_in is None and len(inp) == self._g_B):
+            return self._graph_step(inp, next_inp)
         loss, mid = self.forward_loss(inp, out, facs, noise, aug_params, noise_vec_in)
         self.prefetch(next_inp)                                                 # next batch's text tower under this backward
         self.opt.zero_grad()                                                    # :825

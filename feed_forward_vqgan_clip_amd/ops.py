@@ -415,6 +415,13 @@ class _TokenMLPFn(Function):
         ctx.fused = (not ctx.drop and residual is not None and residual.dtype == torch.float32 and
                      (out_dtype or cdt) == torch.float32 and W1.bias is not None and W2.bias is not None and
                      K.tokmix_supported(cdt, T, D, O))
+        ctx.saved_hidden = False
+        if ctx.fused and _TM_SAVE and any(ctx.needs_input_grad):
+            # one launch that also writes h and act'(pre): the backward is a plain aux-multiply GEMM, no recomputation
+            y, h, gact = K.tokmix_fwd_save(xn, W1.sh, W1.bias, W2.sh, W2.bias, _contig(residual))
+            ctx.saved_hidden = True
+            ctx.save_for_backward(xn if ctx.train else None, gact, h if ctx.train else None)
+            return y
         if ctx.fused:
             # one launch, the hidden activation stays on chip; backward recomputes it (nothing saved but xn)
             ctx.save_for_backward(xn, None, None)
@@ -447,8 +454,14 @@ class _TokenMLPFn(Function):
         dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         # db1 inside the fused kernel is available (FFVC_TOKMIX_DB1=1) but measured +1.1..2 ms/step (atomics in its chunk
         # loop, profiles/r02_bias_grad_fusion_ab.txt): the rowsum launch on the side stream stays the default
-        b1_fused = ctx.fused and ctx.train and W1.bias.requires_grad and os.environ.get("FFVC_TOKMIX_DB1", "0") != "0"
-        if ctx.fused:
+        b1_fused = (ctx.fused and not ctx.saved_hidden and ctx.train and W1.bias.requires_grad and
+                    os.environ.get("FFVC_TOKMIX_DB1", "0") != "0")
+        if ctx.saved_hidden:
+            # dh[b] = (W2^T @ dy[b]) * act'(pre[b]), act' saved by the forward
+            dh = torch.empty_like(h_pre)
+            K.gemm(W2.sht, dyt, dh, O, D, T, ldx=T, ldw=D, w_mode=K.OP_TRANS, aux=h_pre, ldaux=D, act=ACT_GELU,
+                   flags=K.F_MUL_ACT_GRAD | K.F_AUX_ACTGRAD, batch=B, wb=(T * D, 0), yb=(O * D, 0), ab=(O * D, 0))
+        elif ctx.fused:
             h, dh = K.tokmix_bwd_hidden(xn, dyt, W1.sh, W1.bias, W2.sht, db1=_grad_buf(W1.bias) if b1_fused else None)
         else:
             # dh_pre[b] = (W2^T @ dy[b]) * gelu'(h_pre[b])
@@ -761,6 +774,10 @@ def clamp_with_grad(x, lo, hi, mul=1.0, add=0.0, out_dtype=None):
     return _ClampFn.apply(x, float(mul), float(add), float(lo), float(hi), out_dtype)
 
 
+# A/B: the fused token-mix forward saves h / act' so that the backward needs no recomputation.  Measured (profiles/r04_experiments.txt):
+# 228 + 110 us per layer against 121 + 134 for the recomputing pair (the backward kernel's 242 us inside the step is the weight-
+# gradient stream sharing the CUs, not its own cost), step +3 ms -> off
+_TM_SAVE = os.environ.get("FFVC_TOKMIX_SAVE", "0") != "0"
 _VQ_SPLIT = os.environ.get("FFVC_VQ_SPLIT", "1") != "0"   # A/B: 16-bit modes take the z . codebook^T products through split-precision f16
 
 

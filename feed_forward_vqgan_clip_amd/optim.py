@@ -34,6 +34,10 @@ class FusedAdam(torch.optim.Optimizer):
         # overflow guard of the loss-scaled f16 backward: the Adam kernel skips (and counts) non-finite gradient elements, the
         # host reads the counter at its logging synchronisations (check_overflow) and backs the scale off / regrows it
         self._bad = torch.zeros(1, dtype=torch.int32, device=a.params.device)
+        # captured-step mode (main.TrainStep.enable_graph): the per-step scalars of the update live in device memory — a pinned
+        # host mirror is refreshed and copied over before every replay (graph_pre_step) — and the host bookkeeping of step()
+        # is done there instead of inside the (recorded, not executed) capture call
+        self._hyper, self._capturing = None, False
         self._good_steps = 0
         self.scale_growth_interval, self.scale_max, self.scale_min = 2000, 65536.0, 1.0
         for p in a.plist:
@@ -91,21 +95,46 @@ class FusedAdam(torch.optim.Optimizer):
         a = self.arena
         g = self.param_groups[0]
         ops.join_side_stream()          # weight gradients are produced on the side stream
-        self._step += 1
         clip, self._clip = self._clip, None
+        ema_w = 0.0
+        if not self._capturing:
+            ema_w = self._host_tick()
+        shadow = None if a.cdt == torch.float32 else a.shadow
+        for s, e in (ranges if ranges is not None else ((0, a.total),)):
+            K.adam(a.params[s:e], a.grads[s:e], self._m[s:e], self._v[s:e], None if shadow is None else shadow[s:e], g["lr"],
+                   g["betas"][0], g["betas"][1], g["eps"], max(self._step, 1), self._eff_scale(),
+                   ema=None if self._ema is None else self._ema[s:e], ema_weight=ema_w,
+                   dev_scale=None if clip is None else clip[0:1], bad_count=self._bad,
+                   dev_hyper=self._hyper[1] if (self._capturing and self._hyper is not None) else None)
+        a.refresh(cast=False)
+
+    def _host_tick(self):
+        """Host bookkeeping of one update: step counter, EMA schedule, torch-layout `step` entries.  -> this step's ema weight."""
+        self._step += 1
         ema_w = 0.0
         if self._ema is not None:       # torch_ema: decay = min(decay, (1 + n) / (10 + n)) with n counted from 1
             self._ema_updates += 1
             ema_w = 1.0 - min(self._ema_decay, (1 + self._ema_updates) / (10 + self._ema_updates))
-        shadow = None if a.cdt == torch.float32 else a.shadow
-        for s, e in (ranges if ranges is not None else ((0, a.total),)):
-            K.adam(a.params[s:e], a.grads[s:e], self._m[s:e], self._v[s:e], None if shadow is None else shadow[s:e], g["lr"],
-                   g["betas"][0], g["betas"][1], g["eps"], self._step, self._eff_scale(),
-                   ema=None if self._ema is None else self._ema[s:e], ema_weight=ema_w,
-                   dev_scale=None if clip is None else clip[0:1], bad_count=self._bad)
-        a.refresh(cast=False)
+        st_step = torch.tensor(float(self._step))
         for st in self.state.values():
-            st["step"] = torch.tensor(float(self._step))
+            st["step"] = st_step
+        return ema_w
+
+    def enable_graph_hyper(self):
+        """Allocate the device-resident scalars a captured update reads (see __init__)."""
+        if self._hyper is None:
+            self._hyper = (None, torch.zeros(5, dtype=torch.float32, device=self.arena.params.device))
+
+    def graph_pre_step(self):
+        """Before a replay of the captured step: do the update's host bookkeeping and send its scalars (lr after the scheduler,
+        bias corrections of the new step count, gradient scale, EMA weight) to the device, in stream order."""
+        ema_w = self._host_tick()
+        g = self.param_groups[0]
+        # a FRESH pinned block per step (caching host allocator): the host runs many steps ahead of the device in this mode, a
+        # reused staging buffer would be overwritten before its copy has executed
+        host = torch.tensor([g["lr"], 1.0 - g["betas"][0] ** self._step, math.sqrt(1.0 - g["betas"][1] ** self._step),
+                             self._eff_scale(), ema_w], dtype=torch.float32).pin_memory()
+        self._hyper[1].copy_(host, non_blocking=True)
 
     def check_overflow(self):
         """Dynamic loss scaling without a per-step host synchronisation.  Call where the host synchronises anyway (logging):

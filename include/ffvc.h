@@ -380,7 +380,10 @@ int ffvc_spherical_loss(const float* embed, const float* feats, float* rowloss, 
  * ema -= ema_weight * (ema - p_new), ema_weight = 1 - min(decay, (1 + n_updates) / (10 + n_updates)). */
 int ffvc_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, int64_t n, float lr,
               float beta1, float beta2, float eps, int step, float grad_scale, float* ema, float ema_weight,
-              const float* dev_scale, uint32_t* nonfinite_count, void* stream);
+              const float* dev_scale, uint32_t* nonfinite_count,
+              const float* dev_hyper /* may be NULL; else fp32 [5] on the device = {lr, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale,
+                                        ema_weight}, read INSTEAD of the by-value arguments: the launch can sit in a captured hipGraph */,
+              void* stream);
 /* dev_scale (may be NULL): grad_scale *= dev_scale[0].  nonfinite_count (may be NULL): an element whose scaled gradient is inf /
  * NaN (overflow of a loss-scaled f16 backward) keeps p, m, v, ema unchanged, and the counter is incremented once per wavefront
  * that met one — the host polls it to back the loss scale off; nothing non-finite ever enters the optimizer state. */
@@ -427,6 +430,11 @@ int ffvc_axpby(const float* x, float* y, int64_t n, float a, float b, void* stre
 int ffvc_tokmix_supported(int dtype, int T, int D, int O);
 int ffvc_tokmix_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* residual,
                     float* y, int dtype, int B, int T, int D, int O, void* stream);
+/* ffvc_tokmix_fwd that also writes h = gelu(W1 xn + b1) and gact = gelu'(W1 xn + b1) as [B][O][D] tensors of xn's dtype: the backward
+ * pass then takes dh = (W2^T dy) * gact from a plain batched ffvc_gemm (FFVC_F_MUL_ACT_GRAD | FFVC_F_AUX_ACTGRAD) instead of
+ * ffvc_tokmix_bwd_hidden's recomputation. */
+int ffvc_tokmix_fwd_save(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const float* residual,
+                         float* y, void* h, void* gact, int dtype, int B, int T, int D, int O, void* stream);
 int ffvc_tokmix_bwd_hidden(const void* xn, const void* dy, const void* w1, const float* b1, const void* w2t, void* h,
                            void* dh, float* db1, int dtype, int B, int T, int D, int O, void* stream);
 

@@ -421,16 +421,23 @@ def test_tokmix_fused_kernels_vs_fp64(cuda, dt, B, T, D, O):
     F.gelu(p).sum().backward()
     dref = (w2.double().t() @ dy.double()) * p.grad
     assert _rel(hk, h) < tol and _rel(dhk, dref) < tol
+    # the forward that saves h and act'(pre) for the backward: same y and h to the bit, act' vs autograd's derivative
+    ys, hs, gs = K.tokmix_fwd_save(xn, w1, b1, w2, b2, res)
+    assert torch.equal(ys, y) and torch.equal(hs, hk)
+    assert _rel(gs, p.grad) < tol
+    assert torch.equal(K.tokmix_fwd_save(xn, w1, b1, w2, b2, res)[2], gs)     # staging race check: reproducible
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_tokmix_fused_autograd_matches_unfused(cuda, dt):
+@pytest.mark.parametrize("save", ["1", "0"])
+def test_tokmix_fused_autograd_matches_unfused(cuda, dt, save, monkeypatch):
     """ops.token_mlp with the fused kernels (forward recompute in backward) vs the two-GEMM path: output, dx and every
     parameter gradient."""
     import os
     from feed_forward_vqgan_clip_amd import ops
     from feed_forward_vqgan_clip_amd.mappers import Mixer
     torch.manual_seed(3)
+    monkeypatch.setattr(ops, "_TM_SAVE", save == "1")      # fused forward with saved h / act' | recompute in the backward
     outs = {}
     for mode in ("1", "0"):
         os.environ["FFVC_TOKMIX"] = mode

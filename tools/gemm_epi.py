@@ -11,7 +11,7 @@ from feed_forward_vqgan_clip_amd import kernels as K  # noqa: E402
 from tools.gemm_bench import timeit  # noqa: E402
 
 dev = torch.device("cuda:0")
-dt = torch.bfloat16
+dt = torch.float16
 
 
 def r(*s):
