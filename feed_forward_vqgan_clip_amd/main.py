@@ -445,6 +445,7 @@ class TrainStep:
         self.normalize_input = config.get("normalize_input", False)
         self.l2_coef, self.tv_coef = config.get("l2_coef", 0.0), config.get("tv_coef", 0.0)
         self._prefetched, self._text_stream = None, None
+        self._graph = None                                                      # captured step (enable_graph)
 
     def features(self, t):
         if t.dtype != torch.long:
@@ -587,6 +588,8 @@ class TrainStep:
     def _refresh_static_aug(self, n, H):
         """Fresh augmentation draws into the static device tensors the captured kernels read."""
         new = self.make_cutouts.draw_aug_params(n, "cpu", H)
+        if new is None:                                              # configurations without a resampling chain
+            return
         pairs = [(self._g_aug, new)] if isinstance(new, dict) else [(a[1], b[1]) for a, b in zip(self._g_aug, new)]
         for dst, src in pairs:
             for k, v in src.items():
@@ -608,7 +611,7 @@ class TrainStep:
         return self._g_out
 
     def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None, next_inp=None, noise_vec_in=None):
-        if (getattr(self, "_graph", None) is not None and out is None and facs is None and noise is None and aug_params is None and
+        if (self._graph is not None and out is None and facs is None and noise is None and aug_params is None and
                 noise_vec_in is None and len(inp) == self._g_B):
             return self._graph_step(inp, next_inp)
         loss, mid = self.forward_loss(inp, out, facs, noise, aug_params, noise_vec_in)

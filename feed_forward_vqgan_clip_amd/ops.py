@@ -68,7 +68,7 @@ class Weights:
 # wgrad GEMMs and bias-gradient reductions are NOT on the backward critical path: their results are consumed only by
 # the gradient all-reduce / the optimizer.  They are enqueued on a second HIP stream (fenced by events) so that they
 # execute concurrently with the dgrad chain of the following layers and fill MFMA / HBM bubbles of the main stream.
-_SIDE = {"enabled": True, "stream": None, "dirty": False, "cb": False}
+_SIDE = {"enabled": True, "stream": None, "dirty": False, "cb": False, "main": None}
 
 
 def set_wgrad_side_stream(enabled):
@@ -91,7 +91,8 @@ class _on_side:
         if not _SIDE["enabled"]:
             return self
         side = _side_stream()
-        side.wait_stream(torch.cuda.current_stream())
+        _SIDE["main"] = torch.cuda.current_stream()   # the stream this backward pass runs on (autograd restores the forward's stream per node)
+        side.wait_stream(_SIDE["main"])
         for t in self.tensors:                       # keep the allocator from recycling operands still in use there
             if t is not None:
                 t.record_stream(side)
@@ -115,14 +116,17 @@ class _on_side:
 
 
 def _end_of_backward():
+    # The engine runs this callback on whichever thread finishes the graph task; that thread's "current stream" is the device's
+    # default stream, not necessarily the stream the step runs on (a step on a side stream, a stream capture): join the stream that
+    # forked the gradient work.
     _SIDE["cb"] = False
-    join_side_stream()
+    join_side_stream(_SIDE["main"])
 
 
-def join_side_stream():
-    """Make the current (main) stream wait for all outstanding side-stream gradient work."""
+def join_side_stream(stream=None):
+    """Make `stream` (default: the current stream) wait for all outstanding side-stream gradient work."""
     if _SIDE["dirty"] and _SIDE["stream"] is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        (stream or torch.cuda.current_stream()).wait_stream(_SIDE["stream"])
         _SIDE["dirty"] = False
 
 

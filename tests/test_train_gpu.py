@@ -554,3 +554,69 @@ def test_clock_sample_reports_a_plausible_engine_clock(cuda):
     assert bool(((c1[:, 0] - c0[:, 0])[seen] > 0).all()) and bool(((c1[:, 1] - c0[:, 1])[seen] > 0).all())
     mhz = K.effective_clock_mhz(c0, c1)
     assert math.isfinite(mhz) and 1.0 < mhz < 10000.0, (mhz, c0.tolist(), c1.tolist())
+
+
+def _relmax(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+# ----------------------------------------------------------------------------- captured step (hipGraph)
+@pytest.mark.parametrize("model_type", ["mlp_mixer", "vitgan"])
+def test_captured_step_replays_the_eager_step(cuda, model_type):
+    """TrainStep.enable_graph: the step behind the text tower recorded once into a hipGraph and replayed.  With the random draws
+    switched off (augs ['R'], noise_fac 0) eager and replayed training must walk the same trajectory: same losses, same
+    parameters after the same batches (up to the summation order of the few fp32 atomics), scheduler / Adam bias correction /
+    EMA driven through the device-resident scalars."""
+    over = dict(model_type=model_type, lr=2e-3)
+    if model_type == "vitgan":
+        over.update(dim=48, depth=2, num_heads=3, vq_image_size=16)
+    toks = []
+    for sd in range(5):
+        toks.append(_setup(seed=20 + sd, **over)[7].cuda())
+    runs = {}
+    for mode in ("eager", "graph"):
+        cfg, net, vq, perceptor, opt, *_ = _setup(**over)
+        opt.enable_ema(0.9)
+        sched = fmain.CosineAnnealingLR(opt, T_max=20)
+        stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt, scheduler=sched)
+        stepper.make_cutouts.noise_fac = 0
+        losses = [float(stepper(toks[0])[0])]
+        if mode == "graph":
+            stepper.enable_graph(4, toks[1])          # the eager warm-up step on the capture stream consumes batch 1
+            sched.step()                               # (enable_graph's warm-up runs the body only: scheduler tick by hand)
+            losses.append(float(stepper._g_out[0]))
+        else:
+            losses.append(float(stepper(toks[1])[0]))
+        for t in toks[2:]:
+            loss, mid = stepper(t)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert (stepper._graph is not None) == (mode == "graph")
+        runs[mode] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, opt._ema.clone(), opt._step,
+                      opt.param_groups[0]["lr"])
+    (le, pe, ee, se, lre), (lg, pg, eg, sg, lrg) = runs["eager"], runs["graph"]
+    assert se == sg == 5 and abs(lre - lrg) < 1e-12
+    for a, b in zip(le[:1] + le[2:], lg[:1] + lg[2:]):
+        assert abs(a - b) / abs(a) < 1e-4, (le, lg)
+    # parameters: Adam turns the rounding noise of ill-conditioned gradients (the token-mix output bias is invisible behind the
+    # next LayerNorm: its gradient is pure cancellation noise) into +-lr steps, so two EAGER runs already differ by percents in
+    # those entries (fp32 atomics order); the trajectory of the loss above is the sharp check, the bucket-wide rms the coarse one
+    flat = lambda d: torch.cat([v.flatten().double() for v in d.values()])      # noqa: E731
+    assert float((flat(pg) - flat(pe)).pow(2).mean().sqrt() / flat(pe).pow(2).mean().sqrt()) < 5e-3
+    assert float((eg.double() - ee.double()).pow(2).mean().sqrt() / ee.double().pow(2).mean().sqrt()) < 5e-3
+
+
+def test_captured_step_with_the_default_random_draws(cuda):
+    """Default augmentations + cutout noise inside the captured step: fresh draws per replay (augmentation parameters through the
+    static device tensors, noise through torch's graph-safe Philox state), finite and decreasing."""
+    cfg, net, vq, perceptor, opt, _, _, tok, _, _ = _setup(augs=None, lr=3e-3)
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    stepper(tok.cuda())
+    stepper.enable_graph(4, tok.cuda())
+    seen, losses = set(), []
+    for _ in range(12):
+        loss, mid = stepper(tok.cuda())
+        losses.append(float(loss))
+        seen.add(float(mid["embed"].detach().float().sum()))
+    assert all(torch.isfinite(torch.tensor(losses))) and len(seen) == 12          # a new augmentation / noise draw every replay
+    assert sum(losses[-4:]) < sum(losses[:4])
