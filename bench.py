@@ -300,6 +300,8 @@ def main():
     if world != args.gpus:
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.gpus > 1 and hvd.describe().get("ranks") != args.gpus:       # the process group must span exactly the GPUs the line claims
+        raise SystemExit(f"--gpus {args.gpus}: the process group has {hvd.describe().get('ranks')} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(hvd.local_rank())
@@ -397,8 +399,17 @@ def main():
         # rank 0 keeps the per-launch events
         K.PROFILE = [] if rank == 0 else None
         K.HBM_PROFILE = [] if rank == 0 else None
+        dp_opt = stepper.opt if isinstance(stepper.opt, hvd.DistributedOptimizer) else None
+        if dp_opt is not None:
+            dp_opt.measure_exposure(True)        # how long after the backward pass each slice's all-reduce finished
         stepper(toks[:B])
         torch.cuda.synchronize()
+        if dp_opt is not None and rank == 0:
+            rep = dp_opt.exposure_report() or []
+            out["dp_exposure"] = {"slices": len(rep), "exposed_ms": max([r["ms_after_backward"] or 0.0 for r in rep] + [0.0]),
+                                  "late_slices": [r for r in rep if (r["ms_after_backward"] or 0.0) > 0.0][-8:]}
+        if dp_opt is not None:
+            dp_opt.measure_exposure(False)
     if rank == 0 and not args.no_roofline:
         prof, K.PROFILE = K.PROFILE, None
         agg = {}

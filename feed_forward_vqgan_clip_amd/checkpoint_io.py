@@ -10,8 +10,11 @@
   state_dict the module would have produced, which `main.load_model` then loads into a freshly built mapper (the reference's
   `_fix_*_gelu_issue` patches are unnecessary that way: no pickled activation objects survive).
 
-Only state is recovered from stand-ins, never behaviour: nothing from the pickle is executed beyond tensor rebuilding and the
-usual container constructors.
+Only state is recovered from stand-ins, never behaviour.  `find_class` is an ALLOWLIST: tensor / storage rebuilders of
+torch, numpy's array rebuilders, `collections.OrderedDict`, the builtin containers and scalars resolve to the real objects; every
+other global a pickle names — importable or not: `os.system`, `builtins.eval`, `subprocess.*`, but also `torch.nn.Linear` or an
+optimizer class — becomes an inert stand-in whose "call" returns another stand-in, so a REDUCE opcode cannot run foreign code.
+(That is a much smaller surface than plain `torch.load(weights_only=False)`; files should still come from a trusted source.)
 """
 import collections
 import pickle
@@ -73,18 +76,44 @@ def _stub_class(module, name):
     return _STUBS[key]
 
 
-class TolerantUnpickler(pickle.Unpickler):
-    """pickle.Unpickler whose find_class never fails: importable classes resolve normally, everything else is a stub."""
+_ALLOWED = {
+    "collections": {"OrderedDict"},
+    "builtins": {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice",
+                 "range", "object"},
+    "__builtin__": {"set", "frozenset", "list", "dict", "tuple", "int", "long", "float", "bool", "str", "unicode", "bytes", "complex",
+                    "slice", "object"},
+    "copyreg": {"_reconstructor"}, "copy_reg": {"_reconstructor"},
+    "_codecs": {"encode"},
+    "numpy": {"ndarray", "dtype"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"}, "numpy._core.multiarray": {"_reconstruct", "scalar"},
+    "numpy.core.numeric": {"_frombuffer"}, "numpy._core.numeric": {"_frombuffer"},
+    "torch": {"Size", "device", "dtype", "Tensor", "FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage",
+              "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage", "TypedStorage"},
+    "torch._utils": {"_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_tensor_v3", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                     "_rebuild_qtensor", "_rebuild_device_tensor_from_numpy", "_rebuild_wrapper_subclass"},
+    "torch._tensor": {"_rebuild_from_type_v2", "Tensor"},
+    "torch.nn.parameter": {"Parameter", "Buffer"},
+    "torch.storage": {"_load_from_bytes", "UntypedStorage", "TypedStorage"},
+    "torch.serialization": {"_get_layout"},
+}
 
-    stubbed = None        # set per load: names that were replaced
+
+class TolerantUnpickler(pickle.Unpickler):
+    """pickle.Unpickler whose find_class never fails and never hands out foreign code: the allowlisted rebuilders / containers
+    resolve to the real objects, every other global becomes an inert stand-in (names collected in `self.stubbed_names` and, for
+    the duration of a tolerant_load, in the caller's set)."""
+
+    _collect = None       # set by tolerant_load (thread-local would be needed for concurrent loads; tolerant_load takes a lock)
 
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)               # (also applies pickle's Python-2 name mapping)
-        except Exception:                                         # ImportError, AttributeError, ...
-            if TolerantUnpickler.stubbed is not None:
-                TolerantUnpickler.stubbed.add(f"{module}.{name}")
-            return _stub_class(module, name)
+        if name in _ALLOWED.get(module, ()):
+            try:
+                return super().find_class(module, name)           # (also applies pickle's Python-2 name mapping)
+            except Exception:                                     # an allowlisted name this torch / numpy does not have
+                pass
+        if TolerantUnpickler._collect is not None:
+            TolerantUnpickler._collect.add(f"{module}.{name}")
+        return _stub_class(module, name)
 
 
 class _PickleModule:
@@ -101,14 +130,19 @@ class _PickleModule:
     UnpicklingError = pickle.UnpicklingError
 
 
+_LOAD_LOCK = __import__("threading").Lock()
+
+
 def tolerant_load(path, return_stubbed=False):
-    """torch.load(path, map_location='cpu') that survives classes of packages that are not installed."""
-    TolerantUnpickler.stubbed = set()
-    try:
-        obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
-        names = sorted(TolerantUnpickler.stubbed)
-    finally:
-        TolerantUnpickler.stubbed = None
+    """torch.load(path, map_location='cpu') that survives classes of packages that are not installed (and does not execute what
+    a pickle names outside the allowlist above)."""
+    with _LOAD_LOCK:
+        TolerantUnpickler._collect = set()
+        try:
+            obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
+            names = sorted(TolerantUnpickler._collect)
+        finally:
+            TolerantUnpickler._collect = None
     return (obj, names) if return_stubbed else obj
 
 

@@ -106,7 +106,12 @@ class _SplitLinear:
     def __init__(self, weight, bias):
         w = weight.detach().reshape(weight.shape[0], -1).float().cuda().contiguous()
         self.N, self.K = w.shape
-        self.w3 = K.split3(w, torch.float16, weight_order=True)
+        # range handling: f16 segments overflow above 65504 and lose the lo term below 2^-14.  The weight gets a
+        # per-tensor power-of-two scale that puts its largest entry at ~2^10 (exact: only exponents move) and leaves through the
+        # GEMM's alpha; activations are checked once per checkpoint by CLIP._probe_text_tower (non-finite -> exact fp32 MFMA)
+        amax = float(w.abs().max())
+        self.scale = 2.0 ** (10 - int(np.ceil(np.log2(amax)))) if amax > 0 and np.isfinite(amax) else 1.0
+        self.w3 = K.split3(w * self.scale, torch.float16, weight_order=True)
         self.bias = None if bias is None else bias.detach().float().cuda().contiguous()
 
     def __call__(self, x, act=K.ACT_NONE, residual=None):
@@ -114,7 +119,7 @@ class _SplitLinear:
         x3 = K.split3(x.reshape(rows, self.K))
         y = torch.empty(*x.shape[:-1], self.N, dtype=torch.float32, device=x.device)
         K.gemm(x3, self.w3, y, rows, self.N, 3 * self.K, ldx=3 * self.K, ldw=3 * self.K, bias=self.bias, residual=residual,
-               act=act)
+               act=act, alpha=1.0 / self.scale)
         return y
 
 
@@ -214,6 +219,23 @@ class CLIP:
         self.ln_final = (_f(sd["ln_final.weight"]), _f(sd["ln_final.bias"]))
         self.tproj = ops.Weights.frozen(sd["text_projection"].t().contiguous(), None, f32, False)
         self.logit_scale = _f(sd["logit_scale"]) if "logit_scale" in sd else torch.tensor(np.log(1 / 0.07)).cuda()
+        if not self.text_exact:
+            self._probe_text_tower(sd, act)
+
+    def _probe_text_tower(self, sd, act):
+        """One forward of the split-precision text tower on a probe batch (every position filled, SOT .. EOT), once per checkpoint:
+        if an activation leaves f16's range somewhere (a checkpoint with large-magnitude channels), the features come out
+        non-finite -> rebuild the tower on the exact fp32 MFMA instead of returning NaN features later."""
+        V = self.tok_emb.shape[0]
+        L = self.context_length
+        g = torch.Generator().manual_seed(0)
+        tok = torch.randint(1, max(2, V - 2), (4, L), generator=g)
+        tok[:, -1] = V - 1
+        feats = self.encode_text(tok)
+        if not bool(torch.isfinite(feats).all()):
+            self.text_exact = True
+            f32 = torch.float32
+            self.tblocks = [_Block(sd, f"transformer.resblocks.{n}", f32, False, act) for n in range(len(self.tblocks))]
 
     # -- image tower ------------------------------------------------------------
     def encode_patches(self, patches):

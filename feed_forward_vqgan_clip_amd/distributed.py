@@ -83,21 +83,29 @@ class _NativeWork:
 # exchange is ~20 slices of 64 MiB per step.  `setdefault` only — anything the user exports wins; `describe()` records the result.
 # UNMEASURED (no multi-GPU box was available to this build): the values follow the topology, not a sweep.
 RCCL_PRESET = {
-    "HSA_ENABLE_IPC_MODE_LEGACY": "0",     # the host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
-    "NCCL_IB_DISABLE": "1",                # single node: no verbs transport probing
-    "NCCL_SOCKET_IFNAME": "lo",            # bootstrap over loopback (the container hostname may not resolve)
     "NCCL_MIN_NCHANNELS": "28",            # >= 4 channels per xGMI link (7 links): large slices need all links busy
     "NCCL_BUFFSIZE": str(8 << 20),         # 8 MiB per channel: fewer, larger steps for 64 MiB all-reduces
     "NCCL_DEBUG": "VERSION",
 }
+# only when every rank of the job is on THIS host (LOCAL_WORLD_SIZE == WORLD_SIZE): on a multi-node launch these two would hang
+# the bootstrap (the reference's Horovod path is multi-node capable)
+RCCL_PRESET_SINGLE_NODE = {
+    "NCCL_IB_DISABLE": "1",                # no verbs transport probing
+    "NCCL_SOCKET_IFNAME": "lo",            # bootstrap over loopback (the container hostname may not resolve)
+}
+# HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver only supports dmabuf IPC; RCCL fails with hipIpcGetMemHandle otherwise) is read by
+# ROCr at hsa_init, i.e. before this module can act (torch.cuda.is_available() in the caller has initialised HIP already): it must
+# be exported by the launcher (it is, on the target image); describe() reports when it is missing instead of pretending to set it.
 
 
 def apply_rccl_preset():
     """Export RCCL_PRESET for the keys the environment does not already set (FFVC_RCCL_PRESET=0 disables)."""
     if os.environ.get("FFVC_RCCL_PRESET", "1") == "0":
         return {}
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    single_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
     applied = {}
-    for k, v in RCCL_PRESET.items():
+    for k, v in list(RCCL_PRESET.items()) + (list(RCCL_PRESET_SINGLE_NODE.items()) if single_node else []):
         if k not in os.environ:
             os.environ[k] = v
             applied[k] = v
@@ -112,6 +120,7 @@ def describe():
         return {"backend": None, "ranks": 1, "env": env}
     return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env,
             "preset_applied": sorted(_STATE.get("preset", {})),
+            "hsa_ipc_mode_legacy_exported_0": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0",
             "bucket_exchange": "ffvc_allreduce_bucket (own RCCL communicator)" if _STATE.get("native") else "torch.distributed"}
 
 
@@ -200,10 +209,22 @@ class DistributedOptimizer:
     torch.bfloat16 (halves xGMI traffic; the sum is still accumulated by RCCL in bf16).
     """
 
-    def __init__(self, opt, arena=None, bucket_bytes=64 << 20, wire_dtype=None):
+    def __init__(self, opt, arena=None, bucket_bytes=64 << 20, wire_dtype=None, tail_bytes=None, tail_bucket_bytes=16 << 20,
+                 tail_wire_dtype=torch.bfloat16):
+        """tail_*: the slices that go on the wire LAST have nothing left of the backward pass to hide behind (the Mixer's
+        `proj.weight`, 134 MB, is the last gradient produced; the first block's bucket right before it).  After the first step
+        the observed launch order decides which slices make up the last `tail_bytes` (default 192 MiB, FFVC_DP_TAIL_MIB; 0 = off);
+        those are re-cut to `tail_bucket_bytes` (the ring pipelines several small messages over the 7 xGMI links instead of
+        serialising behind one long pass) and travel in `tail_wire_dtype` (bf16: half the exposed bytes; the other slices keep
+        `wire_dtype`).  Every rank takes the same decision (the launch order is a function of the model)."""
         self.opt = opt
         self.arena = arena if arena is not None else opt.arena
         self.wire_dtype = wire_dtype
+        if tail_bytes is None:
+            tail_bytes = int(os.environ.get("FFVC_DP_TAIL_MIB", "192")) << 20
+        self.tail_bytes, self.tail_bucket_bytes, self.tail_wire_dtype = int(tail_bytes), int(tail_bucket_bytes), tail_wire_dtype
+        self._tail_tuned = self.tail_bytes <= 0
+        self._timing = None                 # exposure instrumentation (measure_exposure)
         a = self.arena
         # buckets in reverse registration order (= the order backward produces gradients)
         self.buckets = []           # (start_elem, end_elem, [param indices])
@@ -236,11 +257,8 @@ class DistributedOptimizer:
                 cur, cur_end, cur_bytes = [], None, 0
         if cur:
             self.buckets.append((a.param_range(a.plist[cur[-1]])[0], cur_end, cur))
-        self._bucket_of = {}                # id(param) -> [bucket indices] (several for a sliced tensor)
-        for b, (_, _, idxs) in enumerate(self.buckets):
-            for i in idxs:
-                self._bucket_of.setdefault(id(a.plist[i]), []).append(b)
-        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+        self._wire_of = [wire_dtype] * len(self.buckets)      # per-slice wire format
+        self._index_buckets()
         self._seen = set()
         self._handles = {}
         self._wire = {}
@@ -255,6 +273,61 @@ class DistributedOptimizer:
     def _aligned_end(self, i):
         a = self.arena
         return a.offsets[i + 1] if i + 1 < len(a.plist) else a.total
+
+    def _index_buckets(self):
+        a = self.arena
+        self._bucket_of = {}                # id(param) -> [bucket indices] (several for a sliced tensor)
+        for b, (_, _, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                self._bucket_of.setdefault(id(a.plist[i]), []).append(b)
+        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+
+    def _retune_tail(self, order):
+        """order: bucket indices in the launch order of the step that just ran.  Re-cut the slices that make up its last
+        `tail_bytes` into `tail_bucket_bytes` pieces on the tail wire format (see __init__)."""
+        self._tail_tuned = True
+        tail, acc = set(), 0
+        for b in reversed(order):
+            if acc >= self.tail_bytes:
+                break
+            tail.add(b)
+            acc += (self.buckets[b][1] - self.buckets[b][0]) * 4
+        if not tail:
+            return
+        nb, nw = [], []
+        per = max(64, self.tail_bucket_bytes // 4 // 64 * 64)
+        for b, (s, e, idxs) in enumerate(self.buckets):
+            if b in tail:
+                cuts = list(range(s, e, per)) + [e]
+                for k in reversed(range(len(cuts) - 1)):       # highest addresses first, like the slices of one large tensor
+                    nb.append((cuts[k], cuts[k + 1], idxs))
+                    nw.append(self.tail_wire_dtype if self.tail_wire_dtype is not None else self._wire_of[b])
+            else:
+                nb.append((s, e, idxs))
+                nw.append(self._wire_of[b])
+        self.buckets, self._wire_of = nb, nw
+        self._index_buckets()
+
+    def measure_exposure(self, on=True):
+        """Instrument the next step(s): an event behind every slice's all-reduce and one at the end of the backward pass;
+        exposure_report() then says how long after the backward pass each exchange finished (what the step could not hide)."""
+        self._timing = {"done": {}, "bwd_end": None} if on else None
+
+    def exposure_report(self):
+        """[{slice, MiB, wire, params, ms_after_backward}] of the last instrumented step, launch order; call after a device sync."""
+        t = self._timing
+        if not t or t.get("last") is None:
+            return None
+        done, end, order, buckets, wire = t["last"]
+        names = {id(p): n for n, p in self.arena.module.named_parameters()} if hasattr(self.arena, "module") else {}
+        out = []
+        for b in sorted(done, key=lambda k: order.get(k, 1 << 30)):
+            s, e, idxs = buckets[b]
+            pn = [names.get(id(self.arena.plist[i]), str(i)) for i in idxs]
+            out.append({"slice": b, "MiB": round((e - s) * 4 / 2 ** 20, 1), "wire": str(wire[b] or torch.float32).replace("torch.", ""),
+                        "params": pn[0] if len(pn) == 1 else f"{pn[-1]} .. {pn[0]}",
+                        "ms_after_backward": round(end.elapsed_time(done[b]), 3) if end is not None else None})
+        return out
 
     # -- gradient-ready plumbing ------------------------------------------------
     def _param_ready_hook(self, p):
@@ -278,6 +351,11 @@ class DistributedOptimizer:
 
     def _on_backward_end(self):
         self._backward_done = True
+        if self._timing is not None and torch.cuda.is_available() and self.arena.grads.is_cuda:
+            from . import ops
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(ops._SIDE["main"] or torch.cuda.current_stream())
+            self._timing["bwd_end"] = ev
 
     def _refuse(self, p):
         name = next((n for n, q in self.arena.module.named_parameters() if q is p), "?")
@@ -323,8 +401,9 @@ class DistributedOptimizer:
     def _enqueue(self, b, g):
         self._order[b] = len(self._order)
         t = g
-        if self.wire_dtype is not None and self.wire_dtype != g.dtype:
-            t = g.to(self.wire_dtype)
+        wd = self._wire_of[b]
+        if wd is not None and wd != g.dtype:
+            t = g.to(wd)
             self._wire[b] = t
         nat = _STATE.get("native")
         if nat is not None and t.is_cuda:
@@ -339,6 +418,18 @@ class DistributedOptimizer:
             self._handles[b] = _NativeWork(ev)
         else:
             self._handles[b] = dist.all_reduce(t, async_op=True)
+        if self._timing is not None and t.is_cuda:
+            # an event behind the exchange: on the exchange stream (own communicator) or, for torch.distributed's process group,
+            # on a throw-away stream that waits for the work handle (the host is not blocked)
+            ev = torch.cuda.Event(enable_timing=True)
+            if nat is not None:
+                ev.record(nat["stream"])
+            else:
+                ws = self._timing.setdefault("stream", torch.cuda.Stream())
+                with torch.cuda.stream(ws):
+                    self._handles[b].wait()
+                    ev.record(ws)
+            self._timing["done"][b] = ev
 
     def _flush_unlaunched(self):
         for b in range(len(self.buckets)):
@@ -363,13 +454,16 @@ class DistributedOptimizer:
         self._pending = [len(idxs) for _, _, idxs in self.buckets]
         self._seen = set()
 
-    def synchronize(self):
+    def synchronize(self, keep_order=False):
         """Flush buckets that never completed (unused params), wait for every exchange."""
         if is_distributed():
             self._flush_unlaunched()
             for b in list(self._handles):
                 self._wait_bucket(b)
-        self._reset()
+        if not keep_order:
+            self._reset()
+        else:
+            self._handles, self._wire = {}, {}
 
     def _ranges_as_reduced(self):
         """(start, end) of every bucket in launch order, each yielded once its exchange is waited for (on the stream): the
@@ -415,17 +509,27 @@ class DistributedOptimizer:
             self._flush_unlaunched()
             self._set_scale()
             out = self.opt.step(ranges=self._ranges_as_reduced())
-            self._reset()
-            self._order = {}
+            self._after_step()
             return out
         if not getattr(self, "_synced", False):
-            self.synchronize()
+            self.synchronize(keep_order=True)
         self._synced = False
-        self._order = {}
         if not self._set_scale() and not getattr(self, "_prescaled", False) and size() > 1:
             self.arena.grads.div_(size())
         self._prescaled = False
-        return self.opt.step()
+        out = self.opt.step()
+        self._after_step()
+        return out
+
+    def _after_step(self):
+        order = sorted(self._order, key=self._order.get)
+        if self._timing is not None:
+            self._timing["last"] = (self._timing["done"], self._timing["bwd_end"], dict(self._order), list(self.buckets), list(self._wire_of))
+            self._timing["done"], self._timing["bwd_end"] = {}, None
+        self._reset()
+        self._order = {}
+        if not self._tail_tuned and is_distributed() and len(order) == len(self.buckets):
+            self._retune_tail(order)
 
     def __getattr__(self, name):
         # everything else (loss_scale, enable_ema, ema_state_dict, ...) is the wrapped optimizer's business

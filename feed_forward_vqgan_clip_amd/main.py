@@ -688,6 +688,7 @@ def train(config_file):
     base_lr = config.lr
     opt = FusedAdam(net.parameters(), lr=base_lr)
     opt.loss_scale = float(config.get("loss_scale", 4096.0 if cdt == torch.float16 else 1.0))
+    opt.skip_step_on_overflow = bool(config.get("skip_step_on_overflow", True))   # an overflowed f16 backward skips the WHOLE update
     opt_path = os.path.join(config.folder, "opt.th")
     if os.path.exists(opt_path):
         print(f"Resuming optimizer state from {opt_path}")

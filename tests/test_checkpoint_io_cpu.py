@@ -81,3 +81,28 @@ def test_module_state_dict_matches_torch_on_a_real_module():
     assert list(sd) == list(m.state_dict())
     for k, v in m.state_dict().items():
         assert torch.equal(sd[k], v)
+
+
+def test_tolerant_load_does_not_execute_importable_globals(tmp_path):
+    """a pickle that names an importable callable (os.system, builtins.eval, subprocess.*) must not run it — every
+    global outside the allowlist of tensor / container rebuilders becomes an inert stand-in."""
+    import os
+    import pickle
+
+    from feed_forward_vqgan_clip_amd import checkpoint_io as cio
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    class Evil2:
+        def __reduce__(self):
+            return (eval, (f"open({str(marker)!r}, 'w').close()",))
+
+    p = tmp_path / "evil.ckpt"
+    torch.save({"state_dict": {"w": torch.arange(6.0).view(2, 3)}, "a": Evil(), "b": Evil2()}, p, pickle_module=pickle)
+    obj, stubbed = cio.tolerant_load(p, return_stubbed=True)
+    assert not marker.exists()
+    assert torch.equal(obj["state_dict"]["w"], torch.arange(6.0).view(2, 3))
+    assert any(n.endswith(".system") for n in stubbed) and any(n.endswith(".eval") for n in stubbed)

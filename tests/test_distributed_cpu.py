@@ -55,7 +55,7 @@ def _worker(rank, world, port, wire, q):
     arena = ParamArena(net, torch.float32, allow_cpu=True)
     hvd.broadcast_parameters(net, root_rank=0) if False else hvd.broadcast(arena.params, 0)  # flat-bucket broadcast (no shadows on CPU)
     opt = hvd.DistributedOptimizer(torch.optim.SGD(net.parameters(), lr=0.1), arena=arena, bucket_bytes=1024,
-                                   wire_dtype=wire)
+                                   wire_dtype=wire, tail_bytes=0)
     assert len(opt.buckets) >= 3               # several buckets -> several overlapped all-reduces
     g = torch.Generator().manual_seed(1)
     X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
@@ -108,6 +108,66 @@ def test_dp_equivalence_world2(wire):
     assert (torch.from_numpy(res[0][2]) - arena.params.detach()).abs().max().item() < tol
 
 
+def _tail_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    from feed_forward_vqgan_clip_amd.arena import ParamArena
+    hvd.init(backend="gloo")
+    net = _model()
+    arena = ParamArena(net, torch.float32, allow_cpu=True)
+    opt = hvd.DistributedOptimizer(torch.optim.SGD(net.parameters(), lr=0.1), arena=arena, bucket_bytes=1024, tail_bytes=3000,
+                                   tail_bucket_bytes=512, tail_wire_dtype=torch.bfloat16)
+    n0, wire0 = len(opt.buckets), list(opt._wire_of)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    idx = list(iter(hvd.DistributedSampler(8, shuffle=False)))
+    counts = []
+    for _ in range(4):
+        opt.zero_grad()
+        ((net(X[idx]) - Y[idx]) ** 2).mean().backward()
+        opt.step()
+        counts.append(len(opt.buckets))
+    covered = sorted((s, e) for s, e, _ in opt.buckets)
+    q.put((rank, arena.params.detach().numpy().copy(), n0, counts, [str(w) for w in opt._wire_of], covered, arena.total,
+           all(w is None for w in wire0)))
+
+
+def test_dp_tail_slices_are_recut_and_travel_in_bf16_after_the_first_step():
+    """The slices that go on the wire last (observed launch order of step 1) are re-cut into small pieces on the bf16 wire from
+    step 2 on; the others keep fp32.  The bucket list still tiles the gradient arena, replicas stay identical, and the result is
+    the single-process one up to the bf16 rounding of the tail gradients."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+    (_, p0, n0, counts, wires, covered, total, all_fp32_first), (_, p1, *_rest) = res
+    assert (p0 == p1).all()
+    assert all_fp32_first and counts[0] > n0 and counts[1:] == [counts[0]] * 3            # re-cut once, after the first step
+    assert "torch.bfloat16" in wires and "None" in wires                                   # tail on bf16, the rest on fp32
+    assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    from feed_forward_vqgan_clip_amd.arena import ParamArena
+    net = _model()
+    arena = ParamArena(net, torch.float32, allow_cpu=True)
+    ref = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    for _ in range(4):
+        arena.zero_grad()
+        ((net(X) - Y) ** 2).mean().backward()
+        ref.step()
+    assert (torch.from_numpy(p0) - arena.params.detach()).abs().max().item() < 3e-3
+
+
 def test_sampler_matches_torch():
     from torch.utils.data import DistributedSampler as TorchSampler
 
@@ -158,7 +218,7 @@ def _worker_fused(rank, world, port, wire, overlap, q):
     net = _big_model()
     arena = ParamArena(net, torch.float32, allow_cpu=True)
     inner = _FlatSGD(arena, 0.05)
-    opt = hvd.DistributedOptimizer(inner, bucket_bytes=8192, wire_dtype=wire)
+    opt = hvd.DistributedOptimizer(inner, bucket_bytes=8192, wire_dtype=wire, tail_bytes=0)
     w0 = net[0].weight
     slices = [b for b, (_, _, idxs) in enumerate(opt.buckets) if idxs == [arena.plist.index(w0)]]
     assert len(slices) >= 3, opt.buckets                         # 24 KiB tensor, 8 KiB buckets

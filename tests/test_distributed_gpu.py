@@ -80,7 +80,7 @@ def _run(rank, world, steps=2):
     perceptor = fclip.CLIP(fclip.random_state_dict(CLIP_CFG, 11), torch.float32)
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
     if world > 1:
-        opt = hvd.DistributedOptimizer(opt, bucket_bytes=64 << 10)
+        opt = hvd.DistributedOptimizer(opt, bucket_bytes=64 << 10, tail_bytes=0)
         assert len(opt.buckets) >= 2
         hvd.broadcast_parameters(net, root_rank=0)
         hvd.broadcast_optimizer_state(opt, root_rank=0)

@@ -305,7 +305,10 @@ def test_cfg2_full_size_f16_step_matches_oracle(cuda):
     assert abs(r["fp32"]["same"] - o) / o < 1e-4 and r["fp32"]["flips"] <= 1
     assert abs(r["f16"]["same"] - o) / o < 1e-4                      # the timed dtype, reference's codes: north_star tolerance
     assert r["f16"]["xr"] < 3e-3 and r["f16"]["embed"] < 3e-3
-    assert r["f16"]["flips"] <= 0.01 * r["f16"]["n"] and abs(r["f16"]["free"] - o) / o < 5e-3
+    # free-running: the argmin is a discontinuity of the reference itself, every flipped code moves the loss by ~1.5e-4 x 1024 / n
+    # (profiles/r02_error_budget_b4.txt): 1e-4 is NOT guaranteed here (measured 2.6e-4 at batch 4 with 3 flips of 1024, 2.9e-5 at
+    # the benchmark's batch 64) — the bound below is what the f16 mapper's z error (rel-rms 9.6e-4) allows
+    assert r["f16"]["flips"] <= 0.005 * r["f16"]["n"] + 1 and abs(r["f16"]["free"] - o) / o < 1e-4 + 4e-4 * r["f16"]["flips"] * 512 / r["f16"]["n"]
 
 
 def test_cfg5_full_size_f16_step_matches_oracle(cuda):
@@ -323,4 +326,7 @@ def test_cfg5_full_size_f16_step_matches_oracle(cuda):
     assert abs(r["fp32"]["same"] - o) / o < 1e-4
     assert abs(r["f16"]["same"] - o) / o < 1e-4
     assert r["f16"]["xr"] < 3e-3 and r["f16"]["embed"] < 3e-3
-    assert r["f16"]["flips"] <= 0.01 * r["f16"]["n"] and abs(r["f16"]["free"] - o) / o < 5e-3
+    # free-running: the argmin is a discontinuity of the reference itself, every flipped code moves the loss by ~1.5e-4 x 1024 / n
+    # (profiles/r02_error_budget_b4.txt): 1e-4 is NOT guaranteed here (measured 2.6e-4 at batch 4 with 3 flips of 1024, 2.9e-5 at
+    # the benchmark's batch 64) — the bound below is what the f16 mapper's z error (rel-rms 9.6e-4) allows
+    assert r["f16"]["flips"] <= 0.005 * r["f16"]["n"] + 1 and abs(r["f16"]["free"] - o) / o < 1e-4 + 4e-4 * r["f16"]["flips"] * 512 / r["f16"]["n"]

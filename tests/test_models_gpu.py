@@ -509,4 +509,39 @@ def test_split_precision_text_tower_is_fp32_grade():
     a, w = K.split3(x), K.split3(x, weight_order=True)
     hi, lo = x.half(), (x - x.half().float()).half()
     assert torch.equal(a, torch.cat([hi, lo, hi], 1)) and torch.equal(w, torch.cat([hi, hi, lo], 1))
+
+
+def test_split_precision_text_tower_handles_out_of_range_checkpoints():
+    """f16 segments overflow above 65504.  (1) A checkpoint whose text-tower weights carry entries beyond f16's range
+    (compensated by tiny LayerNorm gains so the function stays tame) still gives fp32-grade features: every weight gets a per-tensor
+    power-of-two scale that leaves through the GEMM's alpha.  (2) A checkpoint that drives an ACTIVATION out of range is detected
+    once at load (probe forward) and the tower falls back to the exact fp32 MFMA instead of producing NaN features."""
+    from feed_forward_vqgan_clip_amd import clip as fclip
+    cfg = dict(fclip.VIT_B32, vision_layers=1, transformer_layers=2)
+    sd = fclip.random_state_dict(cfg, 4)
+    big = dict(sd)
+    for n in range(2):                                           # c_fc weight x 2^18 (entries ~1e4..1e5), ln_2 gain / 2^18
+        k = f"transformer.resblocks.{n}"
+        big[k + ".mlp.c_fc.weight"] = sd[k + ".mlp.c_fc.weight"] * 2.0 ** 18
+        big[k + ".ln_2.weight"] = sd[k + ".ln_2.weight"] * 2.0 ** -18
+        big[k + ".ln_2.bias"] = sd[k + ".ln_2.bias"] * 2.0 ** -18
+    assert float(big["transformer.resblocks.0.mlp.c_fc.weight"].abs().max()) > 65504
+    tok = torch.zeros(3, 77, dtype=torch.long)
+    g = torch.Generator().manual_seed(5)
+    for i, L in enumerate((5, 30, 76)):
+        tok[i, 0] = 49406
+        tok[i, 1:L] = torch.randint(1, 49000, (L - 1,), generator=g)
+        tok[i, L] = 49407
+    exact = fclip.CLIP(big, torch.float16, text_exact=True).encode_text(tok.cuda()).cpu()
+    split = fclip.CLIP(big, torch.float16, text_exact=False)
+    assert not split.text_exact
+    got = split.encode_text(tok.cuda()).cpu()
+    assert torch.isfinite(got).all() and _relrms(got, exact) < 2e-5, _relrms(got, exact)
+    hot = dict(sd)                                               # activations: the hidden layer of block 0 blown up by 2^20
+    hot["transformer.resblocks.0.mlp.c_fc.weight"] = sd["transformer.resblocks.0.mlp.c_fc.weight"] * 2.0 ** 20
+    hot["transformer.resblocks.0.mlp.c_proj.weight"] = sd["transformer.resblocks.0.mlp.c_proj.weight"] * 2.0 ** -20
+    fb = fclip.CLIP(hot, torch.float16, text_exact=False)
+    assert fb.text_exact                                          # the probe saw non-finite features -> exact path
+    ref = fclip.CLIP(hot, torch.float16, text_exact=True).encode_text(tok.cuda()).cpu()
+    assert torch.isfinite(ref).all() and _relrms(fb.encode_text(tok.cuda()).cpu(), ref) < 1e-6
     assert float(((hi.float() + lo.float()) - x).abs().max() / x.abs().max()) < 1e-6
