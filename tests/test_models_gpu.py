@@ -509,6 +509,7 @@ def test_split_precision_text_tower_is_fp32_grade():
     a, w = K.split3(x), K.split3(x, weight_order=True)
     hi, lo = x.half(), (x - x.half().float()).half()
     assert torch.equal(a, torch.cat([hi, lo, hi], 1)) and torch.equal(w, torch.cat([hi, hi, lo], 1))
+    assert float(((hi.float() + lo.float()) - x).abs().max() / x.abs().max()) < 1e-6
 
 
 def test_split_precision_text_tower_handles_out_of_range_checkpoints():
@@ -520,11 +521,13 @@ def test_split_precision_text_tower_handles_out_of_range_checkpoints():
     cfg = dict(fclip.VIT_B32, vision_layers=1, transformer_layers=2)
     sd = fclip.random_state_dict(cfg, 4)
     big = dict(sd)
-    for n in range(2):                                           # c_fc weight x 2^18 (entries ~1e4..1e5), ln_2 gain / 2^18
+    for n in range(2):      # c_fc weight x 2^21 (entries up to ~3e5: beyond f16), ln_2 gain / 2^10, c_fc bias and c_proj weight rescaled to match
         k = f"transformer.resblocks.{n}"
-        big[k + ".mlp.c_fc.weight"] = sd[k + ".mlp.c_fc.weight"] * 2.0 ** 18
-        big[k + ".ln_2.weight"] = sd[k + ".ln_2.weight"] * 2.0 ** -18
-        big[k + ".ln_2.bias"] = sd[k + ".ln_2.bias"] * 2.0 ** -18
+        big[k + ".mlp.c_fc.weight"] = sd[k + ".mlp.c_fc.weight"] * 2.0 ** 21
+        big[k + ".ln_2.weight"] = sd[k + ".ln_2.weight"] * 2.0 ** -10
+        big[k + ".ln_2.bias"] = sd[k + ".ln_2.bias"] * 2.0 ** -10
+        big[k + ".mlp.c_fc.bias"] = sd[k + ".mlp.c_fc.bias"] * 2.0 ** 11
+        big[k + ".mlp.c_proj.weight"] = sd[k + ".mlp.c_proj.weight"] * 2.0 ** -11
     assert float(big["transformer.resblocks.0.mlp.c_fc.weight"].abs().max()) > 65504
     tok = torch.zeros(3, 77, dtype=torch.long)
     g = torch.Generator().manual_seed(5)
@@ -538,10 +541,10 @@ def test_split_precision_text_tower_handles_out_of_range_checkpoints():
     got = split.encode_text(tok.cuda()).cpu()
     assert torch.isfinite(got).all() and _relrms(got, exact) < 2e-5, _relrms(got, exact)
     hot = dict(sd)                                               # activations: the hidden layer of block 0 blown up by 2^20
-    hot["transformer.resblocks.0.mlp.c_fc.weight"] = sd["transformer.resblocks.0.mlp.c_fc.weight"] * 2.0 ** 20
-    hot["transformer.resblocks.0.mlp.c_proj.weight"] = sd["transformer.resblocks.0.mlp.c_proj.weight"] * 2.0 ** -20
+    hot["transformer.resblocks.0.mlp.c_fc.weight"] = sd["transformer.resblocks.0.mlp.c_fc.weight"] * 2.0 ** 22
+    hot["transformer.resblocks.0.mlp.c_fc.bias"] = sd["transformer.resblocks.0.mlp.c_fc.bias"] * 2.0 ** 22
+    hot["transformer.resblocks.0.mlp.c_proj.weight"] = sd["transformer.resblocks.0.mlp.c_proj.weight"] * 2.0 ** -22
     fb = fclip.CLIP(hot, torch.float16, text_exact=False)
     assert fb.text_exact                                          # the probe saw non-finite features -> exact path
     ref = fclip.CLIP(hot, torch.float16, text_exact=True).encode_text(tok.cuda()).cpu()
     assert torch.isfinite(ref).all() and _relrms(fb.encode_text(tok.cuda()).cpu(), ref) < 1e-6
-    assert float(((hi.float() + lo.float()) - x).abs().max() / x.abs().max()) < 1e-6

@@ -78,10 +78,10 @@ def main():
         pn = [names[id(a.plist[i])] for i in idxs]
         rows.append((b, (e - s) * 4 / 2**20, ms_before_end, b in launched_in_backward, pn[0] if len(pn) == 1 else f"{pn[-1]} .. {pn[0]}"))
     print(f"# {kind} 32x1024, batch {B}, f16, 1 rank on RCCL: backward {bwd_ms:.1f} ms, gradient bucket {total / 2**20:.0f} MiB in {len(opt.buckets)} slices")
-    print("# slice   MiB   all-reduce done before backward's end [ms]   enqueued inside backward   parameters")
+    print("# slice   MiB   all-reduce done before backward's end [ms]   enqueued inside backward   wire   parameters")
     early = 0
     for b, mib, ms, inb, pn in rows:
-        print(f"  {b:4d} {mib:6.1f} {ms:10.2f} {'yes' if inb else 'NO':>6s}   {pn}")
+        print(f"  {b:4d} {mib:6.1f} {ms:10.2f} {'yes' if inb else 'NO':>6s}   {str(opt._wire_of[b] or 'fp32').replace('torch.', ''):>8s}   {pn}")
         if ms == ms and ms > 0.02 * bwd_ms:
             early += mib
         else:
@@ -91,8 +91,10 @@ def main():
                "MiB_done_before_last_2pct_of_backward": early, "frac_bytes_early": early / (total / 2**20), "late": late,
                "first_parameter": first, "dp": hvd.describe()}
     print(json.dumps(summary))
+    # the tail of the launch order = what DistributedOptimizer itself re-cut onto the bf16 wire after the first step (the last
+    # ~192 MiB of gradients the pass produces: proj.weight's slices, the first block's bucket) plus the tiny slice in front of them
     order = sorted(range(len(opt.buckets)), key=lambda b: -rows[b][2] if rows[b][2] == rows[b][2] else 1e9)   # earliest finished first
-    tail = set(order[-5:])          # the last gradients of the pass: proj.weight's slices and the one or two slices before them
+    tail = {b for b in range(len(opt.buckets)) if opt._wire_of[b] is not None} | set(order[-2:])
     bad = [r for r in rows if not r[3]] + [r for r in rows if not (r[2] == r[2] and r[2] > 0.02 * bwd_ms) and r[0] not in tail]
     if bad:
         print("FAIL: slices outside the tail of the launch order that were late / not enqueued inside backward:", bad)
