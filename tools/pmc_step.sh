@@ -1,8 +1,8 @@
-# Profiles of one bench step for profiles/r03_* (run on the GPU box: bash tools/pmc_step.sh).  Every output carries the library
+# Profiles of one bench step for profiles/${FFVC_ROUND:-r04}_* (run on the GPU box: bash tools/pmc_step.sh).  Every output carries the library
 # stamp (tools/stamp.py).  Counter passes are their own runs: --kernel-trace + --pmc only (no other trace domains).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/${FFVC_ROUND:-r04}
 mkdir -p $O
 B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-alt-dtype"
 # 1. kernel trace (per-kernel time) of 5 steps
