@@ -69,7 +69,7 @@ def build(args, device):
     vq_sd = fvq.random_state_dict(fvq.F16_16384, seed=1234)
     arch, quick = fmain.clip_arch(args.clip_model)
     clip_sd = fclip.random_state_dict(arch, seed=1234)
-    vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
+    vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt, fp8=getattr(args, "dec_fp8", False))
     perceptor = fclip.CLIP(clip_sd, cdt, quick_gelu=quick, fp8=args.clip_fp8)
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
     opt.loss_scale = args.loss_scale if cdt == torch.float16 else 1.0
@@ -269,6 +269,8 @@ def main():
                     "ViT-B/16, ViT-L/14, openclip/<arch>/<pretrained> (cfg5: openclip/ViT-L-14/laion2b_s32b_b82k)")
     ap.add_argument("--clip-fp8", action="store_true", help="image-tower linears (fwd + dgrad) on the fp8 MFMA path: e4m3 "
                     "weights / activations, e5m2 gradients, per-tensor delayed scaling (cfg5); NOT the headline configuration")
+    ap.add_argument("--dec-fp8", action="store_true", help="the frozen decoder's large 3x3 convolutions (forward + dgrad) on the fp8 MFMA path "
+                    "(e4m3 activations / filters, e5m2 gradients, per-tensor delayed scaling; cfg5); NOT the headline configuration")
     ap.add_argument("--augs", default="default", help="'default' = the reference's Af,Pe,Ji,Er (main.py:164-165), or a "
                     "comma list, e.g. 'R'")
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp32"],
@@ -365,7 +367,7 @@ def main():
         "metric": "train-step images/sec (whole node), ViT-B/32 + VQGAN-f16 256x256, bs=64, 1/2/4/8 GPU",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "step_ms_main_stream": step_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": args.dtype + ("+fp8(clip image tower linears)" if args.clip_fp8 else ""), "data": "synthetic seeded token batches, random-init weights (no network)",
+        "dtype": args.dtype + ("+fp8(clip image tower linears)" if args.clip_fp8 else "") + ("+fp8(decoder 3x3 convs)" if args.dec_fp8 else ""), "data": "synthetic seeded token batches, random-init weights (no network)",
         "precision_recipe": {"bf16": "bf16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
                                      "fp32 text tower, VQ distances and loss",
                              "f16": "IEEE f16 storage / MFMA inputs, fp32 accumulate, fp32 residual streams + norm statistics, "
@@ -473,7 +475,7 @@ def main():
         # HBM-bound kernels of the step: algorithmic bytes / HIP-event time, against the 8 TB/s HBM3E peak
         out["hbm_kernels"] = {k_: {"launches": v[0], "ms": v[2] * 1e3, "GB/s": v[1] / max(v[2], 1e-12) / 1e9,
                                    "frac_of_8TBps": v[1] / max(v[2], 1e-12) / 8e12} for k_, v in hagg.items()}
-    if world == 1 and not args.no_alt_dtype and args.dtype in ("f16", "bf16") and not args.clip_fp8:
+    if world == 1 and not args.no_alt_dtype and args.dtype in ("f16", "bf16") and not args.clip_fp8 and not args.dec_fp8:
         # the same step in the OTHER 16-bit storage format (BASELINE's bf16 when the headline is f16), same box, same inputs
         alt = "bf16" if args.dtype == "f16" else "f16"
         del stepper

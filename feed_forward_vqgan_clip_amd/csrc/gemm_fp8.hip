@@ -134,6 +134,119 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm_
     ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1, 0);
 }
 
+// ---- fp8 3x3 convolution of the frozen decoder (round 4; BASELINE configs[4], reference main.py:140-143) ------------------------
+// conv_row_kernel (gemm2.hip) with fp8 operands: the haloed X row tile and the filter tile hold 128-byte rows = 128 fp8 channels
+// per K step (the DMA address generators see 16-bit words: Cin / 2 words per pixel), the three kw taps are served from the same
+// X tile, the MFMAs are v_mfma_f32_32x32x64_f8f6f4 on two 16-byte fragment reads per operand exactly as in gemm_f8_kernel.  Same
+// two-workgroups-per-CU single-stage schedule, same epilogues (bias, residual, GroupNorm moments).  Needs Cin % 128 == 0.
+template <typename L, int XFMT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_row_f8_kernel(const ffvc_gemm_desc p, int tiles_n, int n_tiles, int vec_ok,
+                                                             const float* __restrict__ s0, const float* __restrict__ s1) {
+  constexpr int MT = 4, BM = 256, BN = 128;
+  constexpr int XTILE = 264 * 128, WTILE = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int l31 = lane & 31;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int W = p.conv_W, Cin16 = p.conv_Cin >> 1, K16 = p.K >> 1, ldw16 = (int)(p.ldw >> 1);
+  ConvRowDmaB sx;
+  KMajorDmaB<BN, 4> sw;
+  sx.init((const uint16_t*)p.x, m0, p.conv_H, W, Cin16, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
+  sw.init((const uint16_t*)p.w + (int64_t)n0 * ldw16, ldw16, p.N - n0, tid);
+  f32x16_t acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  int xrow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int px = wm * 128 + t * 32 + l31;
+    const int Wt = W < 256 ? W : 256;
+    xrow[t] = (px / Wt) * (Wt + 2) + (px % Wt);
+  }
+  unsigned char* sX = smem;
+  unsigned char* sW = smem + XTILE;
+  const int nblk = Cin16 / 64;
+  for (int kh = 0; kh < 3; ++kh) {
+    for (int cb = 0; cb < nblk; ++cb) {
+#pragma unroll 1
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kw == 0) sx.issue(sX, kh, cb * 64, nullptr, tid);
+        sw.issue(sW, (kh * 3 + kw) * Cin16 + cb * 64, K16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          u32x4_t fa0[2], fa1[2], fb0[MT], fb1[MT];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int rw = wn * 64 + t * 32 + l31;
+            fa0[t] = frag_kmajor(sW, rw, 2 * t2, lane);
+            fa1[t] = frag_kmajor(sW, rw, 2 * t2 + 1, lane);
+          }
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            fb0[t] = frag_kmajor(sX, xrow[t] + kw, 2 * t2, lane);
+            fb1[t] = frag_kmajor(sX, xrow[t] + kw, 2 * t2 + 1, lane);
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) mma_f8<XFMT>(acc[a][b], fa0[a], fa1[a], fb0[b], fb1[b]);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (s0) {
+    const float s = s0[0] * (s1 ? s1[0] : 1.0f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] *= s;
+  }
+  if (vec_ok == 2)
+    ffvc_gemm_detail::gemm_epilogue_rows<L, MT, false, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096, 0);
+  else
+    ffvc_gemm_detail::gemm_epilogue<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1, 0);
+}
+
+template <typename L>
+int launch_conv_f8(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, const float* s1, hipStream_t st) {
+  using namespace ffvc_gemm_detail;
+  const int tiles_n = d.N / 128, n_tiles = (d.M / 256) * tiles_n;
+  constexpr int lds = 264 * 128 + 128 * 128 + 4 * 4096;
+  const bool gnv = (d.flags & FFVC_F_GN_SUMS) != 0;
+  auto go = [&](auto xf, auto epi_tag) -> int {
+    constexpr int XF = decltype(xf)::value, EPI = decltype(epi_tag)::value;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv_row_f8_kernel<L, XF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((conv_row_f8_kernel<L, XF, EPI>), dim3(n_tiles), dim3(256), lds, st, d, tiles_n, n_tiles, vec_ok, s0, s1);
+    FFVC_LAUNCH_CHECK();
+    return 0;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (x_fmt) return gnv ? go(I1{}, std::integral_constant<int, EPI_GN>{}) : go(I1{}, std::integral_constant<int, EPI_LEAN>{});
+  return gnv ? go(I0{}, std::integral_constant<int, EPI_GN>{}) : go(I0{}, std::integral_constant<int, EPI_LEAN>{});
+}
+
 // returns 0 (launched), 2 (launched, aux already holds act'(pre)) or an error code
 template <typename L, int BM, int BN>
 int launch_f8(const ffvc_gemm_desc& d, int x_fmt, int vec_ok, const float* s0, const float* s1, hipStream_t st) {
@@ -298,6 +411,26 @@ extern "C" int ffvc_gemm_fp8(const ffvc_gemm_desc* dp, int x_fmt, int lo_dtype, 
   FFVC_CHECK_ARG(d.x && d.w && d.y && d.M > 0 && d.N > 0 && d.K > 0, "ffvc_gemm_fp8: bad problem");
   FFVC_CHECK_ARG(x_fmt == 0 || x_fmt == 1, "ffvc_gemm_fp8: x_fmt must be 0 (e4m3) or 1 (e5m2)");
   FFVC_CHECK_ARG(lo_dtype == FFVC_BF16 || lo_dtype == FFVC_F16, "ffvc_gemm_fp8: lo_dtype must be a 16-bit storage type");
+  if (d.x_mode == FFVC_OP_CONV3X3) {
+    // fp8 3x3 convolution (frozen decoder): the haloed-row kernel's geometry, 128-channel K steps
+    const int W = d.conv_W, Cin = d.conv_Cin;
+    FFVC_CHECK_ARG(d.w_mode == FFVC_OP_KMAJOR && d.batch <= 1 && d.split_k <= 1 && d.slab_stride == 0 && d.act == FFVC_ACT_NONE &&
+                       !(d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM | FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_OUT_F32)),
+                   "ffvc_gemm_fp8 (conv): plain 16-bit output, optional bias / residual / GroupNorm moments only");
+    FFVC_CHECK_ARG((W == 64 || W == 128 || (W >= 256 && W % 256 == 0)) && ((int64_t)d.conv_H * W) % 256 == 0 && (d.N % 128) == 0 &&
+                       (d.M % 256) == 0 && Cin > 0 && (Cin % 128) == 0 && d.K == 9 * Cin && d.ldw == d.K,
+                   "ffvc_gemm_fp8 (conv): needs W in {64, 128, 256 k}, H*W %% 256 == 0, Cout %% 128 == 0, Cin %% 128 == 0 (W=%d Cin=%d N=%d)", W, Cin, d.N);
+    FFVC_CHECK_ARG(((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.w % 16) == 0 && ((uintptr_t)d.y % 16) == 0 && d.y_mi == 0 && d.y_sm == d.N &&
+                       (!d.residual || (d.r_mi == 0 && d.r_sm == d.N && !(d.flags & FFVC_F_RES_F32) && ((uintptr_t)d.residual % 16) == 0)) &&
+                       (!d.bias || ((uintptr_t)d.bias % 16) == 0),
+                   "ffvc_gemm_fp8 (conv): 16-byte aligned NHWC tensors expected");
+    const int ups = (d.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0;
+    FFVC_CHECK_ARG(((int64_t)(d.M >> (2 * ups)) * Cin) < 0x7FFFFF00ll && (int64_t)d.N * d.K < 0x7FFFFF00ll, "ffvc_gemm_fp8 (conv): operand beyond 32-bit DMA offsets");
+    FFVC_CHECK_ARG(!(d.flags & FFVC_F_GN_SUMS) || (d.gn_sums && d.gn_hw > 0 && (d.gn_hw % 256) == 0 && d.gn_cpg >= 4 && (d.gn_cpg % 4) == 0),
+                   "ffvc_gemm_fp8 (conv): bad GroupNorm-moment request");
+    hipStream_t stc = (hipStream_t)stream;
+    return lo_dtype == FFVC_F16 ? launch_conv_f8<f16_t>(d, x_fmt, 2, scale0, scale1, stc) : launch_conv_f8<uint16_t>(d, x_fmt, 2, scale0, scale1, stc);
+  }
   FFVC_CHECK_ARG(d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR && d.batch <= 1 && d.split_k <= 1 && d.kseg == 0 &&
                      d.x_mi == 0 && d.slab_stride == 0,
                  "ffvc_gemm_fp8: plain K-major x K-major problems only");

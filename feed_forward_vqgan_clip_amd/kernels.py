@@ -304,8 +304,14 @@ def fp8_next_scale(sc):
     _call("ffvc_fp8_update", sc.state.data_ptr(), sc.fmt, FP8_MARGIN, stream_ptr())
 
 
+def conv_fp8_ok(B, H, W, Cin, Cout):
+    """Geometry the fp8 3x3 convolution (conv_row_f8_kernel) covers: whole 256-pixel row tiles, 128-channel K steps, a full chip."""
+    return ((W == 64 or W == 128 or (W >= 256 and W % 256 == 0)) and (H * W) % 256 == 0 and Cout % 128 == 0 and Cin % 128 == 0 and
+            (B * H * W) % 256 == 0 and (B * H * W // 256) * (Cout // 128) >= 256 and os.environ.get("FFVC_CONV_FP8", "1") != "0")
+
+
 def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0,
-             colsum=None, out_scale=None):
+             colsum=None, out_scale=None, conv=None, gn_sums=None):
     """y[M,N] = act(sx.inv * sw.inv * X8 W8^T + bias) (+ residual): x8 [M,K], w8 [N,K] uint8 fp8 bytes (x in sx.fmt).
     out_scale (an initialised Fp8Scale): y is a uint8 tensor that receives the result as fp8 bytes in out_scale.fmt, scaled by its
     current scale, and out_scale's running amax is updated — the operand of the next fp8 GEMM straight from the epilogue (the two
@@ -318,6 +324,13 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
     d.bias, d.residual, d.aux = _ptr(bias), _ptr(residual), _ptr(aux)
     d.M, d.N, d.K = M, N, K
     d.x_mode, d.w_mode = OP_KMAJOR, OP_KMAJOR
+    if conv is not None:          # 3x3 convolution on an NHWC fp8 tensor: conv = (H, W, Cin) of the OUTPUT grid (F_UPSAMPLE2X in flags)
+        d.x_mode = OP_CONV3X3
+        d.conv_H, d.conv_W, d.conv_Cin = conv
+    if gn_sums is not None:
+        buf, hw, cpg = gn_sums
+        d.gn_sums, d.gn_hw, d.gn_cpg = buf.data_ptr(), hw, cpg
+        flags |= _lib.F_GN_SUMS
     if out_scale is not None:
         if y.dtype != torch.uint8 or not out_scale.ready:
             raise TypeError("gemm_fp8: fp8 output needs a uint8 y and an initialised Fp8Scale")
@@ -349,7 +362,7 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
                "ffvc_gemm_fp8")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * K, e0, e1, (M, N, K, 1, 1)))
+        PROFILE.append(("conv3x3_fp8" if conv is not None else "gemm_nt_fp8", 2.0 * M * N * K, e0, e1, (M, N, K, 1, 1)))
     return y
 
 

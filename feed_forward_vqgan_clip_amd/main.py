@@ -671,7 +671,7 @@ def train(config_file):
         torch.cuda.set_device(hvd.local_rank())
     cdt = _cdt(config)
     toks = load_dataset(config.path)
-    vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt)
+    vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt, fp8=bool(config.get("decoder_fp8", False)))
     perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt, fp8=bool(config.get("clip_fp8", False)))
     vq_channels = vq.codebook.shape[1]
     checkpoint_path = os.path.join(config.folder, "checkpoint.th")

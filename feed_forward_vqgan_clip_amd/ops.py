@@ -587,9 +587,12 @@ def groupnorm_fork(x, gamma, beta, swish=True):
 class ConvWeights:
     """Frozen 3x3 conv: w [Cout, 3,3,Cin] and the dgrad filter wd [Cin, 3,3,Cout] (flipped taps), both K-major."""
 
-    __slots__ = ("w", "wd", "bias", "Cin", "Cout", "wd_small")
+    __slots__ = ("w", "wd", "bias", "Cin", "Cout", "wd_small", "fp8")
 
-    def __init__(self, weight_oihw, bias, cdt):
+    def __init__(self, weight_oihw, bias, cdt, fp8=False):
+        """fp8: also keep OCP e4m3 copies of the filter and of the dgrad filter (per-tensor scale from the fp32 master) and the
+        delayed-scaling state of the layer's activation (e4m3) / gradient (e5m2) streams: launches whose geometry the fp8 row
+        kernel covers (kernels.conv_fp8_ok) then run on v_mfma_f32_32x32x64_f8f6f4 (BASELINE configs[4])."""
         w = weight_oihw.detach().float().cuda()
         self.Cout, self.Cin = w.shape[0], w.shape[1]
         w_k = w.permute(0, 2, 3, 1).contiguous()                         # [Cout, kh, kw, Cin]
@@ -606,6 +609,12 @@ class ConvWeights:
             wds = torch.zeros(self.Cin, kp, dtype=torch.float32, device=w.device)
             wds[:, :9 * self.Cout] = wd_k.view(self.Cin, 9 * self.Cout)
             self.wd_small = _as(wds, cdt)
+        self.fp8 = None
+        if fp8 and cdt in K.LOWP and self.Cin % 128 == 0 and self.Cout % 128 == 0:
+            sw = K.Fp8Scale(K.E4M3, w.device)
+            self.fp8 = {"w": sw, "w8": K.fp8_quant(w_k.view(self.Cout, 9 * self.Cin), sw, frozen=True),
+                        "wd8": K.fp8_quant(wd_k.view(self.Cin, 9 * self.Cout), sw, frozen=True),
+                        "x": K.Fp8Scale(K.E4M3, w.device), "g": K.Fp8Scale(K.E5M2, w.device)}
 
 
 class _Conv3x3Fn(Function):
@@ -616,9 +625,19 @@ class _Conv3x3Fn(Function):
         H, W = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
         y = torch.empty(B, H, W, P.Cout, dtype=out_dtype or x.dtype, device=x.device)
         sums = _gn_request(gn, y, B, H * W, P.Cout)
-        K.gemm(x, P.w, y, B * H * W, P.Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=P.bias,
-               residual=residual, conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0,
-               gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
+        ctx.f8 = (P.fp8 is not None and x.dtype in K.LOWP and y.dtype == x.dtype and K.conv_fp8_ok(B, H, W, Cin, P.Cout) and
+                  (residual is None or residual.dtype == x.dtype))
+        if ctx.f8:
+            f = P.fp8                      # e4m3 activation (per-tensor delayed scale) x e4m3 filter on the fp8 row kernel
+            x8 = K.fp8_quant(x, f["x"])
+            K.gemm_fp8(x8, f["w8"], y, B * H * W, P.Cout, 9 * Cin, f["x"], f["w"], lo_dtype=x.dtype, bias=P.bias, residual=residual,
+                       conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0,
+                       gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
+            K.fp8_next_scale(f["x"])
+        else:
+            K.gemm(x, P.w, y, B * H * W, P.Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=P.bias,
+                   residual=residual, conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0,
+                   gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
         ctx.P, ctx.upsample, ctx.geom, ctx.cdt = P, upsample, (B, H, W, Cin), x.dtype
         ctx.has_res = residual is not None
         return y
@@ -631,7 +650,12 @@ class _Conv3x3Fn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxu = torch.empty(B, H, W, Cin, dtype=ctx.cdt, device=dy.device)
-            if P.wd is not None:
+            if P.wd is not None and ctx.f8 and K.conv_fp8_ok(B, H, W, P.Cout, Cin):
+                f = P.fp8                  # gradients travel as e5m2
+                dy8 = K.fp8_quant(_as(dy, ctx.cdt), f["g"])
+                K.gemm_fp8(dy8, f["wd8"], dxu, B * H * W, Cin, 9 * P.Cout, f["g"], f["w"], lo_dtype=ctx.cdt, conv=(H, W, P.Cout))
+                K.fp8_next_scale(f["g"])
+            elif P.wd is not None:
                 dyt = _as(dy, ctx.cdt)
                 K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3,
                        conv=(H, W, P.Cout))

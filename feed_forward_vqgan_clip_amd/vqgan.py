@@ -76,12 +76,12 @@ def random_state_dict(cfg=F16_16384, seed=1234, codebook_std=1.0):
 
 
 class _Res:
-    def __init__(self, sd, p, cdt):
+    def __init__(self, sd, p, cdt, fp8=False):
         f = lambda k: sd[p + k].detach().float().cuda().contiguous()  # noqa: E731
         self.n1 = (f(".norm1.weight"), f(".norm1.bias"))
         self.n2 = (f(".norm2.weight"), f(".norm2.bias"))
-        self.conv1 = ops.ConvWeights(sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], cdt)
-        self.conv2 = ops.ConvWeights(sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], cdt)
+        self.conv1 = ops.ConvWeights(sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], cdt, fp8)
+        self.conv2 = ops.ConvWeights(sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], cdt, fp8)
         self.nin = None
         if (p + ".nin_shortcut.weight") in sd:
             self.nin = ops.Weights.frozen(sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"], cdt)
@@ -117,10 +117,14 @@ class VQGAN:
     """Frozen VQGAN: `.quantize.embedding.weight` (fp32 codebook) and `.decode` like the object `synth` receives
     (main.py:140-143), plus the NHWC fast path used by the fused train step."""
 
-    def __init__(self, state_dict, cfg=F16_16384, cdt=torch.float16):
+    def __init__(self, state_dict, cfg=F16_16384, cdt=torch.float16, fp8=False):
+        """fp8: the 3x3 convolutions whose geometry the fp8 row kernel covers (128-multiple channel counts, 64 / 128 / 256 k wide
+        images, a full chip of tiles) run forward (e4m3 x e4m3) and dgrad (e5m2 x e4m3) on the fp8 MFMA path with per-tensor delayed
+        scaling; everything else (GroupNorm, attention, 1x1 convs, the small levels, conv_out) stays in `cdt`."""
         if not torch.cuda.is_available():
             raise RuntimeError("VQGAN needs a HIP device; there is no CPU fallback")
         sd, self.cfg, self.cdt = state_dict, cfg, cdt
+        self.fp8 = bool(fp8) and cdt != torch.float32
         cb = sd["quantize.embedding.weight"].detach().float().cuda().contiguous()
         self.quantize = types.SimpleNamespace(embedding=types.SimpleNamespace(weight=cb))
         self.codebook = cb
@@ -131,20 +135,21 @@ class VQGAN:
                                                                      float(cb.abs().max()) < 6e4) else None
         self.post_quant = ops.Weights.frozen(sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], cdt)
         d = "decoder"
-        self.conv_in = ops.ConvWeights(sd[d + ".conv_in.weight"], sd[d + ".conv_in.bias"], cdt)
-        self.mid = [_Res(sd, d + ".mid.block_1", cdt), _Attn(sd, d + ".mid.attn_1", cdt), _Res(sd, d + ".mid.block_2", cdt)]
+        f8 = self.fp8
+        self.conv_in = ops.ConvWeights(sd[d + ".conv_in.weight"], sd[d + ".conv_in.bias"], cdt, f8)
+        self.mid = [_Res(sd, d + ".mid.block_1", cdt, f8), _Attn(sd, d + ".mid.attn_1", cdt), _Res(sd, d + ".mid.block_2", cdt, f8)]
         self.levels = []
         mult, nrb = cfg["ch_mult"], cfg["num_res_blocks"]
         curr = cfg["resolution"] // 2 ** (len(mult) - 1)
         for lvl in reversed(range(len(mult))):
             stages = []
             for i in range(nrb + 1):
-                stages.append(_Res(sd, f"{d}.up.{lvl}.block.{i}", cdt))
+                stages.append(_Res(sd, f"{d}.up.{lvl}.block.{i}", cdt, f8))
                 if curr in cfg["attn_resolutions"]:          # decided from the CONFIG resolution (App. A.1)
                     stages.append(_Attn(sd, f"{d}.up.{lvl}.attn.{i}", cdt))
             up = None
             if lvl != 0:
-                up = ops.ConvWeights(sd[f"{d}.up.{lvl}.upsample.conv.weight"], sd[f"{d}.up.{lvl}.upsample.conv.bias"], cdt)
+                up = ops.ConvWeights(sd[f"{d}.up.{lvl}.upsample.conv.weight"], sd[f"{d}.up.{lvl}.upsample.conv.bias"], cdt, f8)
                 curr *= 2
             self.levels.append((stages, up))
         self.norm_out = (sd[d + ".norm_out.weight"].detach().float().cuda().contiguous(),
@@ -198,7 +203,7 @@ def synth(model, z):
     return xr.permute(0, 3, 1, 2)
 
 
-def load_vqgan_model(config_path, checkpoint_path, cdt=torch.float16):
+def load_vqgan_model(config_path, checkpoint_path, cdt=torch.float16, fp8=False):
     """main.py:84-103: yaml read with PyYAML; the three targets the reference accepts —
       taming.models.vqgan.VQModel                        decoder / post_quant_conv / quantize.embedding
       taming.models.vqgan.GumbelVQ                       same decoder; the codebook is `quantize.embed` (main.py:95 aliases it)
@@ -233,4 +238,4 @@ def load_vqgan_model(config_path, checkpoint_path, cdt=torch.float16):
         if "quantize.embedding.weight" not in sd and "quantize.embed.weight" in sd:      # GumbelVQ
             sd = dict(sd)
             sd["quantize.embedding.weight"] = sd["quantize.embed.weight"]
-    return VQGAN(sd, cfg, cdt)
+    return VQGAN(sd, cfg, cdt, fp8=fp8)

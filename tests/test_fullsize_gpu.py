@@ -211,10 +211,13 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
     facs, noise = (torch.rand(cutn * Bn, generator=g) * 0.1).cuda(), torch.randn(cutn * Bn, 3, 224, 224, generator=g).cuda()
     prm = None
     out = {}
-    for mode, cdt, fp8 in (("fp32", torch.float32, False), ("f16", torch.float16, False), ("fp8", torch.float16, True)):
+    for mode, cdt, fp8 in (("fp32", torch.float32, False), ("f16", torch.float16, False), ("fp8", torch.float16, True),
+                           ("fp8dec", torch.float16, True)):
         torch.manual_seed(3)
         net = fmain.build_model(cfg, 256).cuda().prepare(cdt)
-        vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt)
+        vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt, fp8=(mode == "fp8dec"))       # r4: + the decoder's large 3x3 convs on the fp8 row kernel
+        if mode == "fp8dec":
+            assert vq.levels[-1][0][0].conv1.fp8 is not None
         perceptor = fclip.CLIP(clip_sd, cdt, quick_gelu=quick, fp8=fp8)
         assert perceptor.grid == 16 and len(perceptor.vblocks) == 24 and perceptor.embed_dim == 768
         opt = FusedAdam(net.parameters(), lr=cfg.lr)
@@ -227,7 +230,7 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
             loss, mid = stepper.forward_loss(tok, facs=facs, noise=noise, aug_params=prm, force_idx=idx)
         assert tuple(mid["xr"].shape) == (Bn, 512, 512, 3) and tuple(mid["embed"].shape) == (cutn * Bn, 768)
         out[mode] = dict(loss=loss.item(), indices=mid["indices"], embed=mid["embed"].float(), xr=mid["xr"].float())
-        if mode == "fp8":
+        if mode in ("fp8", "fp8dec"):
             l1, _ = stepper(tok, facs=facs, noise=noise, aug_params=prm)   # a full training step in the fp8 mode
             gr = net._ffvc_arena.grads
             assert math.isfinite(l1.item()) and torch.isfinite(gr).all() and gr.abs().max().item() > 0
@@ -243,6 +246,11 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
     print(f"[cfg5] loss fp32 {ref['loss']:.7f} | f16 rel {r16:.2e} embed {e16:.2e} | fp8 rel {r8:.2e} embed {e8:.2e}")
     assert rr(out["f16"]["xr"], ref["xr"]) < 3e-3 and e16 < 3e-3 and r16 < 1e-4        # the north_star tolerance in f16 mode
     assert e8 < 6e-2 and r8 < 3e-3                                                      # fp8 tower: its own budget
+    e8d = rr(out["fp8dec"]["embed"], ref["embed"])
+    r8d = abs(out["fp8dec"]["loss"] - ref["loss"]) / ref["loss"]
+    xd = rr(out["fp8dec"]["xr"], ref["xr"])
+    print(f"[cfg5] fp8 tower + fp8 decoder convs: loss rel {r8d:.2e} embed {e8d:.2e} xr {xd:.2e}")
+    assert xd < 8e-2 and e8d < 1e-1 and r8d < 3e-3                                      # e4m3 activations through 30 convolutions
 
 
 # ----------------------------------------------------------------------------- the TIMED dtype at full model size vs the oracle

@@ -660,3 +660,49 @@ def test_fp8_gemm_writes_the_next_operand_itself(cuda, ldt, act):
     from feed_forward_vqgan_clip_amd._lib import FFVCError
     with pytest.raises(FFVCError, match="fp8 output"):
         K.gemm_fp8(x8, w8, h8, M, N, Kd, sx, sw, lo_dtype=ldt, out_scale=so)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,Hin,Cin,Cout,ups,res,gn", [(8, 128, 128, 128, False, True, True), (16, 64, 256, 128, False, False, False),
+                                                      (4, 64, 128, 256, True, False, True), (2, 256, 128, 128, False, False, False)])
+def test_fp8_conv3x3_forward_and_dgrad(cuda, dt, B, Hin, Cin, Cout, ups, res, gn):
+    """The frozen decoder's 3x3 convolution on the fp8 row kernel (e4m3 x e4m3 forward with bias / residual / GroupNorm moments /
+    fused nearest-2x upsample, e5m2 x e4m3 dgrad) against fp64 math on the DECODED fp8 operands (torch's own float8 dtypes): the
+    kernel's arithmetic is exact up to fp32 accumulation; and against the 16-bit convolution of the unquantised operands within the
+    quantisation budget."""
+    from feed_forward_vqgan_clip_amd import ops
+    H = 2 * Hin if ups else Hin
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = (torch.randn(B, Hin, Hin, Cin, generator=g) * 0.7).to(dt).cuda()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    r = (torch.randn(B, H, H, Cout, generator=g) * 0.5).to(dt).cuda() if res else None
+    P8, P16 = ops.ConvWeights(w, b, dt, fp8=True), ops.ConvWeights(w, b, dt)
+    assert P8.fp8 is not None and K.conv_fp8_ok(B, H, H, Cin, Cout)
+    xg = x.clone().requires_grad_(True)
+    y8 = ops.conv3x3(xg, P8, residual=r, upsample=ups, gn=gn)
+    sums8 = getattr(y8, "_ffvc_gn", None)
+    y16 = ops.conv3x3(x, P16, residual=r, upsample=ups)
+    # fp64 reference on the decoded fp8 bytes
+    f = P8.fp8
+    sx, sw = f["x"].state.cpu(), f["w"].state.cpu()
+    x8 = _f8_ref(K.fp8_quant(x, f["x"]).cpu(), K.E4M3).double() * float(sx[2])
+    w8 = _f8_ref(f["w8"].cpu(), K.E4M3).double().view(Cout, 3, 3, Cin) * float(sw[2])
+    xn = x8.permute(0, 3, 1, 2)
+    if ups:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xn, w8.permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double().cpu()
+    assert _rel(y8.detach().cpu(), ref) < (2e-3 if dt == torch.float16 else 1e-2)   # storage rounding of y only
+    assert _rel(y8.detach(), y16.double()) < 5e-2                                    # e4m3 quantisation of x and w
+    if gn:
+        assert sums8 is not None
+        m = ref.view(B, H * H, 32, Cout // 32)
+        want = torch.stack([m.sum((1, 3)), (m * m).sum((1, 3))], -1)
+        assert _rel(sums8.cpu(), want) < 2e-3
+    gy = (torch.randn(B, H, H, Cout, generator=g) * 1e-2).to(dt).cuda()
+    y8.backward(gy)
+    x16 = x.clone().requires_grad_(True)
+    ops.conv3x3(x16, P16, residual=r, upsample=ups).backward(gy)
+    assert _rel(xg.grad, x16.grad.double()) < 8e-2                                   # e5m2 gradients (2 mantissa bits) x e4m3 filter
