@@ -13,7 +13,7 @@ python3 bench.py --steps 20 --warmup 3 2> $O/bench_line.err | tail -1 > $O/bench
 ( python3 tools/stamp.py; python3 tools/gemm_bench.py --dtype f16 2>&1 | grep -v amdgpu.ids ) > $O/gemm_shapes.txt
 # 3. the other configurations
 bash tools/bench_configs.sh > $O/bench_configs.txt 2>&1
-for f in cfg3 cfg4 cfg5_f16 cfg5_fp8; do cp gpurun_out/r04_bench_$f.json $O/bench_$f.json; done
+for f in cfg3 cfg4 cfg5_f16 cfg5_fp8 cfg5_fp8dec; do cp gpurun_out/r04_bench_$f.json $O/bench_$f.json; done
 # 4. profiler passes (kernel trace, HBM traffic, MFMA busy)
 bash tools/pmc_step.sh > $O/pmc_step.log 2>&1
 # 5. two-stream timeline of the step
