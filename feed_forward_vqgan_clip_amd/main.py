@@ -670,6 +670,10 @@ def train(config_file):
     if torch.cuda.is_available():
         torch.cuda.set_device(hvd.local_rank())
     cdt = _cdt(config)
+    if config.get("batch_invariant", False):
+        # the library reads the switch at its first GEMM launch: with it, a prompt's latent and codes do not depend on the batch around
+        # it (tests/test_fullsize_gpu.py::test_batch_rows_bit_identical_without_inkernel_splitk); costs the small-batch ViT / VitGAN shapes
+        os.environ["FFVC_SK_FIXUP"] = "0"
     toks = load_dataset(config.path)
     vq = load_vqgan_model(config.vqgan_config, config.vqgan_checkpoint, cdt, fp8=bool(config.get("decoder_fp8", False)))
     perceptor = load_clip_model(config.clip_model, path=config.get("clip_model_path"), cdt=cdt, fp8=bool(config.get("clip_fp8", False)))

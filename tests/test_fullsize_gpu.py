@@ -84,7 +84,8 @@ def test_batch_rows_are_independent(full):
     # split along K inside the kernel (r3), so 2048-row and 1024-row launches add the same products in a different order.  The
     # difference is accumulation round-off, re-rounded to bf16 between the 64 layers of the mapper (this fixture runs bf16), and
     # a code flips where two codebook distances tie within it.  Ranks of a data-parallel job run identical shapes, hence
-    # identical arithmetic (tests/test_distributed_gpu.py checks replicas bit for bit).
+    # identical arithmetic (tests/test_distributed_gpu.py checks replicas bit for bit).  With the shape-dependent split switched off
+    # the latents ARE bit-identical: test_batch_rows_bit_identical_without_inkernel_splitk below.
     ia, ib = a["indices"].reshape(B, -1)[:4], b["indices"].reshape(4, -1)
     agree = (ia == ib).float().mean().item()
     zd = (a["z"][:4] - b["z"]).abs()
@@ -99,6 +100,51 @@ def test_batch_rows_are_independent(full):
                                     aug_params=None, force_idx=a["indices"].reshape(B, -1)[:4].reshape(-1))
     d = (a["xr"][:4] - c["xr"]).abs()
     assert d.mean().item() < 5e-3 and d.max().item() < 0.1, (d.mean().item(), d.max().item())
+
+
+_INVARIANT_SCRIPT = r"""
+import torch
+from feed_forward_vqgan_clip_amd import clip as fclip, main as fmain, vqgan as fvq
+from feed_forward_vqgan_clip_amd.optim import FusedAdam
+B = 8
+cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=1024, depth=32, dropout=0, cutn=8, batch_size=B, repeat=1, nb_noise=None,
+                   diversity_coef=0, clip_model="ViT-B/32", model_type="mlp_mixer", vq_image_size=16)
+torch.manual_seed(7)
+net = fmain.build_model(cfg, 256).cuda().prepare(torch.bfloat16)
+vq = fvq.VQGAN(fvq.random_state_dict(fvq.F16_16384, seed=7), fvq.F16_16384, torch.bfloat16)
+perceptor = fclip.CLIP(fclip.random_state_dict(fclip.VIT_B32, seed=7), torch.bfloat16)
+stepper = fmain.TrainStep(cfg, net, vq, perceptor, FusedAdam(net.parameters(), lr=cfg.lr))
+tok = fmain.synthetic_tokens(B, seed=3).cuda()
+z = lambda n: dict(facs=torch.zeros(8 * n, device="cuda"), noise=torch.zeros(8 * n, 3, 224, 224, device="cuda"), aug_params=None)
+with torch.no_grad():
+    _, a = stepper.forward_loss(tok, **z(B))
+    _, b = stepper.forward_loss(tok[:4], **z(4))
+    _, c = stepper.forward_loss(tok[:2], **z(2))
+for name, o, n in (("4of8", b, 4), ("2of8", c, 2)):
+    print(name, "z_equal", int(torch.equal(a["z"][:n], o["z"])), "codes_equal",
+          int(torch.equal(a["indices"].reshape(B, -1)[:n], o["indices"].reshape(n, -1))),
+          "xr_maxdiff", (a["xr"][:n].float() - o["xr"].float()).abs().max().item())
+"""
+
+
+def test_batch_rows_bit_identical_without_inkernel_splitk(cuda):
+    """FFVC_SK_FIXUP=0 (config key `batch_invariant`) turns the shape-dependent in-kernel split-K off: every kernel on the mapper path then
+    adds each output element's products in an order that does not depend on the number of rows in the launch, so a prompt's latent
+    and its VQ codes are BIT-identical whatever the batch around it (bf16 step, cfg2 sizes).  Own process: the switch is read
+    at the first launch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FFVC_SK_FIXUP="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _INVARIANT_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    print(r.stdout)
+    lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith(("4of8", "2of8"))]
+    assert len(lines) == 2
+    for ln in lines:
+        assert ln[2] == "1" and ln[4] == "1", ln          # z and codes bit-identical
+        assert float(ln[6]) < 0.1, ln                     # the image: decoder tile order may still depend on the launch (see above)
 
 
 # ----------------------------------------------------------------------------- cfg3 / cfg4 at full model sizes
