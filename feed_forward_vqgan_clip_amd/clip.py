@@ -90,10 +90,10 @@ class _Block:
         """cloob.py:202-205: x + attn(ln_1(x)); x + mlp(ln_2(x)). x: fp32 residual stream (N, L, D)."""
         f32 = torch.float32
         dh = x.shape[-1] // heads
-        xn, xid = ops.layernorm_fork(x, *self.ln1, cdt)
+        xn, xid = ops.layernorm_fork(x, *self.ln1, cdt, f8_for=self.in_proj)       # fp8 tower: LN writes the e4m3 operand of its linear
         o = ops.attention(ops.linear(xn, self.in_proj), heads, dh ** -0.5, causal)
         x = ops.linear(o, self.out_proj, residual=xid, out_dtype=f32)
-        xn, xid = ops.layernorm_fork(x, *self.ln2, cdt)
+        xn, xid = ops.layernorm_fork(x, *self.ln2, cdt, f8_for=self.c_fc)
         return ops.mlp(xn, self.c_fc, self.c_proj, self.act, residual=xid, out_dtype=f32)
 
 

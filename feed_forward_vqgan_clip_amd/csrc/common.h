@@ -298,6 +298,29 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- fp8 bytes straight from a producing kernel (delayed per-tensor scaling, the convention of ffvc_fp8_quant: state[0] = scale applied
+// before the conversion, state[1] = running max |value| for the next update).  fmt 0 = OCP e4m3 (saturating at 448), 1 = e5m2 (57344);
+// a NaN stays a NaN.
+__device__ __forceinline__ float f8_sat_(float a, float lim) { return a != a ? a : fminf(fmaxf(a, -lim), lim); }
+__device__ __forceinline__ uint32_t f8_pack4(int fmt, float a, float b, float c, float d) {
+  int r = 0;
+  if (fmt == 0) {
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(f8_sat_(a, 448.0f), f8_sat_(b, 448.0f), r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(f8_sat_(c, 448.0f), f8_sat_(d, 448.0f), r, true);
+  } else {
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(f8_sat_(a, 57344.0f), f8_sat_(b, 57344.0f), r, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(f8_sat_(c, 57344.0f), f8_sat_(d, 57344.0f), r, true);
+  }
+  return (uint32_t)r;
+}
+// fold a wave's max |value| into state[1]: same-address atomics serialise in L2, so a wave whose maximum is not above what is already
+// there (a plain, possibly stale read: the value only grows) skips it — after the first few waves almost all do
+__device__ __forceinline__ void f8_amax_wave(float m, float* __restrict__ state) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.0f && !(m <= *(volatile float*)(state + 1)))
+    atomicMax((unsigned int*)(state + 1), __float_as_uint(m));      // m >= 0: uint order == float order (a NaN maximum goes through)
+}
+
 // ---- activations ----------------------------------------------------------
 __device__ __forceinline__ float act_gelu(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

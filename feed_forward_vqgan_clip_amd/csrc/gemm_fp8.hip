@@ -397,6 +397,23 @@ __global__ void fp8_update_kernel(float* __restrict__ state, float fmt_max, floa
   state[1] = 0.0f;
 }
 
+// every state of a pool [n][4] whose running amax is set: the update of fp8_update_kernel with the format kept in state[3]
+// (0 = e4m3, 1 = e5m2); states that saw no tensor since their last update (amax 0) keep their scale
+__global__ __launch_bounds__(256) void fp8_update_many_kernel(float* __restrict__ pool, int n, float margin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float* state = pool + 4 * (int64_t)i;
+  const float a = state[1];
+  if (a == 0.0f) return;
+  const float fmt_max = state[3] == 0.0f ? 448.0f : 57344.0f;
+  if (a > 0.0f && isfinite(a)) {
+    const float s = fmt_max / (a * margin);
+    state[0] = s;
+    state[2] = 1.0f / s;
+  }
+  state[1] = 0.0f;
+}
+
 inline int f8_grid(int64_t n) {
   const int64_t g = (n / 8 + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -520,6 +537,13 @@ extern "C" int ffvc_fp8_amax(const void* src, int src_dtype, float* state, int64
 extern "C" int ffvc_fp8_update(float* state, int fmt, float margin, void* stream) {
   FFVC_CHECK_ARG(state && (fmt == 0 || fmt == 1) && margin >= 1.0f, "ffvc_fp8_update: bad args");
   hipLaunchKernelGGL(fp8_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, fmt == 0 ? 448.0f : 57344.0f, margin);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ffvc_fp8_update_many(float* pool, int n, float margin, void* stream) {
+  FFVC_CHECK_ARG(pool && n > 0 && margin >= 1.0f, "ffvc_fp8_update_many: bad args");
+  hipLaunchKernelGGL(fp8_update_many_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pool, n, margin);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -46,9 +46,14 @@ template <int VEC, typename XT, typename YT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int64_t rows, int dim, float eps) {
+                                                     int64_t rows, int dim, float eps, uint8_t* __restrict__ y8 = nullptr,
+                                                     float* __restrict__ f8_state = nullptr, int f8_fmt = 0) {
+  // y8 (VEC == 4, 16-bit YT): the row also leaves as fp8 bytes = saturate(round_YT(y) * f8_state[0]) and f8_state[1] collects
+  // max |round_YT(y)| — exactly what ffvc_fp8_quant would produce from y; y itself may then be NULL
   constexpr int NIT = LN_MAXE / VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float f8s = y8 ? f8_state[0] : 0.0f;
+  float f8m = 0.0f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const XT* xr = x + row * dim;
     float v[LN_MAXE];
@@ -86,7 +91,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
         ld_vec<VEC>(beta + idx, b);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = (v[k * VEC + j] - mu) * rs * g[j] + b[j];
-        st_vec<VEC>(yr + idx, o);
+        if (y) st_vec<VEC>(yr + idx, o);
+        if constexpr (VEC == 4 && sizeof(YT) == 2) {
+          if (y8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              o[j] = lo_round<YT>(o[j]);
+              f8m = fmaxf(f8m, fabsf(o[j]));
+            }
+            *(uint32_t*)(y8 + row * dim + idx) = f8_pack4(f8_fmt, o[0] * f8s, o[1] * f8s, o[2] * f8s, o[3] * f8s);
+          }
+        }
       }
     }
     if (lane == 0) {
@@ -94,6 +109,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
       rstd[row] = rs;
     }
   }
+  if (y8) f8_amax_wave(f8m, f8_state);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma.
@@ -467,7 +483,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta, const double* __restrict__ ws,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int HW,
                                                        int C, int G, int nch, float eps, int swish,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, uint8_t* __restrict__ y8 = nullptr,
+                                                       float* __restrict__ f8_state = nullptr, int f8_fmt = 0) {
+  // y8 (16-bit T): the output also leaves as fp8 bytes (see ln_fwd_kernel); y may then be NULL — the operand of an fp8 convolution
+  // straight from the normalisation pass, 3 bytes per element over HBM instead of 4 + 3
   constexpr int EPC = ElemTraits<T>::kPerChunk;
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
@@ -481,15 +500,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
   const int cpr = C / EPC, rpp = 256 / cpr;
   const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
-  if (rr >= rpp) return;
   float sc[EPC], sh[EPC];
 #pragma unroll
   for (int j = 0; j < EPC; ++j) {
-    const int c = cc * EPC + j, g = c / cpg;
+    const int c = (cc * EPC + j) % C, g = c / cpg;
     sc[j] = gamma[c] * s_rstd[g];
     sh[j] = beta[c] - s_mean[g] * sc[j];
   }
-  const int p0 = blockIdx.x * rows_per_block, p1 = min(HW, p0 + rows_per_block);
+  const float f8s = y8 ? f8_state[0] : 0.0f;
+  float f8m = 0.0f;
+  const int p0 = blockIdx.x * rows_per_block, p1 = rr < rpp ? min(HW, p0 + rows_per_block) : 0;
   for (int p = p0 + rr; p < p1; p += rpp) {
     const int64_t off = ((int64_t)b * HW + p) * C + cc * EPC;
     if constexpr (EPC == 8) {
@@ -499,7 +519,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         const float u = v.v[j] * sc[j] + sh[j];
         v.v[j] = swish ? act_swish_t<T>(u) : u;
       }
-      store8s(y + off, v);
+      if (y) store8s(y + off, v);
+      if (y8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v.v[j] = lo_round<T>(v.v[j]);
+          f8m = fmaxf(f8m, fabsf(v.v[j]));
+        }
+        u32x2_t o;
+        o[0] = f8_pack4(f8_fmt, v.v[0] * f8s, v.v[1] * f8s, v.v[2] * f8s, v.v[3] * f8s);
+        o[1] = f8_pack4(f8_fmt, v.v[4] * f8s, v.v[5] * f8s, v.v[6] * f8s, v.v[7] * f8s);
+        __builtin_nontemporal_store(o, (u32x2_t*)(y8 + off));
+      }
     } else {
       f32x4_t v = load4(x + off);
 #pragma unroll
@@ -510,6 +541,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       store4(y + off, v);
     }
   }
+  if (y8) f8_amax_wave(f8m, f8_state);
 }
 
 // Backward pass 1: per group S1 = sum dxh, S2 = sum dxh * xh, with dxh = dy * swish'(u) * gamma.
@@ -596,7 +628,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ rstd,
                                                            const double* __restrict__ ws, const T* __restrict__ dres,
                                                            T* __restrict__ dx, int HW, int C, int G, int nch,
-                                                           int swish, int rows_per_block) {
+                                                           int swish, int rows_per_block, uint8_t* __restrict__ dx8 = nullptr,
+                                                           float* __restrict__ f8_state = nullptr, int f8_fmt = 1) {
+  // dx8 (16-bit T): the gradient also leaves as fp8 bytes for the producing convolution's dgrad (see gn_apply_kernel); dx may be NULL
   constexpr int EPC = ElemTraits<T>::kPerChunk;
   __shared__ float s_1[64], s_2[64];
   const int b = blockIdx.y;
@@ -615,11 +649,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   __syncthreads();
   const int cpr = C / EPC, rpp = 256 / cpr;
   const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
-  if (rr >= rpp) return;
   float gm[EPC], bt[EPC], mu[EPC], rs[EPC], m1[EPC], m2[EPC];
 #pragma unroll
   for (int j = 0; j < EPC; ++j) {
-    const int c = cc * EPC + j, g = c / cpg;
+    const int c = (cc * EPC + j) % C, g = c / cpg;
     gm[j] = gamma[c];
     bt[j] = beta[c];
     mu[j] = mean[b * G + g];
@@ -627,7 +660,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     m1[j] = s_1[g];
     m2[j] = s_2[g];
   }
-  const int p0 = blockIdx.x * rows_per_block, p1 = min(HW, p0 + rows_per_block);
+  const float f8s = dx8 ? f8_state[0] : 0.0f;
+  float f8m = 0.0f;
+  const int p0 = blockIdx.x * rows_per_block, p1 = rr < rpp ? min(HW, p0 + rows_per_block) : 0;
   for (int p = p0 + rr; p < p1; p += rpp) {
     const int64_t off = ((int64_t)b * HW + p) * C + cc * EPC;
     float dv[EPC], xv[EPC], rv[EPC];
@@ -671,12 +706,24 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
       f32x8 w;
 #pragma unroll
       for (int j = 0; j < 8; ++j) w.v[j] = o[j];
-      store8s(dx + off, w);
+      if (dx) store8s(dx + off, w);
+      if (dx8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o[j] = lo_round<T>(o[j]);
+          f8m = fmaxf(f8m, fabsf(o[j]));
+        }
+        u32x2_t q;
+        q[0] = f8_pack4(f8_fmt, o[0] * f8s, o[1] * f8s, o[2] * f8s, o[3] * f8s);
+        q[1] = f8_pack4(f8_fmt, o[4] * f8s, o[5] * f8s, o[6] * f8s, o[7] * f8s);
+        __builtin_nontemporal_store(q, (u32x2_t*)(dx8 + off));
+      }
     } else {
       f32x4_t w = {o[0], o[1], o[2], o[3]};
       store4(dx + off, w);
     }
   }
+  if (dx8) f8_amax_wave(f8m, f8_state);
 }
 
 // Backward in ONE pass over HBM (round 4): 2 reads (dy, x) + 1 write (dx) (+ dres) instead of the 4 + 1 of the two kernels above.
@@ -935,6 +982,31 @@ extern "C" int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma
                   hipLaunchKernelGGL((ln_fwd_kernel<1, XT, YT>), dim3(grid), dim3(256), 0, st, (const XT*)x, gamma,
                                      beta, (YT*)y, mean, rstd, rows, dim, eps);
               }));
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+// LayerNorm whose output (also) leaves as fp8 bytes for the fp8 GEMM that consumes it: y8 = saturate(round_16(y) * f8_state[0]), f8_state[1]
+// collects max |round_16(y)| — byte for byte what ffvc_fp8_quant makes of y (delayed per-tensor scaling).  y may be NULL (fp8 only).
+extern "C" int ffvc_layernorm_fwd_f8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, void* y8,
+                                     float* f8_state, int f8_fmt, float* mean, float* rstd, int64_t rows, int dim, float eps,
+                                     void* stream) {
+  FFVC_CHECK_ARG(x && gamma && beta && y8 && f8_state && mean && rstd, "ffvc_layernorm_fwd_f8: null pointer");
+  FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE && dim % 4 == 0, "ffvc_layernorm_fwd_f8: dim=%d unsupported (multiple of 4, max %d)",
+                 dim, 64 * LN_MAXE);
+  FFVC_CHECK_ARG(y_dtype == FFVC_F16 || y_dtype == FFVC_BF16, "ffvc_layernorm_fwd_f8: the rounding type of y must be f16 or bf16");
+  FFVC_CHECK_ARG(f8_fmt == 0 || f8_fmt == 1, "ffvc_layernorm_fwd_f8: f8_fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG(((uintptr_t)y8 % 4) == 0, "ffvc_layernorm_fwd_f8: misaligned y8");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_rows(rows);
+  DISPATCH_DT(x_dtype, XT, {
+    if (y_dtype == FFVC_F16)
+      hipLaunchKernelGGL((ln_fwd_kernel<4, XT, f16_t>), dim3(grid), dim3(256), 0, st, (const XT*)x, gamma, beta, (f16_t*)y, mean, rstd, rows,
+                         dim, eps, (uint8_t*)y8, f8_state, f8_fmt);
+    else
+      hipLaunchKernelGGL((ln_fwd_kernel<4, XT, uint16_t>), dim3(grid), dim3(256), 0, st, (const XT*)x, gamma, beta, (uint16_t*)y, mean, rstd,
+                         rows, dim, eps, (uint8_t*)y8, f8_state, f8_fmt);
+  });
   FFVC_LAUNCH_CHECK();
   return 0;
 }
@@ -1216,6 +1288,66 @@ extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* ga
                        beta, mean, rstd, (double*)ws, HW, C, G, swish, rpc);
     hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
                        beta, mean, rstd, (const double*)ws, (const T*)dres, (T*)dx, HW, C, G, nch, swish, rpb);
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+// GroupNorm (+ swish) whose output (also) leaves as fp8 bytes — the operand of the fp8 3x3 convolution that follows (see
+// ffvc_layernorm_fwd_f8 for the byte contract).  sums != NULL: the moments come from the producing GEMM (ffvc_groupnorm_fwd_sums), ws
+// is not used.  y may be NULL.  16-bit tensors only.
+extern "C" int ffvc_groupnorm_fwd_f8(const void* x, void* y, void* y8, float* f8_state, int f8_fmt, const float* gamma, const float* beta,
+                                     float* mean, float* rstd, void* ws, const double* sums, int B, int HW, int C, int G, float eps,
+                                     int swish, int dtype, void* stream) {
+  FFVC_CHECK_ARG(x && y8 && f8_state && gamma && beta && mean && rstd && (ws || sums), "ffvc_groupnorm_fwd_f8: null pointer");
+  FFVC_CHECK_ARG(dtype == FFVC_F16 || dtype == FFVC_BF16, "ffvc_groupnorm_fwd_f8: 16-bit tensors only");
+  FFVC_CHECK_ARG(f8_fmt == 0 || f8_fmt == 1, "ffvc_groupnorm_fwd_f8: f8_fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG(((uintptr_t)y8 % 8) == 0, "ffvc_groupnorm_fwd_f8: misaligned y8");
+  if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_fwd_f8")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  int rpc = 0;
+  const int nch = sums ? 1 : gn_chunks(B, HW, &rpc);
+  int bpi = 4096 / (B < 1 ? 1 : B);
+  if (bpi > HW / 64) bpi = HW / 64;
+  if (bpi < 1) bpi = 1;
+  const int rpb = (HW + bpi - 1) / bpi;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    if constexpr (sizeof(T) == 2) {
+      if (!sums) hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)x, (double*)ws, HW, C, G, rpc);
+      hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta,
+                         sums ? sums : (const double*)ws, mean, rstd, HW, C, G, nch, eps, swish, rpb, (uint8_t*)y8, f8_state, f8_fmt);
+    }
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+// GroupNorm backward (two-pass form) whose dx (also) leaves as fp8 bytes (e5m2 on the path) for the dgrad of the convolution that
+// produced the normalised tensor.  dx may be NULL.  16-bit tensors only.
+extern "C" int ffvc_groupnorm_bwd_f8(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                                     const float* rstd, const void* dres, void* dx, void* dx8, float* f8_state, int f8_fmt, void* ws,
+                                     int B, int HW, int C, int G, int swish, int dtype, void* stream) {
+  FFVC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx8 && f8_state && ws, "ffvc_groupnorm_bwd_f8: null pointer");
+  FFVC_CHECK_ARG(dtype == FFVC_F16 || dtype == FFVC_BF16, "ffvc_groupnorm_bwd_f8: 16-bit tensors only");
+  FFVC_CHECK_ARG(f8_fmt == 0 || f8_fmt == 1, "ffvc_groupnorm_bwd_f8: f8_fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG(((uintptr_t)dx8 % 8) == 0, "ffvc_groupnorm_bwd_f8: misaligned dx8");
+  if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_bwd_f8")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  int rpc;
+  const int nch = gn_chunks(B, HW, &rpc);
+  int bpi = 4096 / (B < 1 ? 1 : B);
+  if (bpi > HW / 64) bpi = HW / 64;
+  if (bpi < 1) bpi = 1;
+  const int rpb = (HW + bpi - 1) / bpi;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    if constexpr (sizeof(T) == 2) {
+      hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd,
+                         (double*)ws, HW, C, G, swish, rpc);
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd,
+                         (const double*)ws, (const T*)dres, (T*)dx, HW, C, G, nch, swish, rpb, (uint8_t*)dx8, f8_state, f8_fmt);
+    }
   });
   FFVC_LAUNCH_CHECK();
   return 0;

@@ -188,8 +188,10 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args), name)
 
 
-def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
-    """x: (..., dim) fp32|bf16 contiguous -> (y[out_dtype], mean, rstd)."""
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, f8=None, f8_only=False):
+    """x: (..., dim) fp32|bf16 contiguous -> (y[out_dtype], mean, rstd).
+    f8 (an initialised Fp8Scale, 16-bit out_dtype, dim % 4 == 0): -> (y, mean, rstd, y8) with y8 = the fp8 bytes fp8_quant(y, f8) would
+    give; f8_only: y is NOT written (uninitialised) — for the one consumer that takes y8."""
     _req_f32(gamma, beta)
     _need_cuda(x, gamma, beta)
     dim = x.shape[-1]
@@ -197,6 +199,16 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if f8 is not None:
+        if out_dtype not in LOWP or not f8.ready or dim % 4:
+            raise TypeError("layernorm_fwd: fp8 output needs a 16-bit out_dtype, dim % 4 == 0 and an initialised Fp8Scale")
+        fp8_begin(f8)
+        y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        with _hbm("layernorm_fwd", x.numel() * (x.element_size() + 1 + (0 if f8_only else y.element_size()))):
+            _call("ffvc_layernorm_fwd_f8", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(),
+                  0 if f8_only else y.data_ptr(), dtype_code(out_dtype), y8.data_ptr(), f8.state.data_ptr(), f8.fmt, mean.data_ptr(),
+                  rstd.data_ptr(), rows, dim, eps, stream_ptr())
+        return y, mean, rstd, y8
     with _hbm("layernorm_fwd", x.numel() * (x.element_size() + y.element_size())):
         _call("ffvc_layernorm_fwd", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
               dtype_code(out_dtype), mean.data_ptr(), rstd.data_ptr(), rows, dim, eps, stream_ptr())
@@ -266,20 +278,59 @@ E4M3, E5M2 = 0, 1
 FP8_MARGIN = 2.0          # headroom of the delayed scale: next step's values may exceed this step's amax by this factor
 
 
-class Fp8Scale:
-    """Device-resident scale of one tensor stream: state = [scale, running amax, 1/scale, -].  The first use measures the
-    tensor itself (current scaling); afterwards the amax seen while quantising step t sets the scale of step t+1
-    (delayed scaling: no extra pass over the tensor, no host synchronisation)."""
+_F8_POOLS = {}        # device -> list of [buf [1024, 4] fp32, rows handed out]
+_F8_PENDING = []      # scales whose update (amax -> next scale) has not been enqueued yet
 
-    __slots__ = ("state", "fmt", "ready")
+
+class Fp8Scale:
+    """Device-resident scale of one tensor stream: state = [scale, running amax, 1/scale, format code].  The first use measures the
+    tensor itself (current scaling); afterwards the amax seen while quantising step t sets the scale of step t+1
+    (delayed scaling: no extra pass over the tensor, no host synchronisation).  States live in a pool so that ONE launch
+    (fp8_flush_updates, called at the top of a train step) refreshes every stream that saw a tensor."""
+
+    __slots__ = ("state", "fmt", "ready", "pending")
 
     def __init__(self, fmt, device):
-        self.state = torch.zeros(4, dtype=torch.float32, device=device)
-        self.fmt, self.ready = fmt, False
+        device = torch.device(device)
+        pools = _F8_POOLS.setdefault(device, [])
+        if not pools or pools[-1][1] == pools[-1][0].shape[0]:
+            pools.append([torch.zeros(1024, 4, dtype=torch.float32, device=device), 0])
+        buf, n = pools[-1]
+        self.state = buf[n]
+        pools[-1][1] = n + 1
+        self.state[3] = float(fmt)
+        self.fmt, self.ready, self.pending = fmt, False, False
 
     @property
     def inv(self):
         return self.state[2:3]
+
+
+def fp8_begin(sc):
+    """Before a kernel writes fp8 bytes in sc's scale: if the update that folds the previous use's amax into the scale has not been
+    enqueued yet (no fp8_flush_updates since), do it for this stream now."""
+    if sc.pending:
+        _call("ffvc_fp8_update", sc.state.data_ptr(), sc.fmt, FP8_MARGIN, stream_ptr())
+        sc.pending = False
+        try:
+            _F8_PENDING.remove(sc)
+        except ValueError:
+            pass
+
+
+def fp8_flush_updates():
+    """ONE launch per pool: every stream whose running amax is set gets its next scale.  Call where no fp8 tensor is between its producer
+    and its consumer (the top of a step); streams nobody flushes are updated lazily by fp8_begin."""
+    if not _F8_PENDING:
+        return
+    st = stream_ptr()
+    for pools in _F8_POOLS.values():
+        for buf, n in pools:
+            if n:
+                _call("ffvc_fp8_update_many", buf.data_ptr(), n, FP8_MARGIN, st)
+    for sc in _F8_PENDING:
+        sc.pending = False
+    _F8_PENDING.clear()
 
 
 def fp8_quant(x, sc, frozen=False):
@@ -293,15 +344,20 @@ def fp8_quant(x, sc, frozen=False):
         _call("ffvc_fp8_amax", x.data_ptr(), dtype_code(x.dtype), sc.state.data_ptr(), n, st)
         _call("ffvc_fp8_update", sc.state.data_ptr(), sc.fmt, 1.0 if frozen else FP8_MARGIN, st)
         sc.ready = True
+    fp8_begin(sc)
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     _call("ffvc_fp8_quant", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), sc.fmt, sc.state.data_ptr(), n, st)
+    if frozen:
+        sc.state[1].zero_()     # a weight keeps the scale its bytes were written with: leave no amax behind for fp8_flush_updates to fold in
     return out
 
 
 def fp8_next_scale(sc):
-    """Fold the amax accumulated by the last fp8_quant into the scale the next step will use (after the GEMM that
-    consumed this step's scale has been enqueued)."""
-    _call("ffvc_fp8_update", sc.state.data_ptr(), sc.fmt, FP8_MARGIN, stream_ptr())
+    """The GEMM that consumed this step's bytes has been enqueued: the amax accumulated while they were written may become the scale
+    of the next step (enqueued by fp8_flush_updates for all streams at once, or by the stream's next producer)."""
+    if not sc.pending:
+        sc.pending = True
+        _F8_PENDING.append(sc)
 
 
 def conv_fp8_ok(B, H, W, Cin, Cout):
@@ -334,6 +390,7 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
     if out_scale is not None:
         if y.dtype != torch.uint8 or not out_scale.ready:
             raise TypeError("gemm_fp8: fp8 output needs a uint8 y and an initialised Fp8Scale")
+        fp8_begin(out_scale)
         d.y8_state, d.y8_fmt = out_scale.state.data_ptr(), out_scale.fmt
     elif y.dtype == torch.float32:
         flags |= F_OUT_F32
@@ -389,8 +446,11 @@ def gn_sums_buffer(images, G, device):
     return torch.zeros(images, G, 2, dtype=torch.float64, device=device)
 
 
-def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None):
-    """x: NHWC (B, H, W, C) -> (y, mean[B,G], rstd[B,G]).  sums: moments already accumulated by the producer GEMM."""
+def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None, f8=None, f8_only=False):
+    """x: NHWC (B, H, W, C) -> (y, mean[B,G], rstd[B,G]).  sums: moments already accumulated by the producer GEMM.
+    f8 (an initialised Fp8Scale, 16-bit x): -> (y, mean, rstd, y8) where y8 holds the output as fp8 bytes in f8's scale (what fp8_quant(y, f8)
+    would give); f8_only: y is NOT written (an uninitialised tensor is returned in its place — only for a caller that hands y8 to the
+    one consumer)."""
     _req_f32(gamma, beta)
     _need_cuda(x)
     _need_cuda(x, gamma, beta)
@@ -399,6 +459,20 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None):
     y = torch.empty_like(x)
     mean = torch.empty(B, G, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    if f8 is not None:
+        if x.dtype not in LOWP or not f8.ready:
+            raise TypeError("groupnorm_fwd: fp8 output needs a 16-bit tensor and an initialised Fp8Scale")
+        if sums is not None and (sums.dtype != torch.float64 or tuple(sums.shape) != (B, G, 2)):
+            raise TypeError("groupnorm_fwd: sums must be fp64 [B, G, 2]")
+        fp8_begin(f8)
+        y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        ws = None if sums is not None else _gn_ws(B, HW, G, x.device)
+        nb = x.numel() * x.element_size()
+        with _hbm("groupnorm_fwd", (nb if f8_only else 2 * nb) + x.numel() + (0 if sums is not None else nb)):
+            _call("ffvc_groupnorm_fwd_f8", x.data_ptr(), 0 if f8_only else y.data_ptr(), y8.data_ptr(), f8.state.data_ptr(), f8.fmt,
+                  gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(ws), _ptr(sums), B, HW, C, G, eps, int(swish),
+                  dtype_code(x.dtype), stream_ptr())
+        return y, mean, rstd, y8
     if sums is not None:
         if sums.dtype != torch.float64 or tuple(sums.shape) != (B, G, 2):
             raise TypeError("groupnorm_fwd: sums must be fp64 [B, G, 2]")
@@ -412,7 +486,9 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None):
     return y, mean, rstd
 
 
-def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True):
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True, f8=None, f8_only=False):
+    """f8 (an initialised Fp8Scale, 16-bit tensors): -> (dx, dx8), the gradient also as fp8 bytes in f8's scale (what fp8_quant(dx, f8)
+    would give); f8_only: dx is not written (uninitialised)."""
     _req_f32(gamma, beta, mean, rstd)
     _need_cuda(dy, x, dres)
     _need_cuda(dy, x)
@@ -420,6 +496,17 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True):
     HW = x.numel() // (B * C)
     dx = torch.empty_like(x)
     ws = _gn_ws(B, HW, G, x.device)
+    if f8 is not None:
+        if x.dtype not in LOWP or not f8.ready:
+            raise TypeError("groupnorm_bwd: fp8 output needs 16-bit tensors and an initialised Fp8Scale")
+        fp8_begin(f8)
+        dx8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        nb = x.numel() * x.element_size()
+        with _hbm("groupnorm_bwd", nb * (4 + (0 if f8_only else 1) + (1 if dres is not None else 0)) + x.numel()):
+            _call("ffvc_groupnorm_bwd_f8", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  _ptr(dres), 0 if f8_only else dx.data_ptr(), dx8.data_ptr(), f8.state.data_ptr(), f8.fmt, ws.data_ptr(), B, HW, C, G,
+                  int(swish), dtype_code(x.dtype), stream_ptr())
+        return dx, dx8
     # algorithmic bytes of the two-pass backward: statistics (dy, x) + apply (dy, x, dres, dx)
     with _hbm("groupnorm_bwd", x.numel() * x.element_size() * (5 + (1 if dres is not None else 0))):
         _call("ffvc_groupnorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),

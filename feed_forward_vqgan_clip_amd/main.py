@@ -485,6 +485,7 @@ class TrainStep:
 
     def _loss_from_feats(self, inp_feats, out_feats_in=None, facs=None, noise=None, aug_params=None, noise_vec_in=None, force_idx=None):
         """forward_loss behind the text tower: everything from the prompt features on (the part a captured step replays)."""
+        K.fp8_flush_updates()           # fp8 tower / decoder: last step's amax -> this step's scales, one launch for all tensor streams
         raw = inp_feats
         if self.normalize_input:
             inp_feats = torch.nn.functional.normalize(inp_feats, dim=1)         # :734-735

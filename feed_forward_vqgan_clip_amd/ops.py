@@ -15,7 +15,10 @@ Conventions
   * producer -> consumer hints ride on the tensor OBJECT (autograd hands the same Python object from one
     Function to the next): `t._ffvc_lo` = bf16 copy of an fp32 gradient written by LayerNorm backward (picked up
     by `_as`), `t._ffvc_gn` = GroupNorm moments accumulated by the GEMM that produced `t` (picked up by
-    `_GNForkFn`).  A consumer that does not find the attribute (a view, a clone) simply does the work itself.
+    `_GNForkFn`), `t._ffvc_f8` = (fp8 bytes of t, their Fp8Scale, only) written by the normalisation kernel that produced t for the
+    fp8 GEMM / convolution named as its consumer (`only`: the 16-bit t itself was NOT written — a consumer that cannot take the bytes
+    raises), `t._ffvc_gsc` = the e5m2 gradient scale of the fp8 convolution that produced t (its GroupNorm's backward then writes the
+    gradient as fp8 bytes too).  A consumer that does not find the attribute (a view, a clone) simply does the work itself.
 """
 import math
 import os
@@ -196,6 +199,19 @@ def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
 
 
 _LN_LO = os.environ.get("FFVC_LN_LO", "1") != "0"      # A/B switch for the fused bf16 gradient copy
+_F8_PRODUCER = os.environ.get("FFVC_FP8_PRODUCER", "1") != "0"   # A/B switch: LayerNorm / GroupNorm write the fp8 operand of their consumer
+
+
+def _f8_twin(t, sc):
+    """The fp8 bytes of `t` in scale `sc` if its producer wrote them, else None (and a tensor that exists ONLY as such bytes must
+    not reach a consumer that would read its 16-bit values)."""
+    tw = getattr(t, "_ffvc_f8", None)
+    if tw is not None and sc is not None and tw[1] is sc:
+        return tw[0]
+    if tw is not None and tw[2]:
+        raise RuntimeError("a tensor whose producer wrote only its fp8 bytes reached a consumer that cannot use them "
+                           "(FFVC_FP8_PRODUCER=0 disables the producer-side quantisation)")
+    return None
 _ACTGRAD = os.environ.get("FFVC_ACTGRAD", "1") != "0"  # A/B switch: MLPs keep act'(pre) instead of pre (16-bit modes)
 
 
@@ -247,10 +263,13 @@ class _LinearFn(Function):
             K.dropout(y, ctx.drop[0], ctx.drop[1], residual=residual, out=y)
         elif W.fp8 is not None and not gn_hw and x.dtype in K.LOWP:
             f = W.fp8                  # fp8 MFMA path of a frozen layer: quantise the activation, per-tensor delayed scale
-            x8 = K.fp8_quant(x, f["x"])
+            x8 = _f8_twin(x, f["x"])
+            if x8 is None:
+                x8 = K.fp8_quant(x, f["x"])
             K.gemm_fp8(x8, f["sh"], y, rows, W.N, W.K, f["x"], f["w"], lo_dtype=cdt, bias=W.bias, residual=residual)
             K.fp8_next_scale(f["x"])
         else:
+            _f8_twin(x, None)
             sums = _gn_request(gn_hw > 0, y, rows // gn_hw if gn_hw else 0, gn_hw, W.N)
             K.gemm(x, W.sh, y, rows, W.N, W.K, ldx=W.K, ldw=W.K, bias=W.bias, residual=residual,
                    gn_sums=None if sums is None else (sums, gn_hw, W.N // 32))
@@ -312,7 +331,9 @@ class _MLPFn(Function):
                 W2.fp8["x"].ready and W1.N % 8 == 0)
         if ctx.fp8:
             f1 = W1.fp8
-            x8 = K.fp8_quant(x, f1["x"])
+            x8 = _f8_twin(x, f1["x"])
+            if x8 is None:
+                x8 = K.fp8_quant(x, f1["x"])
             if fuse:
                 h8 = torch.empty(h_pre.shape, dtype=torch.uint8, device=x.device)
                 K.gemm_fp8(x8, f1["sh"], h8, rows, W1.N, W1.K, f1["x"], f1["w"], lo_dtype=cdt, bias=W1.bias, act=act, aux=h_pre,
@@ -322,6 +343,7 @@ class _MLPFn(Function):
                            ldaux=W1.N, flags=K.F_WRITE_PREACT | ctx.ag)
             K.fp8_next_scale(f1["x"])
         else:
+            _f8_twin(x, None)
             K.gemm(x, W1.sh, h, rows, W1.N, W1.K, ldx=W1.K, ldw=W1.K, bias=W1.bias, act=act, aux=h_pre, ldaux=W1.N,
                    flags=K.F_WRITE_PREACT | ctx.ag)
         y = torch.empty(*x.shape[:-1], W2.N, dtype=out_dtype or cdt, device=x.device)
@@ -509,10 +531,18 @@ def token_mlp(xn, W1, W2, residual=None, out_dtype=None, drop=0.0):
 # ---------------------------------------------------------------------------
 class _LNForkFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, out_dtype, eps):
+    def forward(ctx, x, gamma, beta, out_dtype, eps, f8_for=None):
         x = _contig(x)
         g, b = gamma.detach(), beta.detach()
-        y, mean, rstd = K.layernorm_fwd(x, g, b, out_dtype, eps)
+        f8 = None
+        if (f8_for is not None and _F8_PRODUCER and getattr(f8_for, "fp8", None) is not None and out_dtype in K.LOWP and
+                x.shape[-1] % 4 == 0 and f8_for.fp8["x"].ready):
+            f8 = f8_for.fp8["x"]       # the one consumer is a frozen fp8 linear: its operand leaves this kernel as e4m3 bytes, y is not written
+        if f8 is not None:
+            y, mean, rstd, y8 = K.layernorm_fwd(x, g, b, out_dtype, eps, f8=f8, f8_only=True)
+            y._ffvc_f8 = (y8, f8, True)
+        else:
+            y, mean, rstd = K.layernorm_fwd(x, g, b, out_dtype, eps)
         ctx.save_for_backward(x, g, mean, rstd)
         ctx.train = gamma.requires_grad
         # parameters that live in a ParamArena get their gradients accumulated straight into the flat bucket
@@ -525,7 +555,7 @@ class _LNForkFn(Function):
     def backward(ctx, dy, dres):
         x, g, mean, rstd = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None, None
+            return dres, None, None, None, None, None
         dy = _contig(dy)
         if dres is not None:
             dres = _as(_contig(dres), x.dtype)
@@ -535,14 +565,16 @@ class _LNForkFn(Function):
             gamma, beta = ctx.params
             dx = K.layernorm_bwd_acc(dy, x, g, mean, rstd, _grad_buf(gamma), _grad_buf(beta), dres=dres, want_lo=lo)
             gamma._ffvc_arena.grad_written(gamma, beta)
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=ctx.train, want_lo=lo)
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
-def layernorm_fork(x, gamma, beta, out_dtype, eps=1e-5):
-    """-> (LN(x) in out_dtype, identity alias of x whose gradient is fused into LN's backward)."""
-    return _LNForkFn.apply(x, gamma, beta, out_dtype, eps)
+def layernorm_fork(x, gamma, beta, out_dtype, eps=1e-5, f8_for=None):
+    """-> (LN(x) in out_dtype, identity alias of x whose gradient is fused into LN's backward).
+    f8_for: the frozen fp8 `Weights` pack of the ONE layer that consumes LN(x) (linear / mlp): once its activation scale exists the
+    kernel writes that layer's e4m3 operand itself and skips the 16-bit output."""
+    return _LNForkFn.apply(x, gamma, beta, out_dtype, eps, f8_for)
 
 
 def layernorm(x, gamma, beta, out_dtype, eps=1e-5):
@@ -554,14 +586,25 @@ def layernorm(x, gamma, beta, out_dtype, eps=1e-5):
 # ---------------------------------------------------------------------------
 class _GNForkFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, swish):
+    def forward(ctx, x, gamma, beta, swish, f8_for=None, grad_sole=False):
         x = _contig(x)
         sums = getattr(x, "_ffvc_gn", None)          # moments accumulated by the GEMM that produced x
         if sums is not None and tuple(sums.shape) != (x.shape[0], 32, 2):
             sums = None
-        y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish, sums=sums)
+        f8 = None
+        if (f8_for is not None and _F8_PRODUCER and f8_for.fp8 is not None and x.dtype in K.LOWP and x.dim() == 4 and
+                f8_for.fp8["x"].ready and K.conv_fp8_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], f8_for.Cout)):
+            f8 = f8_for.fp8["x"]       # the one consumer is an fp8 convolution: its e4m3 operand leaves this kernel, y is not written
+        if f8 is not None:
+            y, mean, rstd, y8 = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish, sums=sums, f8=f8, f8_only=True)
+            y._ffvc_f8 = (y8, f8, True)
+        else:
+            y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish, sums=sums)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.swish = swish
+        # x came out of an fp8 convolution whose dgrad wants this node's gradient as e5m2 bytes
+        ctx.gsc = getattr(x, "_ffvc_gsc", None) if _F8_PRODUCER else None
+        ctx.grad_sole = bool(grad_sole)
         ctx.set_materialize_grads(False)
         return y, x.view_as(x)
 
@@ -569,16 +612,27 @@ class _GNForkFn(Function):
     def backward(ctx, dy, dres):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None
+            return dres, None, None, None, None, None
+        _f8_twin(dy, None)
         dy = _as(_contig(dy), x.dtype)
         if dres is not None:
+            _f8_twin(dres, None)
             dres = _as(_contig(dres), x.dtype)
-        dx = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=dres, G=32, swish=ctx.swish)
-        return dx, None, None, None
+        gsc = ctx.gsc
+        if gsc is not None and gsc.ready and x.dtype in K.LOWP:
+            only = ctx.grad_sole and dres is None        # nothing but that dgrad reads the gradient: skip its 16-bit form
+            dx, dx8 = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=dres, G=32, swish=ctx.swish, f8=gsc, f8_only=only)
+            dx._ffvc_f8 = (dx8, gsc, only)
+        else:
+            dx = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=dres, G=32, swish=ctx.swish)
+        return dx, None, None, None, None, None
 
 
-def groupnorm_fork(x, gamma, beta, swish=True):
-    return _GNForkFn.apply(x, gamma, beta, swish)
+def groupnorm_fork(x, gamma, beta, swish=True, f8_for=None, grad_sole=False):
+    """f8_for: the `ConvWeights` of the ONE 3x3 convolution that consumes the normalised tensor — when that launch will run on the fp8
+    path the kernel writes its e4m3 operand and skips the 16-bit output.  grad_sole: x has no consumer but this node and the
+    identity output is not used, so (x being the output of an fp8 convolution) the gradient may leave as e5m2 bytes only."""
+    return _GNForkFn.apply(x, gamma, beta, swish, f8_for, grad_sole)
 
 
 # ---------------------------------------------------------------------------
@@ -629,12 +683,17 @@ class _Conv3x3Fn(Function):
                   (residual is None or residual.dtype == x.dtype))
         if ctx.f8:
             f = P.fp8                      # e4m3 activation (per-tensor delayed scale) x e4m3 filter on the fp8 row kernel
-            x8 = K.fp8_quant(x, f["x"])
+            x8 = _f8_twin(x, f["x"])       # written by the GroupNorm in front (groupnorm_fork(f8_for=P)), else quantised here
+            if x8 is None:
+                x8 = K.fp8_quant(x, f["x"])
             K.gemm_fp8(x8, f["w8"], y, B * H * W, P.Cout, 9 * Cin, f["x"], f["w"], lo_dtype=x.dtype, bias=P.bias, residual=residual,
                        conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0,
                        gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
             K.fp8_next_scale(f["x"])
+            if P.wd is not None and K.conv_fp8_ok(B, H, W, P.Cout, Cin):
+                y._ffvc_gsc = f["g"]       # this launch's dgrad will run on the fp8 path too: see _GNForkFn.backward
         else:
+            _f8_twin(x, None)
             K.gemm(x, P.w, y, B * H * W, P.Cout, 9 * Cin, ldw=9 * Cin, x_mode=K.OP_CONV3X3, bias=P.bias,
                    residual=residual, conv=(H, W, Cin), flags=K.F_UPSAMPLE2X if upsample else 0,
                    gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
@@ -652,10 +711,15 @@ class _Conv3x3Fn(Function):
             dxu = torch.empty(B, H, W, Cin, dtype=ctx.cdt, device=dy.device)
             if P.wd is not None and ctx.f8 and K.conv_fp8_ok(B, H, W, P.Cout, Cin):
                 f = P.fp8                  # gradients travel as e5m2
-                dy8 = K.fp8_quant(_as(dy, ctx.cdt), f["g"])
+                dy8 = _f8_twin(dy, f["g"])
+                if dy8 is None:
+                    dy8 = K.fp8_quant(_as(dy, ctx.cdt), f["g"])
+                elif ctx.has_res and dy._ffvc_f8[2]:
+                    raise RuntimeError("conv3x3 backward: the skip connection needs the 16-bit gradient, but only its fp8 bytes were written")
                 K.gemm_fp8(dy8, f["wd8"], dxu, B * H * W, Cin, 9 * P.Cout, f["g"], f["w"], lo_dtype=ctx.cdt, conv=(H, W, P.Cout))
                 K.fp8_next_scale(f["g"])
             elif P.wd is not None:
+                _f8_twin(dy, None)
                 dyt = _as(dy, ctx.cdt)
                 K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3,
                        conv=(H, W, P.Cout))

@@ -87,9 +87,10 @@ class _Res:
             self.nin = ops.Weights.frozen(sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"], cdt)
 
     def __call__(self, x):
-        xn, xid = ops.groupnorm_fork(x, *self.n1, True)
+        # fp8 decoder: each norm writes the e4m3 operand of the convolution behind it, and norm2's backward the e5m2 operand of conv1's dgrad
+        xn, xid = ops.groupnorm_fork(x, *self.n1, True, f8_for=self.conv1)
         h = ops.conv3x3(xn, self.conv1, gn=True)                   # -> norm2: moments from the conv epilogue
-        hn, _ = ops.groupnorm_fork(h, *self.n2, True)
+        hn, _ = ops.groupnorm_fork(h, *self.n2, True, f8_for=self.conv2, grad_sole=True)
         sc = xid if self.nin is None else ops.linear(xid, self.nin)
         return ops.conv3x3(hn, self.conv2, residual=sc, gn=True)   # block output -> the next block's norm
 

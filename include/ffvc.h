@@ -177,6 +177,9 @@ int ffvc_gemm_fp8(const ffvc_gemm_desc* d, int x_fmt, int lo_dtype, const float*
 int ffvc_fp8_quant(const void* src, int src_dtype, void* dst, int fmt, float* state, int64_t n, void* stream);
 int ffvc_fp8_amax(const void* src, int src_dtype, float* state, int64_t n, void* stream);
 int ffvc_fp8_update(float* state, int fmt, float margin, void* stream);
+/* ffvc_fp8_update of every state of a contiguous pool [n][4] whose running amax is non-zero (state[3] holds the format code as a float:
+ * 0 e4m3 | 1 e5m2): ONE launch per step instead of one per tensor stream (round 4: 325 launches per cfg5 step). */
+int ffvc_fp8_update_many(float* pool, int n, float margin, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Normalisation / softmax (HBM-bound; fp32 statistics; dtype codes per tensor)
@@ -189,6 +192,12 @@ int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
 /* dx = LN'(dy) (+ dres, same dtype as x/dx).  If part_g/part_b are given they receive
  * ffvc_layernorm_bwd_blocks(rows) partial rows of dgamma/dbeta (reduce with ffvc_colsum).  dx_lo (optional, only with
  * an fp32 dx): a bf16 copy of dx written in the same pass, for the GEMM that consumes this gradient. */
+/* Producer-side quantisation (round 4; the fp8 tower / decoder of BASELINE configs[4], reference main.py:140-143 + cloob.py:170-176):
+ * the normalised row also leaves as fp8 bytes y8 = saturate(round_y_dtype(y) * f8_state[0]) (f8_fmt 0 e4m3 | 1 e5m2) and f8_state[1]
+ * collects max |round_y_dtype(y)| — byte for byte what ffvc_fp8_quant makes of y.  y may be NULL (fp8 output only).  dim % 4 == 0,
+ * y_dtype 16-bit. */
+int ffvc_layernorm_fwd_f8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, void* y8,
+                          float* f8_state, int f8_fmt, float* mean, float* rstd, int64_t rows, int dim, float eps, void* stream);
 int ffvc_layernorm_bwd_blocks(int64_t rows);
 int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                        const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
@@ -232,6 +241,16 @@ int ffvc_groupnorm_fwd_sums(const void* x, void* y, const float* gamma, const fl
 int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                        const float* rstd, const void* dres, void* dx, void* ws, int B, int HW, int C, int G,
                        int swish, int dtype, void* stream);
+
+/* The same two passes with the producer-side quantisation of ffvc_layernorm_fwd_f8 (16-bit tensors): the normalised (+ swish) tensor
+ * is the operand of the fp8 3x3 convolution that follows (sums != NULL: moments from the producing GEMM, ws unused), the input gradient
+ * is the operand of the dgrad of the convolution that produced x.  y / dx may be NULL when only the fp8 bytes are consumed. */
+int ffvc_groupnorm_fwd_f8(const void* x, void* y, void* y8, float* f8_state, int f8_fmt, const float* gamma, const float* beta,
+                          float* mean, float* rstd, void* ws, const double* sums, int B, int HW, int C, int G, float eps, int swish,
+                          int dtype, void* stream);
+int ffvc_groupnorm_bwd_f8(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                          const void* dres, void* dx, void* dx8, float* f8_state, int f8_fmt, void* ws, int B, int HW, int C, int G,
+                          int swish, int dtype, void* stream);
 
 /* Row softmax of fp32 scores: p[r,:cols] = softmax(scale*s[r,:cols]); causal: key j visible to query
  * (r % q_len) iff j <= query (cloob.py:510-516).  Columns [cols, ldp) are zero-filled.

@@ -425,7 +425,8 @@ def test_fp8_quant_matches_torch_float8(cuda, fmt):
     assert torch.equal(q.cpu(), ref.view(torch.uint8).cpu())
     sat = K.fp8_quant(x * 100, sc)                       # stale (delayed) scale -> saturates at the format maximum, no NaN / inf
     assert torch.isfinite(_f8_ref(sat, fmt)).all() and _f8_ref(sat, fmt).abs().max().item() == fmax
-    K.fp8_next_scale(sc)
+    K.fp8_next_scale(sc)                                 # marks the stream; the update itself is enqueued by the flush (or the next producer)
+    K.fp8_flush_updates()
     assert abs(sc.state[0].item() - fmax / ((x * 100).float().abs().max().item() * K.FP8_MARGIN)) < 1e-2 * sc.state[0].item()
     xn = x.clone()
     xn[3, 7] = float("nan")                              # a NaN must stay a NaN (not be clamped to -max and hidden)
@@ -706,3 +707,121 @@ def test_fp8_conv3x3_forward_and_dgrad(cuda, dt, B, Hin, Cin, Cout, ups, res, gn
     x16 = x.clone().requires_grad_(True)
     ops.conv3x3(x16, P16, residual=r, upsample=ups).backward(gy)
     assert _rel(xg.grad, x16.grad.double()) < 8e-2                                   # e5m2 gradients (2 mantissa bits) x e4m3 filter
+
+
+# ----------------------------------------------------------------------------- producer-side quantisation (round 4)
+def _ready_scale(t, fmt):
+    """An initialised scale that has seen `t` once, its update folded in (so the next producer quantises with amax(t))."""
+    sc = K.Fp8Scale(fmt, t.device)
+    K.fp8_quant(t, sc)
+    K.fp8_next_scale(sc)
+    K.fp8_flush_updates()
+    return sc
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,C,use_sums", [(2, 32, 128, False), (3, 16, 256, True), (1, 64, 512, False)])
+def test_groupnorm_writes_the_fp8_operand_of_its_convolution(cuda, dt, B, H, C, use_sums):
+    """ffvc_groupnorm_fwd_f8 / _bwd_f8: the fp8 bytes written by the normalisation pass ARE fp8_quant of the 16-bit tensor the plain
+    kernels write (same scale, same rounding), the running amax is the tensor's, and the 16-bit output may be skipped."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, H, H, C, generator=g) * 2 + 0.3).to(dt).cuda()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).cuda()
+    # the moments: given (as the producing GEMM's epilogue hands them over) -> every launch sees the same statistics and the comparison is
+    # exact; measured by the statistics pass -> its LDS atomics add in a different order per launch, compare with a flip allowance
+    xg = x.double().view(B, H * H, 32, C // 32)
+    sums = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1).contiguous()
+    if not use_sums:
+        y0, _, _ = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, True)
+        sc0 = _ready_scale(y0, K.E4M3)
+        q0 = K.fp8_quant(y0, sc0)
+        _, _, _, y8 = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, True, f8=sc0, f8_only=True)
+        assert (y8 != q0).float().mean().item() < 1e-3
+    y_ref, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, True, sums=sums)
+    sc = _ready_scale(y_ref, K.E4M3)
+    q_ref = K.fp8_quant(y_ref, sc)
+    amax_ref = sc.state[1].item()
+    assert amax_ref == y_ref.float().abs().max().item()
+    for only in (False, True):
+        sc.state[1] = 0.0
+        y, m2, r2, y8 = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, True, sums=sums, f8=sc, f8_only=only)
+        assert torch.equal(y8, q_ref) and sc.state[1].item() == amax_ref
+        assert torch.equal(m2, mean) and torch.equal(r2, rstd)
+        if not only:
+            assert torch.equal(y, y_ref)
+    # backward: dx (+ dres) as e5m2.  The statistics pass combines its partial sums with LDS atomics (order differs per launch), so
+    # the bytes are checked exactly against the 16-bit dx of the SAME launch and with a flip allowance against another launch's
+    dy = (torch.randn(B, H, H, C, generator=g) * 1e-3).to(dt).cuda()
+    dres = (torch.randn(B, H, H, C, generator=g) * 1e-3).to(dt).cuda()
+    for r in (None, dres):
+        dx_ref = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=r, G=32, swish=True)
+        sg = _ready_scale(dx_ref, K.E5M2)
+        q_ref = K.fp8_quant(dx_ref, sg)
+        sg.state[1] = 0.0
+        dx, dx8 = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=r, G=32, swish=True, f8=sg)
+        assert sg.state[1].item() == dx.float().abs().max().item()
+        twin = K.Fp8Scale(K.E5M2, x.device)
+        twin.state.copy_(sg.state)
+        twin.ready = True
+        assert torch.equal(dx8, K.fp8_quant(dx, twin))
+        assert (dx.float() - dx_ref.float()).abs().max().item() <= 2e-2 * dx_ref.float().abs().max().item()
+        _, dx8o = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=r, G=32, swish=True, f8=sg, f8_only=True)
+        assert (dx8o != q_ref).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,dim,xdt", [(514, 1024, torch.float32), (100, 768, torch.float32), (64, 512, None)])
+def test_layernorm_writes_the_fp8_operand_of_its_linear(cuda, dt, rows, dim, xdt):
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(rows, dim, generator=g) * 1.5 + 0.1).to(xdt or dt).cuda()
+    gamma = (1 + 0.2 * torch.randn(dim, generator=g)).cuda()
+    beta = (0.2 * torch.randn(dim, generator=g)).cuda()
+    y_ref, mean, rstd = K.layernorm_fwd(x, gamma, beta, dt)
+    sc = _ready_scale(y_ref, K.E4M3)
+    q_ref = K.fp8_quant(y_ref, sc)
+    amax_ref = sc.state[1].item()
+    for only in (False, True):
+        sc.state[1] = 0.0
+        y, m2, r2, y8 = K.layernorm_fwd(x, gamma, beta, dt, f8=sc, f8_only=only)
+        assert torch.equal(y8, q_ref) and sc.state[1].item() == amax_ref
+        assert torch.equal(m2, mean) and torch.equal(r2, rstd)
+        if not only:
+            assert torch.equal(y, y_ref)
+    with pytest.raises(TypeError):
+        K.layernorm_fwd(x, gamma, beta, torch.float32, f8=sc)
+
+
+def test_fp8_updates_are_batched_and_lazy(cuda):
+    """fp8_next_scale only marks a stream; ONE ffvc_fp8_update_many launch folds every marked stream's amax into its scale, and a
+    stream nobody flushed is updated by its next producer.  Streams that saw no tensor keep their scale."""
+    g = torch.Generator().manual_seed(13)
+    a = torch.randn(64, 64, generator=g).half().cuda()
+    sa, sb, sidle = K.Fp8Scale(K.E4M3, a.device), K.Fp8Scale(K.E5M2, a.device), K.Fp8Scale(K.E4M3, a.device)
+    K.fp8_quant(a, sa), K.fp8_quant(a, sb), K.fp8_quant(a, sidle)
+    K.fp8_next_scale(sidle)
+    K.fp8_flush_updates()
+    idle0 = sidle.state.clone()
+    K.fp8_quant(a * 4, sa), K.fp8_quant(a * 8, sb)
+    s_a0, s_b0 = sa.state[0].item(), sb.state[0].item()
+    K.fp8_next_scale(sa), K.fp8_next_scale(sb)
+    assert sa.state[0].item() == s_a0 and sa.pending and sb.pending          # nothing enqueued yet
+    K.fp8_flush_updates()
+    amax = a.float().abs().max().item()
+    assert abs(sa.state[0].item() - 448.0 / (4 * amax * K.FP8_MARGIN)) < 1e-3 * sa.state[0].item()
+    assert abs(sb.state[0].item() - 57344.0 / (8 * amax * K.FP8_MARGIN)) < 1e-3 * sb.state[0].item()
+    assert sa.state[1].item() == 0 and not sa.pending and not sb.pending
+    idle1 = sidle.state.clone()
+    assert torch.equal(idle1[[0, 2, 3]], idle0[[0, 2, 3]])                   # no tensor since its last update: scale kept
+    sw = K.Fp8Scale(K.E4M3, a.device)                                        # a frozen weight: the flush must never move its scale
+    K.fp8_quant(a.float() * 0.05, sw, frozen=True)
+    w0 = sw.state.clone()
+    K.fp8_next_scale(sa)
+    K.fp8_flush_updates()
+    assert torch.equal(sw.state, w0) and w0[1].item() == 0
+    K.fp8_quant(a * 2, sa)
+    K.fp8_next_scale(sa)
+    q = K.fp8_quant(a * 2, sa)                                               # no flush: the producer enqueues this stream's update itself
+    assert not sa.pending and abs(sa.state[0].item() - 448.0 / (2 * amax * K.FP8_MARGIN)) < 1e-3 * sa.state[0].item()
+    ref = (a.float() * 2 * sa.state[0]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(q.cpu(), ref.view(torch.uint8).cpu())
