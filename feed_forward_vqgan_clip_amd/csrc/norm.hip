@@ -545,16 +545,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // Backward pass 1: per group S1 = sum dxh, S2 = sum dxh * xh, with dxh = dy * swish'(u) * gamma.
-template <typename T>
+// ACC > 0: more workgroups than partial slots (image groups of a few images, see ffvc_groupnorm_bwd): workgroup `chunk` ADDS its totals
+// into slot chunk % ACC of a zeroed ws (fp64 atomics) instead of owning a slot.
+template <typename T, bool ACCUM = false>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, double* __restrict__ ws,
-                                                           int HW, int C, int G, int swish, int rows_per_chunk) {
+                                                           int HW, int C, int G, int swish, int rows_per_chunk, int nslots = 0) {
   constexpr int EPC = ElemTraits<T>::kPerChunk;
   __shared__ float s_1[1024], s_2[1024];
-  const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+  const int b = blockIdx.y, chunk = blockIdx.x, nch = ACCUM ? nslots : gridDim.x;
   const int cpg = C / G;
   const int cpr = C / EPC, rpp = 256 / cpr;
   const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
@@ -613,9 +615,15 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
       t1 += (double)s_1[g * cpg + c];
       t2 += (double)s_2[g * cpg + c];
     }
-    double* o = ws + (((int64_t)b * nch + chunk) * G + g) * 2;
-    o[0] = t1;
-    o[1] = t2;
+    if constexpr (ACCUM) {
+      double* o = ws + (((int64_t)b * nch + (chunk % nch)) * G + g) * 2;
+      atomicAdd(o, t1);
+      atomicAdd(o + 1, t2);
+    } else {
+      double* o = ws + (((int64_t)b * nch + chunk) * G + g) * 2;
+      o[0] = t1;
+      o[1] = t2;
+    }
   }
 }
 
@@ -1274,21 +1282,70 @@ extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* ga
       }
     }
   }
-  int rpc;
-  const int nch = gn_chunks(B, HW, &rpc);
-  // ~4096 workgroups in total (each one re-derives the group statistics from the chunk partials, so tiny
-  // workgroups waste time), at least 64 pixels per workgroup
-  int bpi = 4096 / (B < 1 ? 1 : B);
-  if (bpi > HW / 64) bpi = HW / 64;
-  if (bpi < 1) bpi = 1;
-  const int rpb = (HW + bpi - 1) / bpi;
-  const int nblk = (HW + rpb - 1) / rpb;
-  DISPATCH_DT(dtype, T, {
-    hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
-                       beta, mean, rstd, (double*)ws, HW, C, G, swish, rpc);
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
-                       beta, mean, rstd, (const double*)ws, (const T*)dres, (T*)dx, HW, C, G, nch, swish, rpb);
-  });
+  // Experiment (FFVC_GN_BWD_CHUNK_MB=n, default 0 = off): image groups whose dy + x are at most n MiB, statistics + apply per group, so
+  // that the apply pass finds in the 256 MiB Infinity Cache what the statistics pass just streamed.
+  static int chunk_mb = -1;
+  if (chunk_mb < 0) {
+    const char* e = getenv("FFVC_GN_BWD_CHUNK_MB");
+    chunk_mb = e ? atoi(e) : 0;
+  }
+  const int64_t img = (int64_t)HW * C * (dtype == FFVC_F32 ? 4 : 2);
+  int nb = B;
+  if (chunk_mb > 0) {
+    int64_t k = ((int64_t)chunk_mb << 20) / (2 * img);
+    nb = (int)(k < 1 ? 1 : (k > B ? B : k));
+    if ((int64_t)nb * HW < 16384) nb = B;
+  }
+  if (nb < B) {
+    // few images per launch: 256-pixel workgroups adding into NS replicated slots per (image, group) of a zeroed workspace
+    constexpr int NS = 8;
+    hipError_t me = hipMemsetAsync(ws, 0, (size_t)B * NS * G * 2 * sizeof(double), st);
+    if (me != hipSuccess) {
+      ffvc_set_error("ffvc_groupnorm_bwd: memset failed: %s", hipGetErrorString(me));
+      return (int)me;
+    }
+    const int rpc = 256, nblk_s = (HW + rpc - 1) / rpc;
+    for (int i0 = 0; i0 < B; i0 += nb) {
+      const int Bc = B - i0 < nb ? B - i0 : nb;
+      const char* dyc = (const char*)dy + i0 * img;
+      const char* xc = (const char*)x + i0 * img;
+      const char* drc = dres ? (const char*)dres + i0 * img : nullptr;
+      char* dxc = (char*)dx + i0 * img;
+      const float* mc = mean + (int64_t)i0 * G;
+      const float* rc = rstd + (int64_t)i0 * G;
+      double* wsc = (double*)ws + (int64_t)i0 * NS * G * 2;
+      int bpi = 4096 / Bc;
+      if (bpi > HW / 64) bpi = HW / 64;
+      if (bpi < 1) bpi = 1;
+      const int rpb = (HW + bpi - 1) / bpi;
+      const int nblk = (HW + rpb - 1) / rpb;
+      DISPATCH_DT(dtype, T, {
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<T, true>), dim3(nblk_s, Bc), dim3(256), 0, st, (const T*)dyc, (const T*)xc, gamma, beta, mc,
+                           rc, wsc, HW, C, G, swish, rpc, NS);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, Bc), dim3(256), 0, st, (const T*)dyc, (const T*)xc, gamma, beta, mc, rc,
+                           (const double*)wsc, (const T*)drc, (T*)dxc, HW, C, G, NS, swish, rpb);
+      });
+    }
+    FFVC_LAUNCH_CHECK();
+    return 0;
+  }
+  {
+    int rpc;
+    const int nch = gn_chunks(B, HW, &rpc);
+    // ~4096 workgroups in total (each one re-derives the group statistics from the chunk partials, so tiny
+    // workgroups waste time), at least 64 pixels per workgroup
+    int bpi = 4096 / (B < 1 ? 1 : B);
+    if (bpi > HW / 64) bpi = HW / 64;
+    if (bpi < 1) bpi = 1;
+    const int rpb = (HW + bpi - 1) / bpi;
+    const int nblk = (HW + rpb - 1) / rpb;
+    DISPATCH_DT(dtype, T, {
+      hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                         beta, mean, rstd, (double*)ws, HW, C, G, swish, rpc);
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma,
+                         beta, mean, rstd, (const double*)ws, (const T*)dres, (T*)dx, HW, C, G, nch, swish, rpb);
+    });
+  }
   FFVC_LAUNCH_CHECK();
   return 0;
 }
