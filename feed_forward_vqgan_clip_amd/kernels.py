@@ -278,6 +278,7 @@ E4M3, E5M2 = 0, 1
 FP8_MARGIN = 2.0          # headroom of the delayed scale: next step's values may exceed this step's amax by this factor
 
 
+_FP8_ROWSPLIT = os.environ.get("FFVC_FP8_ROWSPLIT", "1") != "0"    # A/B: 64 x 257-row fp8 GEMMs as 16384 + 64 rows
 _F8_POOLS = {}        # device -> list of [buf [1024, 4] fp32, rows handed out]
 _F8_PENDING = []      # scales whose update (amax -> next scale) has not been enqueued yet
 
@@ -415,8 +416,28 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.ffvc_gemm_fp8(byref(d), sx.fmt, dtype_code(lo_dtype), sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()),
-               "ffvc_gemm_fp8")
+    # ViT-L/14 at 64 cutouts: 16448 = 64 x 257 rows = 64 whole 256-row tiles + 64 rows.  With the tail inside the launch every tile
+    # choice pays for a nearly empty extra round (260 tiles of 256 x 256 on 256 CUs); as two launches the 16384 rows fill whole rounds
+    # and the 64 rows cost one short launch.  Every epilogue option is row-separable (column sums / amax accumulate).
+    # Measured (tools/fp8_rows_bench.py, us, one launch -> 16384 + 64): N=1024 K=1024 42.4 -> 39.0, N=1024 K=3072 85.2 -> 79.3, N=1024 K=4096
+    # 105.1 -> 98.9, N=4096 K=1024 106.5 -> 103.7, but N=3072 K=1024 85.2 -> 95.2 (its fourth round of 12 tiles is cheap, the 64-row launch is
+    # not: 13-26 us of K-loop latency) -> narrow outputs and the 4096-wide one only.
+    M0 = M - M % 256
+    if conv is None and _FP8_ROWSPLIT and M0 >= 8192 and 0 < M - M0 <= 64 and (N <= 1024 or N >= 4096):
+        segs = ((0, M0), (M0, M - M0))
+    else:
+        segs = ((0, M),)
+    base = (d.x, d.y, d.residual, d.aux)
+    for r0, rows in segs:
+        d.M = rows
+        d.x = base[0] + r0 * K
+        d.y = base[1] + r0 * N * y.element_size()
+        if residual is not None:
+            d.residual = base[2] + r0 * N * residual.element_size()
+        if aux is not None:
+            d.aux = base[3] + r0 * ldaux * aux.element_size()
+        _lib.check(lib.ffvc_gemm_fp8(byref(d), sx.fmt, dtype_code(lo_dtype), sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()),
+                   "ffvc_gemm_fp8")
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("conv3x3_fp8" if conv is not None else "gemm_nt_fp8", 2.0 * M * N * K, e0, e1, (M, N, K, 1, 1)))
@@ -845,9 +866,10 @@ def clock_sample():
 
 
 def effective_clock_mhz(c0, c1):
-    """Average engine clock between two clock_sample() results: mean over the XCDs present in both."""
+    """Average engine clock between two clock_sample() results: mean over the XCDs present in both whose counters both advanced (the
+    shader-clock counter of an XCD that was power-gated between the samples restarts: such an XCD says nothing about the region)."""
     a, b = c0.cpu(), c1.cpu()
-    ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1])
+    ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1]) & (b[:, 0] > a[:, 0])
     if not bool(ok.any()):
         return float("nan")
     d = (b - a)[ok].double()

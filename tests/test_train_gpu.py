@@ -551,7 +551,10 @@ def test_clock_sample_reports_a_plausible_engine_clock(cuda):
     torch.cuda.synchronize()
     seen = (c0[:, 1] > 0) & (c1[:, 1] > 0)
     assert int(seen.sum()) >= 1, (c0.tolist(), c1.tolist())
-    assert bool(((c1[:, 0] - c0[:, 0])[seen] > 0).all()) and bool(((c1[:, 1] - c0[:, 1])[seen] > 0).all())
+    assert bool(((c1[:, 1] - c0[:, 1])[seen] > 0).all()), (c0.tolist(), c1.tolist())      # the 100 MHz wall clock never stops
+    # the shader-clock counter of an XCD that idled (power-gated) before the first sample may restart: at least one XCD must have
+    # ticked through, and only those enter the average
+    assert int((((c1[:, 0] - c0[:, 0]) > 0) & seen).sum()) >= 1, (c0.tolist(), c1.tolist())
     mhz = K.effective_clock_mhz(c0, c1)
     assert math.isfinite(mhz) and 1.0 < mhz < 10000.0, (mhz, c0.tolist(), c1.tolist())
 
