@@ -106,6 +106,10 @@ _SIGNATURES = {
     "ffvc_fp8_update_many": (c_int, [c_void_p, c_int, c_float, c_void_p]),
     "ffvc_layernorm_fwd_f8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int64, c_int, c_float, c_void_p]),
+    "ffvc_layernorm_bwd_f8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_int64, c_int, c_void_p]),
+    "ffvc_attn_flash_fwd_f8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_int, c_void_p]),
     "ffvc_groupnorm_fwd_f8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "ffvc_groupnorm_bwd_f8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -91,7 +91,7 @@ class _Block:
         f32 = torch.float32
         dh = x.shape[-1] // heads
         xn, xid = ops.layernorm_fork(x, *self.ln1, cdt, f8_for=self.in_proj)       # fp8 tower: LN writes the e4m3 operand of its linear
-        o = ops.attention(ops.linear(xn, self.in_proj), heads, dh ** -0.5, causal)
+        o = ops.attention(ops.linear(xn, self.in_proj), heads, dh ** -0.5, causal, f8_for=self.out_proj)
         x = ops.linear(o, self.out_proj, residual=xid, out_dtype=f32)
         xn, xid = ops.layernorm_fork(x, *self.ln2, cdt, f8_for=self.c_fc)
         return ops.mlp(xn, self.c_fc, self.c_proj, self.act, residual=xid, out_dtype=f32)

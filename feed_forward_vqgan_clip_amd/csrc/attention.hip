@@ -169,6 +169,31 @@ __device__ __forceinline__ void store_transposed(uint16_t* out, int64_t ld, cons
   }
 }
 
+// The same tile as fp8 bytes: out8[(row0 + 32 bt + lane%32) * ld + 32 dt + i(r)] = fp8(round_L(acc) * scale), 4 bytes per store; m collects
+// max |round_L(acc)| (producer-side quantisation of the attention output for the fp8 out_proj, see ffvc_attn_flash_fwd_f8)
+template <typename L, int NB>
+__device__ __forceinline__ void store_transposed_f8(uint8_t* out8, int64_t ld, const f32x16_t (&acc)[2][NB], int row0, int T, int lane,
+                                                    float scale, int fmt, float& m) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int row = row0 + 32 * b + l31;
+    if (row >= T) continue;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = lo_round<L>(acc[dt][b][4 * g + j]);
+          m = fmaxf(m, fabsf(v[j]));
+        }
+        *(uint32_t*)(out8 + (int64_t)row * ld + 32 * dt + 8 * g + 4 * h) = f8_pack4(fmt, v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+      }
+  }
+}
+
 template <typename L>
 __global__ __launch_bounds__(64) void attn_small_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
                                                            int T, int heads, float scale) {
@@ -633,7 +658,9 @@ struct BlockLoader {                   // 64 rows x 64 features of a [T, ld] mat
 
 template <typename L, bool CAUSAL, int NWV>
 __global__ __launch_bounds__(64 * NWV, 2) void attn_flash2_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
-                                                                   float* __restrict__ lse, int T, int heads, float scale) {
+                                                                   float* __restrict__ lse, int T, int heads, float scale,
+                                                                   uint8_t* __restrict__ o8 = nullptr, float* __restrict__ f8_state = nullptr,
+                                                                   int f8_fmt = 0) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[KPANEL];
   __shared__ __attribute__((aligned(16))) uint16_t Vt[PANEL];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -717,18 +744,22 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_flash2_fwd_kernel(const uint
     }
     lds_product<L, 2, 2>(OT, Vt, ST, 0, lane);
   }
-  if (q0 >= T) return;
+  float f8m = 0.0f;
+  if (q0 < T) {
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const float inv = l[qt] > 0.0f ? 1.0f / l[qt] : 0.0f;
+    for (int qt = 0; qt < 2; ++qt) {
+      const float inv = l[qt] > 0.0f ? 1.0f / l[qt] : 0.0f;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) OT[dt][qt][r] *= inv;
-    const int q = q0 + 32 * qt + l31;
-    if (h == 0 && q < T) lse[(int64_t)bh * T + q] = m[qt] * c + __builtin_amdgcn_logf(l[qt]);
+        for (int r = 0; r < 16; ++r) OT[dt][qt][r] *= inv;
+      const int q = q0 + 32 * qt + l31;
+      if (h == 0 && q < T) lse[(int64_t)bh * T + q] = m[qt] * c + __builtin_amdgcn_logf(l[qt]);
+    }
+    store_transposed<L, 2>(o + (int64_t)b * T * D + hd * 64, D, OT, q0, T, lane);
+    if (o8) store_transposed_f8<L, 2>(o8 + (int64_t)b * T * D + hd * 64, D, OT, q0, T, lane, f8_state[0], f8_fmt, f8m);
   }
-  store_transposed<L, 2>(o + (int64_t)b * T * D + hd * 64, D, OT, q0, T, lane);
+  if (o8) f8_amax_block(f8m, f8_state);      // every wave of the workgroup arrives here (also those past the sequence end)
 }
 
 
@@ -985,24 +1016,24 @@ static int flash_gen() {               // FFVC_FLASH_GEN=1: the one-wave first-g
 
 template <typename L>
 static void flash_fwd_launch(const void* qkv, void* out, float* lse, int B, int T, int heads, float scale, int causal,
-                             hipStream_t st) {
-  if (flash_gen() >= 2) {
+                             hipStream_t st, uint8_t* o8 = nullptr, float* f8_state = nullptr, int f8_fmt = 0) {
+  if (flash_gen() >= 2 || o8) {
     if (T > 320) {         // 4 waves share every key block; short sequences (257 tokens) waste fewer query slots with 2
       const dim3 g4((T + 255) / 256, B * heads);
       if (causal)
         hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, true, 4>), g4, dim3(256), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
-                           T, heads, scale);
+                           T, heads, scale, o8, f8_state, f8_fmt);
       else
         hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, false, 4>), g4, dim3(256), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
-                           T, heads, scale);
+                           T, heads, scale, o8, f8_state, f8_fmt);
     } else {
       const dim3 g2((T + 127) / 128, B * heads);
       if (causal)
         hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, true, 2>), g2, dim3(128), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
-                           T, heads, scale);
+                           T, heads, scale, o8, f8_state, f8_fmt);
       else
         hipLaunchKernelGGL((attn_flash2_fwd_kernel<L, false, 2>), g2, dim3(128), 0, st, (const uint16_t*)qkv, (uint16_t*)out, lse,
-                           T, heads, scale);
+                           T, heads, scale, o8, f8_state, f8_fmt);
     }
     return;
   }
@@ -1061,6 +1092,26 @@ extern "C" int ffvc_attn_flash_fwd(const void* qkv, void* out, void* lse, int dt
     flash_fwd_launch<f16_t>(qkv, out, (float*)lse, B, T, heads, scale, causal, (hipStream_t)stream);
   else
     flash_fwd_launch<uint16_t>(qkv, out, (float*)lse, B, T, heads, scale, causal, (hipStream_t)stream);
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
+// ffvc_attn_flash_fwd whose output ALSO leaves as fp8 bytes out8 [B, T, heads*64] = saturate(round_16(out) * f8_state[0]) (f8_fmt 0 e4m3 |
+// 1 e5m2; f8_state[1] collects max |round_16(out)|): the operand of the fp8 out_proj behind it, byte for byte what ffvc_fp8_quant makes
+// of `out` (which the backward pass still needs in 16 bits).
+extern "C" int ffvc_attn_flash_fwd_f8(const void* qkv, void* out, void* lse, void* out8, float* f8_state, int f8_fmt, int dtype, int B, int T,
+                                      int heads, int head_dim, float scale, int causal, void* stream) {
+  FFVC_CHECK_ARG(dtype == FFVC_BF16 || dtype == FFVC_F16, "ffvc_attn_flash_fwd_f8: 16-bit storage only (dtype %d)", dtype);
+  FFVC_CHECK_ARG(qkv && out && lse && out8 && f8_state && B > 0 && heads > 0 && T > 0, "ffvc_attn_flash_fwd_f8: bad args");
+  FFVC_CHECK_ARG(head_dim == 64, "ffvc_attn_flash_fwd_f8: head_dim must be 64 (got %d)", head_dim);
+  FFVC_CHECK_ARG(f8_fmt == 0 || f8_fmt == 1, "ffvc_attn_flash_fwd_f8: f8_fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG((int64_t)B * heads <= 65535, "ffvc_attn_flash_fwd_f8: B*heads = %lld exceeds the grid limit", (long long)B * heads);
+  FFVC_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)out8 % 4) == 0,
+                 "ffvc_attn_flash_fwd_f8: misaligned pointers");
+  if (dtype == FFVC_F16)
+    flash_fwd_launch<f16_t>(qkv, out, (float*)lse, B, T, heads, scale, causal, (hipStream_t)stream, (uint8_t*)out8, f8_state, f8_fmt);
+  else
+    flash_fwd_launch<uint16_t>(qkv, out, (float*)lse, B, T, heads, scale, causal, (hipStream_t)stream, (uint8_t*)out8, f8_state, f8_fmt);
   FFVC_LAUNCH_CHECK();
   return 0;
 }

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
       rstd[row] = rs;
     }
   }
-  if (y8) f8_amax_wave(f8m, f8_state);
+  if (y8) f8_amax_block(f8m, f8_state);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma.
@@ -233,6 +233,68 @@ __global__ __launch_bounds__(64 * NWB, (MAXE <= 16 ? 4 : 2)) void ln_bwd_kernel(
       }
     }
   }
+}
+
+// LayerNorm backward of a FROZEN layer on the fp32 residual stream (the CLIP towers) whose result is the operand of an fp8 dgrad next:
+// dx = LN'(dy) (+ dres) in fp32 and the same values, rounded to dy's 16-bit type first, as fp8 bytes in the consumer's scale — what
+// ffvc_fp8_quant makes of the 16-bit copy (`dx_lo`) the plain kernel writes for that consumer.  No parameter gradients: the kernel keeps
+// the row in 3 x MAXE registers and nothing else.
+template <typename DYT, int MAXE>
+__global__ __launch_bounds__(256) void ln_bwd_f8_kernel(const DYT* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ dres, float* __restrict__ dx, uint8_t* __restrict__ dx8,
+                                                        float* __restrict__ f8_state, int f8_fmt, int64_t rows, int dim) {
+  constexpr int NIT = MAXE / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float f8s = f8_state[0];
+  float f8m = 0.0f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[MAXE], xh[MAXE], rsd[MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * 4;
+      if (idx < dim) {
+        float d[4], xv[4], gm[4];
+        ld_vec<4>(dy + row * dim + idx, d);
+        ld_vec<4>(x + row * dim + idx, xv);
+        ld_vec<4>(gamma + idx, gm);
+        if (dres) ld_vec<4>(dres + row * dim + idx, &rsd[k * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float h = (xv[j] - mu) * rs;
+          xh[k * 4 + j] = h;
+          g[k * 4 + j] = d[j] * gm[j];
+          s1 += g[k * 4 + j];
+          s2 += g[k * 4 + j] * h;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / dim;
+    s2 = wave_sum(s2) / dim;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * 4;
+      if (idx < dim) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (g[k * 4 + j] - s1 - xh[k * 4 + j] * s2);
+        if (dres) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += rsd[k * 4 + j];
+        }
+        st_vec<4>(dx + row * dim + idx, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = lo_round<DYT>(o[j]);
+          f8m = fmaxf(f8m, fabsf(o[j]));
+        }
+        *(uint32_t*)(dx8 + row * dim + idx) = f8_pack4(f8_fmt, o[0] * f8s, o[1] * f8s, o[2] * f8s, o[3] * f8s);
+      }
+    }
+  }
+  f8_amax_block(f8m, f8_state);
 }
 
 // ------------------------- self-modulated LayerNorm ------------------------
@@ -541,7 +603,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       store4(y + off, v);
     }
   }
-  if (y8) f8_amax_wave(f8m, f8_state);
+  if (y8) f8_amax_block(f8m, f8_state);
 }
 
 // Backward pass 1: per group S1 = sum dxh, S2 = sum dxh * xh, with dxh = dy * swish'(u) * gamma.
@@ -731,7 +793,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
       store4(dx + off, w);
     }
   }
-  if (dx8) f8_amax_wave(f8m, f8_state);
+  if (dx8) f8_amax_block(f8m, f8_state);
 }
 
 // Backward in ONE pass over HBM (round 4): 2 reads (dy, x) + 1 write (dx) (+ dres) instead of the 4 + 1 of the two kernels above.
@@ -1050,6 +1112,38 @@ extern "C" int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, i
                                   const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
                                   float* part_b, void* dx_lo, int64_t rows, int dim, void* stream) {
   return ln_bwd_launch(dy, dy_dtype, x, x_dtype, gamma, mean, rstd, dres, dx, part_g, part_b, rows, dim, stream, 0, dx_lo);
+}
+
+// Frozen-layer LayerNorm backward on the fp32 residual stream with producer-side quantisation (see ln_bwd_f8_kernel): dx fp32 [rows, dim]
+// (+ dres) and dx8 = the fp8 bytes ffvc_fp8_quant would make of round_{dy_dtype}(dx).  dim % 4 == 0, dim <= 2048, dy 16-bit.
+extern "C" int ffvc_layernorm_bwd_f8(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, float* dx, void* dx8, float* f8_state, int f8_fmt, int64_t rows, int dim,
+                                     void* stream) {
+  FFVC_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dx8 && f8_state, "ffvc_layernorm_bwd_f8: null pointer");
+  FFVC_CHECK_ARG(dy_dtype == FFVC_F16 || dy_dtype == FFVC_BF16, "ffvc_layernorm_bwd_f8: dy must be f16 or bf16");
+  FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_bwd_f8: dim=%d unsupported", dim);
+  FFVC_CHECK_ARG(f8_fmt == 0 || f8_fmt == 1, "ffvc_layernorm_bwd_f8: f8_fmt must be 0 (e4m3) or 1 (e5m2)");
+  FFVC_CHECK_ARG(((uintptr_t)dx8 % 4) == 0, "ffvc_layernorm_bwd_f8: misaligned dx8");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t gq = (rows + 3) / 4;
+  const int grid = (int)(gq < 1 ? 1 : (gq > 2048 ? 2048 : gq));
+  if (dy_dtype == FFVC_F16) {
+    if (dim <= 1024)
+      hipLaunchKernelGGL((ln_bwd_f8_kernel<f16_t, 16>), dim3(grid), dim3(256), 0, st, (const f16_t*)dy, x, gamma, mean, rstd, dres, dx,
+                         (uint8_t*)dx8, f8_state, f8_fmt, rows, dim);
+    else
+      hipLaunchKernelGGL((ln_bwd_f8_kernel<f16_t, 32>), dim3(grid), dim3(256), 0, st, (const f16_t*)dy, x, gamma, mean, rstd, dres, dx,
+                         (uint8_t*)dx8, f8_state, f8_fmt, rows, dim);
+  } else {
+    if (dim <= 1024)
+      hipLaunchKernelGGL((ln_bwd_f8_kernel<uint16_t, 16>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy, x, gamma, mean, rstd, dres, dx,
+                         (uint8_t*)dx8, f8_state, f8_fmt, rows, dim);
+    else
+      hipLaunchKernelGGL((ln_bwd_f8_kernel<uint16_t, 32>), dim3(grid), dim3(256), 0, st, (const uint16_t*)dy, x, gamma, mean, rstd, dres, dx,
+                         (uint8_t*)dx8, f8_state, f8_fmt, rows, dim);
+  }
+  FFVC_LAUNCH_CHECK();
+  return 0;
 }
 
 // Per-stream scratch for the parameter-gradient partials of the accumulate form: [workgroups][2 * dim] fp32.  Launches on one

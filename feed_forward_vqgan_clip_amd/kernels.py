@@ -219,8 +219,10 @@ def _dx_lo(x, want_lo, lo_dtype=torch.bfloat16):
     return torch.empty(x.shape, dtype=lo_dtype, device=x.device) if (want_lo and x.dtype == torch.float32) else None
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, want_lo=False):
-    """-> (dx [x.dtype], dgamma|None, dbeta|None).  want_lo: also write a bf16 copy of an fp32 dx (`dx._ffvc_lo`)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, want_lo=False, f8=None):
+    """-> (dx [x.dtype], dgamma|None, dbeta|None).  want_lo: also write a bf16 copy of an fp32 dx (`dx._ffvc_lo`).
+    f8 (an initialised Fp8Scale; frozen layer, fp32 x, 16-bit dy): -> (dx, dx8) with dx8 = the fp8 bytes fp8_quant would make of that
+    16-bit copy, which is then not written."""
     _req_f32(gamma, mean, rstd)
     _need_cuda(dy, x, gamma)
     dim = x.shape[-1]
@@ -228,6 +230,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_param_grads=False, w
     dx = torch.empty_like(x)
     if dres is not None and dres.dtype != x.dtype:
         raise TypeError("layernorm_bwd: dres dtype must equal x dtype")
+    if f8 is not None:
+        if want_param_grads or x.dtype != torch.float32 or dy.dtype not in LOWP or dim % 4 or not f8.ready:
+            raise TypeError("layernorm_bwd: the fp8 form needs a frozen layer, fp32 x, 16-bit dy, dim % 4 == 0 and an initialised Fp8Scale")
+        fp8_begin(f8)
+        dx8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        with _hbm("layernorm_bwd", x.numel() * (dy.element_size() + 8 + (4 if dres is not None else 0) + 1)):
+            _call("ffvc_layernorm_bwd_f8", dy.data_ptr(), dtype_code(dy.dtype), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dx8.data_ptr(), f8.state.data_ptr(), f8.fmt, rows, dim, stream_ptr())
+        return dx, dx8
     pg = pb = None
     lo = _dx_lo(x, want_lo, dy.dtype)
     if want_param_grads:
@@ -1054,12 +1065,21 @@ def attn_flash_ok(qkv, heads):
             os.environ.get("FFVC_ATTN_FLASH", "1") != "0")
 
 
-def attn_flash_fwd(qkv, heads, scale, causal):
-    """-> (out [B,T,heads*64], lse fp32 [B*heads,T])"""
+def attn_flash_fwd(qkv, heads, scale, causal, f8=None):
+    """-> (out [B,T,heads*64], lse fp32 [B*heads,T]).  f8 (an initialised Fp8Scale): -> (out, lse, out8), the output also as the fp8
+    bytes fp8_quant(out, f8) would give."""
     _req(qkv.dtype if qkv.dtype in LOWP else torch.bfloat16, qkv)
     B, T, D3 = qkv.shape
     o = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B * heads, T, dtype=torch.float32, device=qkv.device)
+    if f8 is not None:
+        if not f8.ready:
+            raise TypeError("attn_flash_fwd: fp8 output needs an initialised Fp8Scale")
+        fp8_begin(f8)
+        o8 = torch.empty(o.shape, dtype=torch.uint8, device=qkv.device)
+        _call("ffvc_attn_flash_fwd_f8", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), o8.data_ptr(), f8.state.data_ptr(), f8.fmt,
+              dtype_code(qkv.dtype), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
+        return o, lse, o8
     _call("ffvc_attn_flash_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
           float(scale), int(bool(causal)), stream_ptr())
     return o, lse

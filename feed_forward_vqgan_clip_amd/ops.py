@@ -268,6 +268,8 @@ class _LinearFn(Function):
                 x8 = K.fp8_quant(x, f["x"])
             K.gemm_fp8(x8, f["sh"], y, rows, W.N, W.K, f["x"], f["w"], lo_dtype=cdt, bias=W.bias, residual=residual)
             K.fp8_next_scale(f["x"])
+            if f["sht"] is not None:
+                y._ffvc_gsc = f["g"]       # this layer's dgrad runs on the fp8 path: the LayerNorm behind y may write its e5m2 operand
         else:
             _f8_twin(x, None)
             sums = _gn_request(gn_hw > 0, y, rows // gn_hw if gn_hw else 0, gn_hw, W.N)
@@ -285,13 +287,19 @@ class _LinearFn(Function):
         W, rows = ctx.W, ctx.rows
         cdt = W.sh.dtype
         dy = _contig(dy)
-        dyt = K.dropout(dy, ctx.drop[0], ctx.drop[1], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
+        f = W.fp8
+        dy8 = None
+        if f is not None and f["sht"] is not None and not ctx.drop and not ctx.train and cdt in K.LOWP:
+            dy8 = _f8_twin(dy, f["g"])     # written by the LayerNorm backward that produced dy (frozen fp8 layer: nothing else reads a 16-bit dy)
+        dyt = None
+        if dy8 is None:
+            dyt = K.dropout(dy, ctx.drop[0], ctx.drop[1], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=cdt, device=dy.device)
-            f = W.fp8
-            if f is not None and f["sht"] is not None and not ctx.drop and dyt.dtype in K.LOWP:
-                dy8 = K.fp8_quant(dyt, f["g"])                       # gradients travel as e5m2
+            if dy8 is not None or (f is not None and f["sht"] is not None and not ctx.drop and dyt.dtype in K.LOWP):
+                if dy8 is None:
+                    dy8 = K.fp8_quant(dyt, f["g"])                   # gradients travel as e5m2
                 K.gemm_fp8(dy8, f["sht"], dx, rows, W.K, W.N, f["g"], f["w"], lo_dtype=cdt)
                 K.fp8_next_scale(f["g"])
             else:
@@ -354,6 +362,8 @@ class _MLPFn(Function):
                 h8 = K.fp8_quant(h, f2["x"])
             K.gemm_fp8(h8, f2["sh"], y, rows, W2.N, W2.K, f2["x"], f2["w"], lo_dtype=cdt, bias=W2.bias, residual=residual)
             K.fp8_next_scale(f2["x"])
+            if f2["sht"] is not None and W1.fp8["sht"] is not None:
+                y._ffvc_gsc = f2["g"]      # the LayerNorm behind y may write the e5m2 operand of this block's first dgrad
         elif ctx.drop:    # Linear, act, Dropout, Linear, Dropout (mlp_mixer_pytorch.py:16-23, vitgan.py:36-41), then + residual
             if residual is not None and (residual.dtype != torch.float32 or y.dtype != torch.float32):
                 raise TypeError("mlp(drop>0) with a residual needs the fp32 residual stream")
@@ -375,14 +385,19 @@ class _MLPFn(Function):
         cdt = W1.sh.dtype
         x, h_pre, h = ctx.saved_tensors
         dy = _contig(dy)
-        dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
+        f8_bwd = ctx.fp8 and W2.fp8["sht"] is not None and W1.fp8["sht"] is not None
+        dy8 = _f8_twin(dy, W2.fp8["g"]) if (f8_bwd and not ctx.train) else None     # written by the LayerNorm backward that produced dy
+        dyt = None
+        if dy8 is None:
+            dyt = K.dropout(dy, ctx.drop[0], ctx.drop[2], out_dtype=cdt) if ctx.drop else _as(dy, cdt)
         dh = torch.empty_like(h_pre)
         # the first Linear's bias gradient = column sums of dh: accumulated by the epilogue that writes dh
         b1_fused = (ctx.train and not ctx.drop and W1.bias is not None and W1.bias.requires_grad and
                     K.colsum_fusable(cdt, W2.K, W2.N))
-        if ctx.fp8 and W2.fp8["sht"] is not None and W1.fp8["sht"] is not None:
+        if f8_bwd:
             f1, f2 = W1.fp8, W2.fp8
-            dy8 = K.fp8_quant(dyt, f2["g"])
+            if dy8 is None:
+                dy8 = K.fp8_quant(dyt, f2["g"])
             # the hidden gradient leaves the aux-multiply epilogue as e5m2 once its scale exists (nothing else reads it: frozen layer)
             fuse = _FP8_FUSE and ctx.ag and not ctx.train and ctx.needs_input_grad[0] and f1["g"].ready and W2.K % 8 == 0
             dh8 = None
@@ -544,6 +559,8 @@ class _LNForkFn(Function):
         else:
             y, mean, rstd = K.layernorm_fwd(x, g, b, out_dtype, eps)
         ctx.save_for_backward(x, g, mean, rstd)
+        # x (the residual stream) came out of an fp8 linear / mlp whose dgrad wants this node's gradient as e5m2 bytes
+        ctx.gsc = getattr(x, "_ffvc_gsc", None) if _F8_PRODUCER else None
         ctx.train = gamma.requires_grad
         # parameters that live in a ParamArena get their gradients accumulated straight into the flat bucket
         ctx.params = (gamma, beta) if (ctx.train and getattr(gamma, "_ffvc_arena", None) is not None and
@@ -565,6 +582,12 @@ class _LNForkFn(Function):
             gamma, beta = ctx.params
             dx = K.layernorm_bwd_acc(dy, x, g, mean, rstd, _grad_buf(gamma), _grad_buf(beta), dres=dres, want_lo=lo)
             gamma._ffvc_arena.grad_written(gamma, beta)
+            return dx, None, None, None, None, None
+        gsc = ctx.gsc
+        if gsc is not None and gsc.ready and lo and not ctx.train and x.shape[-1] % 4 == 0:
+            # the 16-bit copy's only reader would be that dgrad's quantiser: write its fp8 bytes instead
+            dx, dx8 = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, f8=gsc)
+            dx._ffvc_f8 = (dx8, gsc, False)
             return dx, None, None, None, None, None
         dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, want_param_grads=ctx.train, want_lo=lo)
         return dx, dg, db, None, None, None
@@ -748,7 +771,7 @@ def _pad8(n):
 
 class _AttentionFn(Function):
     @staticmethod
-    def forward(ctx, qkv, heads, scale, causal):
+    def forward(ctx, qkv, heads, scale, causal, f8_for=None):
         qkv = _contig(qkv)
         B, T, D3 = qkv.shape
         D = D3 // 3
@@ -761,7 +784,14 @@ class _AttentionFn(Function):
         ctx.small = False
         ctx.flash = K.attn_flash_ok(qkv, heads)
         if ctx.flash:       # any length, head dim 64: online-softmax kernel, scores never reach HBM, causal blocks skipped
-            o, lse = K.attn_flash_fwd(qkv, heads, scale, causal)
+            f8 = None
+            if f8_for is not None and _F8_PRODUCER and getattr(f8_for, "fp8", None) is not None and f8_for.fp8["x"].ready:
+                f8 = f8_for.fp8["x"]   # the fp8 out_proj behind: its e4m3 operand leaves the attention epilogue (o stays: the backward reads it)
+            if f8 is not None:
+                o, lse, o8 = K.attn_flash_fwd(qkv, heads, scale, causal, f8=f8)
+                o._ffvc_f8 = (o8, f8, False)
+            else:
+                o, lse = K.attn_flash_fwd(qkv, heads, scale, causal)
             ctx.save_for_backward(qkv, o, lse)
             ctx.cfg = (heads, scale, causal)
             return o
@@ -787,11 +817,11 @@ class _AttentionFn(Function):
         if ctx.small:
             (qkv,) = ctx.saved_tensors
             heads, scale = ctx.cfg
-            return K.attn_small_bwd(qkv, _as(_contig(do), qkv.dtype), heads, scale), None, None, None
+            return K.attn_small_bwd(qkv, _as(_contig(do), qkv.dtype), heads, scale), None, None, None, None
         if ctx.flash:
             qkv, o, lse = ctx.saved_tensors
             heads, scale, causal = ctx.cfg
-            return K.attn_flash_bwd(qkv, o, _as(_contig(do), qkv.dtype), lse, heads, scale, causal), None, None, None
+            return K.attn_flash_bwd(qkv, o, _as(_contig(do), qkv.dtype), lse, heads, scale, causal), None, None, None, None
         qkv, P = ctx.saved_tensors
         B, T, D, heads, dh, Tp, scale = ctx.cfg
         D3, BH, cdt = 3 * D, B * heads, qkv.dtype
@@ -815,11 +845,12 @@ class _AttentionFn(Function):
                yb=bs, y_map=(0, 0, D3))
         K.gemm(dS, q, dk, T, dh, T, ldx=Tp, ldw=D3, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS, batch=BH,
                batch_inner=heads, xb=pb, wb=bs, yb=bs, y_map=(0, 0, D3))
-        return dqkv, None, None, None
+        return dqkv, None, None, None, None
 
 
-def attention(qkv, heads, scale, causal=False):
-    return _AttentionFn.apply(qkv, heads, scale, causal)
+def attention(qkv, heads, scale, causal=False, f8_for=None):
+    """f8_for: the frozen fp8 `Weights` pack of the projection that consumes the result (see layernorm_fork)."""
+    return _AttentionFn.apply(qkv, heads, scale, causal, f8_for)
 
 
 class _AttentionTinyFn(Function):

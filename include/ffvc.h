@@ -198,6 +198,10 @@ int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
  * y_dtype 16-bit. */
 int ffvc_layernorm_fwd_f8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, void* y8,
                           float* f8_state, int f8_fmt, float* mean, float* rstd, int64_t rows, int dim, float eps, void* stream);
+/* Backward of a FROZEN LayerNorm on the fp32 residual stream (the CLIP towers, cloob.py:203-204) whose result feeds an fp8 dgrad: dx fp32
+ * (+ dres) and dx8 = the fp8 bytes ffvc_fp8_quant would make of round_{dy_dtype}(dx); no parameter gradients. */
+int ffvc_layernorm_bwd_f8(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, void* dx8, float* f8_state, int f8_fmt, int64_t rows, int dim, void* stream);
 int ffvc_layernorm_bwd_blocks(int64_t rows);
 int ffvc_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                        const float* mean, const float* rstd, const void* dres, void* dx, float* part_g,
@@ -290,6 +294,10 @@ int ffvc_attn_tiny_bwd(const void* qkv, const void* dout, void* dqkv, int dtype,
  * delta_ws: fp32 [B*heads, T] scratch of the backward (row sums of dO*O).  out is the forward's result. */
 int ffvc_attn_flash_fwd(const void* qkv, void* out, void* lse, int dtype, int B, int T, int heads, int head_dim,
                         float scale, int causal, void* stream);
+/* The forward whose output also leaves as fp8 bytes out8 [B, T, heads*64] (producer-side quantisation for the fp8 out_proj of the ViT-L/14
+ * tower, cloob.py:199-200; byte contract of ffvc_layernorm_fwd_f8).  `out` is still written: the backward reads it. */
+int ffvc_attn_flash_fwd_f8(const void* qkv, void* out, void* lse, void* out8, float* f8_state, int f8_fmt, int dtype, int B, int T,
+                           int heads, int head_dim, float scale, int causal, void* stream);
 int ffvc_attn_flash_bwd(const void* qkv, const void* out, const void* dout, const void* lse, void* delta_ws, void* dqkv,
                         int dtype, int B, int T, int heads, int head_dim, float scale, int causal, void* stream);
 

@@ -792,6 +792,46 @@ def test_layernorm_writes_the_fp8_operand_of_its_linear(cuda, dt, rows, dim, xdt
         K.layernorm_fwd(x, gamma, beta, torch.float32, f8=sc)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,dim,with_res", [(514, 1024, True), (100, 768, False), (70, 1280, True)])
+def test_layernorm_backward_writes_the_fp8_operand_of_the_dgrad(cuda, dt, rows, dim, with_res):
+    """ffvc_layernorm_bwd_f8 (frozen layer, fp32 residual stream): dx is the plain kernel's dx bit for bit, and the fp8 bytes are
+    fp8_quant of the 16-bit copy the plain kernel writes next to it."""
+    g = torch.Generator().manual_seed(14)
+    x = (torch.randn(rows, dim, generator=g) * 1.5 + 0.1).cuda()
+    gamma = (1 + 0.2 * torch.randn(dim, generator=g)).cuda()
+    beta = (0.2 * torch.randn(dim, generator=g)).cuda()
+    _, mean, rstd = K.layernorm_fwd(x, gamma, beta, dt)
+    dy = (torch.randn(rows, dim, generator=g) * 1e-3).to(dt).cuda()
+    dres = (torch.randn(rows, dim, generator=g) * 1e-3).cuda() if with_res else None
+    dx_ref, _, _ = K.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres, want_lo=True)
+    lo = dx_ref._ffvc_lo
+    assert lo.dtype == dt
+    sg = _ready_scale(lo, K.E5M2)
+    q_ref = K.fp8_quant(lo, sg)
+    amax_ref = sg.state[1].item()
+    sg.state[1] = 0.0
+    dx, dx8 = K.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres, f8=sg)
+    assert torch.equal(dx, dx_ref) and torch.equal(dx8, q_ref) and sg.state[1].item() == amax_ref
+    with pytest.raises(TypeError):
+        K.layernorm_bwd(dy, x, gamma, mean, rstd, want_param_grads=True, f8=sg)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,T,heads,causal", [(4, 257, 4, False), (2, 130, 2, False), (2, 600, 2, True)])
+def test_flash_attention_writes_the_fp8_operand_of_out_proj(cuda, dt, B, T, heads, causal):
+    g = torch.Generator().manual_seed(15)
+    qkv = (torch.randn(B, T, 3 * heads * 64, generator=g) * 0.7).to(dt).cuda()
+    o_ref, lse_ref = K.attn_flash_fwd(qkv, heads, 0.125, causal)
+    sc = _ready_scale(o_ref, K.E4M3)
+    q_ref = K.fp8_quant(o_ref, sc)
+    amax_ref = sc.state[1].item()
+    sc.state[1] = 0.0
+    o, lse, o8 = K.attn_flash_fwd(qkv, heads, 0.125, causal, f8=sc)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    assert torch.equal(o8, q_ref) and sc.state[1].item() == amax_ref
+
+
 def test_fp8_updates_are_batched_and_lazy(cuda):
     """fp8_next_scale only marks a stream; ONE ffvc_fp8_update_many launch folds every marked stream's amax into its scale, and a
     stream nobody flushed is updated by its next producer.  Streams that saw no tensor keep their scale."""
