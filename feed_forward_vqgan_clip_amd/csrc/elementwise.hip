@@ -117,12 +117,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   if (vec) {
     const int c = (blockIdx.x * 64 + tx) * 4;
-    if (c < cols)
-      for (int64_t r = r0 + ry; r < r1; r += 4) {
+    if (c < cols) {
+      // eight rows in flight per lane: the loop is a chain of dependent global loads otherwise (one ~2 us round trip per 4 rows), and
+      // hiding that with ~1024 workgroups meant as many fp32 atomics per output column (75 ns each when they hit one address)
+      int64_t r = r0 + ry;
+      for (; r + 28 < r1; r += 32) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = load4(x + (r + 4 * u) * ld + c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += v[u][j];
+      }
+      for (; r < r1; r += 4) {
         const f32x4_t v = load4(x + r * ld + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] += v[j];
       }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[ry][tx * 4 + j] = a[j];
     __syncthreads();
@@ -1119,9 +1132,18 @@ extern "C" int ffvc_colsum(const void* x, int dtype, float* out, int64_t rows, i
   }
   const int es = ffvc_dtype_size(dtype);
   const int vec = (cols % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0);
-  // enough row strips that column-blocks x strips fills the chip (>= ~1024 workgroups), >= 8 rows per strip
+  // row strips: column-blocks x strips workgroups.  Every strip ends in one fp32 atomic per column, and atomics on one address serialise
+  // (~75 ns): 1024 workgroups over 256 columns = 1024 atomics per column = 77 us for an 8 MB tensor (the x-transformer's bias gradients,
+  // rocprofv3 r4: 98 us per call).  With eight loads in flight per lane ~256 workgroups are enough (FFVC_COLSUM_WGS overrides).
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("FFVC_COLSUM_WGS");
+    target = e ? atoi(e) : 256;
+    if (target < 1) target = 1;
+  }
   const int colblocks = ceil_div(cols, vec ? 256 : 64);
-  int64_t strips = (1024 + colblocks - 1) / colblocks;
+  int64_t strips = (target + colblocks - 1) / colblocks;
+  if (strips > 128) strips = 128;                  // <= 128 atomics per column (16384 x 256 f16: 102 us at 1024 strips, 29 at 256, 17 at 128)
   if (strips > rows / 8) strips = rows / 8;
   if (strips < 1) strips = 1;
   const int rpb = (int)((rows + strips - 1) / strips);
