@@ -10,6 +10,7 @@ residual / nearest-2x upsample fused; GroupNorm+swish is one stats + one apply k
 single-head spatial attention is batched GEMMs + a row softmax.
 """
 import math
+import os
 import types
 
 import torch
@@ -73,6 +74,10 @@ def random_state_dict(cfg=F16_16384, seed=1234, codebook_std=1.0):
     norm("decoder.norm_out", block_in)
     conv("decoder.conv_out", block_in, cfg["out_ch"], 3)
     return sd
+
+
+_DEC_STREAMS = int(os.environ.get("FFVC_DEC_STREAMS", "1"))
+_DEC_SIZES = os.environ.get("FFVC_DEC_SIZES", "")     # e.g. "24,40": unequal parts (the parts then drift out of phase)
 
 
 class _Res:
@@ -157,10 +162,38 @@ class VQGAN:
                          sd[d + ".norm_out.bias"].detach().float().cuda().contiguous())
         self.conv_out = ops.ConvWeights(sd[d + ".conv_out.weight"], sd[d + ".conv_out.bias"], cdt)
         self.z_min, self.z_max = float(cb.min()), float(cb.max())      # main.py:645-646,763 use the scalar min/max
+        self._dec_streams = []
 
     # -- NHWC fast path -------------------------------------------------------
     def decode_nhwc(self, z_q):
-        """z_q: (B, S, S, C) compute dtype -> (B, 16S, 16S, 3) fp32 in [-1, 1]-ish (VQModel.decode)."""
+        """z_q: (B, S, S, C) compute dtype -> (B, 16S, 16S, 3) fp32 in [-1, 1]-ish (VQModel.decode).
+        FFVC_DEC_STREAMS=n (experiment, default 1): the batch in n parts, each on its own HIP stream (forward AND backward: autograd
+        replays a node on its forward stream), so that one part's HBM-bound GroupNorm passes can share the chip with another part's
+        MFMA-bound convolutions."""
+        n = _DEC_STREAMS
+        if n > 1 and z_q.is_cuda and z_q.shape[0] >= 2 * n and z_q.shape[0] % n == 0:
+            main = torch.cuda.current_stream()
+            while len(self._dec_streams) < n - 1:
+                self._dec_streams.append(torch.cuda.Stream())
+            outs = []
+            sizes = [int(v) for v in _DEC_SIZES.split(",")] if _DEC_SIZES else None
+            parts = z_q.split(sizes, 0) if (sizes and sum(sizes) == z_q.shape[0] and len(sizes) == n) else z_q.chunk(n, 0)
+            for i, part in enumerate(parts):
+                if i == 0:
+                    outs.append(self._decode_one(part))
+                    continue
+                st = self._dec_streams[i - 1]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs.append(self._decode_one(part))
+            for st in self._dec_streams[:n - 1]:
+                main.wait_stream(st)
+            for o in outs[1:]:
+                o.record_stream(main)
+            return torch.cat(outs, 0)
+        return self._decode_one(z_q)
+
+    def _decode_one(self, z_q):
         h = ops.linear(z_q, self.post_quant)
         h = ops.conv3x3(h, self.conv_in, gn=True)
         for m in self.mid:
