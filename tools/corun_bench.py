@@ -29,16 +29,23 @@ def gn():
     K.groupnorm_bwd(dy, x, gm, bt, mean, rstd)
 
 
-def timed(fn, iters=10):
-    for _ in range(3):
+CLK = {}
+
+
+def timed(fn, iters=40, name=None):
+    for _ in range(10):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0 = K.clock_sample()
     e0.record()
     for _ in range(iters):
         fn()
     e1.record()
+    c1 = K.clock_sample()
     torch.cuda.synchronize()
+    if name:
+        CLK[name] = K.effective_clock_mhz(c0, c1)
     return e0.elapsed_time(e1) / iters * 1e3
 
 
@@ -56,8 +63,9 @@ def both_two_streams():
     main.wait_stream(s2)
 
 
-tc, tg = timed(conv), timed(gn)
-tser = timed(lambda: (conv(), conv(), gn(), gn()))
-tpar = timed(both_two_streams)
+tc, tg = timed(conv, name="conv"), timed(gn, name="gn")
+tser = timed(lambda: (conv(), conv(), gn(), gn()), name="serial")
+tpar = timed(both_two_streams, name="two streams")
 print(f"conv 128->128 @256^2 b{B}: {tc:7.1f} us | groupnorm_bwd: {tg:7.1f} us | 2 conv + 2 gn on one stream: {tser:7.1f} us | "
       f"conv stream || gn stream: {tpar:7.1f} us (ideal overlap {2 * max(tc, tg):7.1f})")
+print("effective shader clock, MHz:", {k: round(v) for k, v in CLK.items()})
