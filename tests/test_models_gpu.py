@@ -199,6 +199,28 @@ def test_fp8_producer_side_quantisation_changes_nothing(cuda, what, monkeypatch)
         assert (eg <= 1e-6 if what == "tower" else (eg <= 0.25 and cos > 0.97)), (what, it, eg, cos)
 
 
+def test_decoder_batch_parts_on_streams_change_nothing(cuda, monkeypatch):
+    """FFVC_DEC_STREAMS (an experiment kept opt-in: measured slower): the decoder batch in parts on separate HIP streams, forward and
+    backward, must give the single-launch result — GroupNorm statistics are per image, the parts only change the launch shapes."""
+    g = torch.Generator().manual_seed(41)
+    vsd = fvq.random_state_dict(TINY_VQ, seed=42)
+    z = torch.randn(8, 6, 6, 64, generator=g).cuda()
+    gw = torch.randn(8, 24, 24, 3, generator=g).cuda()
+    res = {}
+    for n, sizes in ((1, ""), (2, ""), (2, "3,5"), (4, "")):
+        monkeypatch.setattr(fvq, "_DEC_STREAMS", n)
+        monkeypatch.setattr(fvq, "_DEC_SIZES", sizes)
+        model = fvq.VQGAN(vsd, TINY_VQ, F32)
+        zi = z.clone().requires_grad_(True)
+        y = model.decode_nhwc(zi)
+        (y * gw).sum().backward()
+        torch.cuda.synchronize()
+        res[(n, sizes)] = (y.detach(), zi.grad.detach())
+    ya, ga = res[(1, "")]
+    for key, (yb, gb) in res.items():
+        assert _relrms(yb, ya) < 1e-5 and _relrms(gb, ga) < 1e-5, key
+
+
 def test_clip_arch_names():
     """main.py:1308-1333: OpenAI names and openclip/<arch>/<pretrained> spellings -> architecture + activation."""
     from feed_forward_vqgan_clip_amd import main as fmain
