@@ -289,6 +289,7 @@ E4M3, E5M2 = 0, 1
 FP8_MARGIN = 2.0          # headroom of the delayed scale: next step's values may exceed this step's amax by this factor
 
 
+_FP8_SKINNY = os.environ.get("FFVC_FP8_SKINNY", "1") != "0"        # A/B: the 64-row remainder on ffvc_gemm_fp8_skinny
 _FP8_ROWSPLIT = os.environ.get("FFVC_FP8_ROWSPLIT", "1") != "0"    # A/B: 64 x 257-row fp8 GEMMs as 16384 + 64 rows
 _F8_POOLS = {}        # device -> list of [buf [1024, 4] fp32, rows handed out]
 _F8_PENDING = []      # scales whose update (amax -> next scale) has not been enqueued yet
@@ -428,18 +429,30 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     # ViT-L/14 at 64 cutouts: 16448 = 64 x 257 rows = 64 whole 256-row tiles + 64 rows.  With the tail inside the launch every tile
-    # choice pays for a nearly empty extra round (260 tiles of 256 x 256 on 256 CUs); as two launches the 16384 rows fill whole rounds
-    # and the 64 rows cost one short launch.  Every epilogue option is row-separable (column sums / amax accumulate).
-    # Measured (tools/fp8_rows_bench.py, us, one launch -> 16384 + 64): N=1024 K=1024 42.4 -> 39.0, N=1024 K=3072 85.2 -> 79.3, N=1024 K=4096
-    # 105.1 -> 98.9, N=4096 K=1024 106.5 -> 103.7, but N=3072 K=1024 85.2 -> 95.2 (its fourth round of 12 tiles is cheap, the 64-row launch is
-    # not: 13-26 us of K-loop latency) -> narrow outputs and the 4096-wide one only.
+    # choice pays for a nearly empty extra round (260 tiles of 256 x 256 on 256 CUs); as two launches the 16384 rows fill whole rounds.
+    # The 64 rows go to the skinny kernel (K split across the waves of a workgroup: ~6 us) when the epilogue is one it has — bias,
+    # residual, plain store — and otherwise to the tiled kernel (13-26 us of K-loop latency: tools/fp8_rows_bench.py; then the split only
+    # pays for narrow outputs and the 4096-wide one: N=1024 K=1024 42.4 -> 39.0 us, N=1024 K=4096 105.1 -> 98.9, N=4096 K=1024 106.5 ->
+    # 103.7, but N=3072 K=1024 85.2 -> 95.2).  Every epilogue option is row-separable (column sums / amax accumulate).
     M0 = M - M % 256
-    if conv is None and _FP8_ROWSPLIT and M0 >= 8192 and 0 < M - M0 <= 64 and (N <= 1024 or N >= 4096):
-        segs = ((0, M0), (M0, M - M0))
+    tail = M - M0
+    simple = (act == ACT_NONE and aux is None and colsum is None and out_scale is None and gn_sums is None and
+              (flags & ~(F_OUT_F32 | F_RES_F32)) == 0 and
+              (residual is None or residual.dtype == torch.float32 or residual.dtype == y.dtype))
+    skinny = bool(_FP8_SKINNY and conv is None and simple and 0 < tail <= 64 and lib.ffvc_gemm_fp8_skinny_ok(tail, N, K))
+    if conv is None and _FP8_ROWSPLIT and M0 >= 8192 and 0 < tail <= 64 and (skinny or N <= 1024 or N >= 4096):
+        segs = ((0, M0), (M0, tail))
     else:
         segs = ((0, M),)
+        skinny = False
     base = (d.x, d.y, d.residual, d.aux)
     for r0, rows in segs:
+        if skinny and r0:
+            _lib.check(lib.ffvc_gemm_fp8_skinny(base[0] + r0 * K, d.w, base[1] + r0 * N * y.element_size(), dtype_code(y.dtype), _ptr(bias),
+                                                (base[2] + r0 * N * residual.element_size()) if residual is not None else None,
+                                                dtype_code(residual.dtype) if residual is not None else 0, rows, N, K, sx.fmt,
+                                                sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()), "ffvc_gemm_fp8_skinny")
+            continue
         d.M = rows
         d.x = base[0] + r0 * K
         d.y = base[1] + r0 * N * y.element_size()
@@ -452,6 +465,14 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("conv3x3_fp8" if conv is not None else "gemm_nt_fp8", 2.0 * M * N * K, e0, e1, (M, N, K, 1, 1)))
+    return y
+
+
+def gemm_fp8_skinny(x8, w8, y, M, N, K, sx, sw, bias=None, residual=None):
+    """y[M <= 64, N] = sx.inv * sw.inv * X8 W8^T (+ bias) (+ residual) on the K-split-across-waves kernel (see gemm_fp8's row split)."""
+    _need_cuda(x8, w8, y, bias, residual)
+    _call("ffvc_gemm_fp8_skinny", x8.data_ptr(), w8.data_ptr(), y.data_ptr(), dtype_code(y.dtype), _ptr(bias), _ptr(residual),
+          dtype_code(residual.dtype) if residual is not None else 0, M, N, K, sx.fmt, sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr())
     return y
 
 

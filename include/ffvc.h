@@ -174,6 +174,13 @@ int ffvc_actgrad_inplace(void* aux, int dtype, int act, int M, int N, int64_t ld
  * state[2] = 1 / state[0], state[1] = 0  (delayed scaling: the amax seen at step t sets the scale of step t+1).
  * state: 4 floats on the device.  n must be a multiple of 8. */
 int ffvc_gemm_fp8(const ffvc_gemm_desc* d, int x_fmt, int lo_dtype, const float* scale0, const float* scale1, void* stream);
+/* The same product for a handful of rows (M <= 64, N % 32 == 0, K % 512 == 0: ffvc_gemm_fp8_skinny_ok): the K loop is split across the
+ * eight waves of a workgroup instead of walked by one tile's workgroup alone — the 64-row remainder of the ViT-L/14 tower's 64 x 257 rows
+ * (cloob.py:199-205 linears at BASELINE configs[4]).  y (y_dtype fp32 | f16 | bf16, row stride N) = scale0 * scale1 * X8 W8^T (+ bias)
+ * (+ residual in res_dtype = fp32 or y_dtype); x8 / w8 K-major with row stride K. */
+int ffvc_gemm_fp8_skinny_ok(int M, int N, int K);
+int ffvc_gemm_fp8_skinny(const void* x8, const void* w8, void* y, int y_dtype, const float* bias, const void* residual, int res_dtype,
+                         int M, int N, int K, int x_fmt, const float* scale0, const float* scale1, void* stream);
 int ffvc_fp8_quant(const void* src, int src_dtype, void* dst, int fmt, float* state, int64_t n, void* stream);
 int ffvc_fp8_amax(const void* src, int src_dtype, float* state, int64_t n, void* stream);
 int ffvc_fp8_update(float* state, int fmt, float margin, void* stream);

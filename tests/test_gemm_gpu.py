@@ -832,6 +832,48 @@ def test_flash_attention_writes_the_fp8_operand_of_out_proj(cuda, dt, B, T, head
     assert torch.equal(o8, q_ref) and sc.state[1].item() == amax_ref
 
 
+@pytest.mark.parametrize("ydt,rdt", [(torch.float32, torch.float32), (torch.float16, torch.float16), (torch.bfloat16, torch.float32),
+                                     (torch.float16, None)])
+@pytest.mark.parametrize("xfmt", [0, 1])
+@pytest.mark.parametrize("M,N,Kd", [(64, 1024, 4096), (37, 96, 512), (1, 32, 1024), (64, 3072, 1024)])
+def test_fp8_skinny_gemm_matches_dequantised_reference(cuda, M, N, Kd, xfmt, ydt, rdt):
+    """ffvc_gemm_fp8_skinny (K split across the eight waves of a workgroup, operands straight from global memory) against fp64 math on the
+    fp8 values decoded by torch's float8 dtypes: ragged M, every output / residual dtype, e4m3 and e5m2 activations."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, Kd, generator=g).half().cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.05).cuda()
+    sx, sw = K.Fp8Scale(xfmt, x.device), K.Fp8Scale(K.E4M3, x.device)
+    x8, w8 = K.fp8_quant(x, sx), K.fp8_quant(w, sw, frozen=True)
+    bias = torch.randn(N, generator=g).cuda()
+    res = None if rdt is None else torch.randn(M, N, generator=g).to(rdt).cuda()
+    y = torch.full((M, N), float("nan"), dtype=ydt, device=x.device)
+    K.gemm_fp8_skinny(x8, w8, y, M, N, Kd, sx, sw, bias=bias, residual=res)
+    ref = (_f8_ref(x8, xfmt).double() @ _f8_ref(w8, K.E4M3).double().t()) * (sx.state[2].double() * sw.state[2].double()) + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    tol = 1e-4 if ydt == torch.float32 else (2e-3 if ydt == torch.float16 else 1.6e-2)      # fp32: accumulation order / MFMA adder tree
+    assert torch.isfinite(y).all() and _rel(y, ref) < tol
+
+
+def test_fp8_gemm_row_split_uses_the_skinny_tail(cuda, monkeypatch):
+    """64 x 257 rows: the 16384 + 64 split with the skinny tail equals the single launch up to fp32 summation order."""
+    g = torch.Generator().manual_seed(18)
+    M, N, Kd = 16448, 1024, 1024
+    x = torch.randn(M, Kd, generator=g).half().cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.05).cuda()
+    sx, sw = K.Fp8Scale(K.E4M3, x.device), K.Fp8Scale(K.E4M3, x.device)
+    x8, w8 = K.fp8_quant(x, sx), K.fp8_quant(w, sw, frozen=True)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    outs = {}
+    for split in (False, True):
+        monkeypatch.setattr(K, "_FP8_ROWSPLIT", split)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        K.gemm_fp8(x8, w8, y, M, N, Kd, sx, sw, lo_dtype=torch.float16, bias=bias, residual=res)
+        outs[split] = y
+    assert _rel(outs[True], outs[False]) < 1e-4
+
+
 def test_fp8_updates_are_batched_and_lazy(cuda):
     """fp8_next_scale only marks a stream; ONE ffvc_fp8_update_many launch folds every marked stream's amax into its scale, and a
     stream nobody flushed is updated by its next producer.  Streams that saw no tensor keep their scale."""

@@ -25,6 +25,7 @@ for (N, Kd, name) in ((3072, 1024, "in_proj"), (1024, 1024, "out_proj"), (1024, 
     K._FP8_ROWSPLIT = False
     t_main = timeit(lambda: K.gemm_fp8(x8[:16384], w8, y[:16384], 16384, N, Kd, sx, sw, lo_dtype=dt, bias=bias))
     t_tail = timeit(lambda: K.gemm_fp8(x8[16384:], w8, y[16384:], 64, N, Kd, sx, sw, lo_dtype=dt, bias=bias))
+    t_sk = timeit(lambda: K.gemm_fp8_skinny(x8[16384:], w8, y[16384:], 64, N, Kd, sx, sw, bias=bias))
     fl = 2.0 * M * N * Kd
     print(f"{name:16s} {M}x{N}x{Kd}: one launch {res[False] * 1e6:6.1f} us ({fl / res[False] / 1e12:5.0f} TF) | 16384 + 64 {res[True] * 1e6:6.1f} us | "
-          f"16384 alone {t_main * 1e6:6.1f} us, 64 alone {t_tail * 1e6:5.1f} us")
+          f"16384 alone {t_main * 1e6:6.1f} us, 64 alone {t_tail * 1e6:5.1f} us (tiled) / {t_sk * 1e6:5.1f} us (skinny)")
