@@ -103,6 +103,8 @@ _SIGNATURES = {
     "ffvc_fp8_quant": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "ffvc_fp8_amax": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "ffvc_fp8_update": (c_int, [c_void_p, c_int, c_float, c_void_p]),
+    "ffvc_gemm_skinny_ok": (c_int, [c_int, c_int, c_int]),
+    "ffvc_gemm_skinny": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_gemm_fp8_skinny_ok": (c_int, [c_int, c_int, c_int]),
     "ffvc_gemm_fp8_skinny": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p]),

@@ -154,15 +154,42 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
         d.colsum = colsum.data_ptr()
         d.flags |= _lib.F_COLSUM
     lib = _lib.load()
+    # 64 x 257 rows (ViT-L/14 at 64 cutouts) = 64 whole 256-row tiles + 64 rows: inside one launch the remainder costs a nearly empty extra
+    # round (tools/f16_rows_bench.py: 16448 vs 16384 rows 62 vs 36 us at N=1024 K=1024, 152 vs 108 at N=1024 K=4096); the plain-epilogue
+    # Linear kinds therefore run as 16384 rows on the tiled kernel + the remainder on ffvc_gemm_skinny (K split across the waves of a
+    # workgroup).  Row-separable by construction: bias / residual / store only.
+    M0 = M - M % 256
+    tail = M - M0
+    skinny = (_GEMM_ROWSPLIT and x.dtype in LOWP and x_mode == OP_KMAJOR and w_mode == OP_KMAJOR and M0 >= 8192 and 0 < tail <= 64 and
+              batch == 1 and split_k == 1 and act == ACT_NONE and aux is None and colsum is None and gn_sums is None and conv is None and
+              x_map is None and y_map is None and r_map is None and kseg == 0 and slab_stride == 0 and alpha == 1.0 and
+              (flags & ~(F_OUT_F32 | F_RES_F32)) == 0 and (ldx in (0, K)) and (ldw in (0, K)) and
+              bool(lib.ffvc_gemm_skinny_ok(tail, N, K)))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if skinny:
+        d.M = M0
         _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
+        _lib.check(lib.ffvc_gemm_skinny(x.data_ptr() + M0 * K * x.element_size(), w.data_ptr(), dtype_code(x.dtype),
+                                        y.data_ptr() + M0 * N * y.element_size(), dtype_code(y.dtype), _ptr(bias),
+                                        (residual.data_ptr() + M0 * N * residual.element_size()) if residual is not None else None,
+                                        dtype_code(residual.dtype) if residual is not None else 0, tail, N, K, stream_ptr()),
+                   "ffvc_gemm_skinny")
+    else:
+        _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
+    if PROFILE is not None:
         e1.record()
         PROFILE.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
                         2.0 * M * N * K * max(1, batch), e0, e1, (M, N, K, max(1, batch), split_k)))
-        return y
-    _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
+    return y
+
+
+def gemm_skinny(x, w, y, M, N, K, bias=None, residual=None):
+    """y[M <= 64, N] = X W^T (+ bias) (+ residual), 16-bit K-major operands, on the K-split-across-waves kernel (see gemm's row split)."""
+    _need_cuda(x, w, y, bias, residual)
+    _call("ffvc_gemm_skinny", x.data_ptr(), w.data_ptr(), dtype_code(x.dtype), y.data_ptr(), dtype_code(y.dtype), _ptr(bias), _ptr(residual),
+          dtype_code(residual.dtype) if residual is not None else 0, M, N, K, stream_ptr())
     return y
 
 
@@ -289,6 +316,7 @@ E4M3, E5M2 = 0, 1
 FP8_MARGIN = 2.0          # headroom of the delayed scale: next step's values may exceed this step's amax by this factor
 
 
+_GEMM_ROWSPLIT = os.environ.get("FFVC_GEMM_ROWSPLIT", "1") != "0"  # A/B: 16-bit 64 x 257-row Linear GEMMs as 16384 rows + ffvc_gemm_skinny
 _FP8_SKINNY = os.environ.get("FFVC_FP8_SKINNY", "1") != "0"        # A/B: the 64-row remainder on ffvc_gemm_fp8_skinny
 _FP8_ROWSPLIT = os.environ.get("FFVC_FP8_ROWSPLIT", "1") != "0"    # A/B: 64 x 257-row fp8 GEMMs as 16384 + 64 rows
 _F8_POOLS = {}        # device -> list of [buf [1024, 4] fp32, rows handed out]

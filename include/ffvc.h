@@ -159,6 +159,12 @@ typedef struct ffvc_gemm_desc {
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
+/* The plain Linear product for a handful of rows (M <= 64, N % 32 == 0, K % 256 == 0: ffvc_gemm_skinny_ok), 16-bit K-major operands with
+ * row stride K: the K loop is split across the eight waves of a workgroup — the 64-row remainder of the ViT-L/14 tower's 64 x 257 rows
+ * (cloob.py:199-205 at BASELINE configs[4]).  y (fp32 or in_dtype, row stride N) = X W^T (+ bias) (+ residual in fp32 or in_dtype). */
+int ffvc_gemm_skinny_ok(int M, int N, int K);
+int ffvc_gemm_skinny(const void* x, const void* w, int in_dtype, void* y, int y_dtype, const float* bias, const void* residual,
+                     int res_dtype, int M, int N, int K, void* stream);
 /* aux[m, n] <- act'(aux[m, n]) in place, 16-bit storage (the conversion pass behind FFVC_F_AUX_ACTGRAD on kernels without
  * the specialised epilogue). */
 int ffvc_actgrad_inplace(void* aux, int dtype, int act, int M, int N, int64_t ld, void* stream);

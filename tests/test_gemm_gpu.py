@@ -874,6 +874,48 @@ def test_fp8_gemm_row_split_uses_the_skinny_tail(cuda, monkeypatch):
     assert _rel(outs[True], outs[False]) < 1e-4
 
 
+@pytest.mark.parametrize("dt,ydt,rdt", [(torch.float16, torch.float32, torch.float32), (torch.float16, torch.float16, torch.float16),
+                                        (torch.bfloat16, torch.bfloat16, torch.float32), (torch.bfloat16, torch.float32, None)])
+@pytest.mark.parametrize("M,N,Kd", [(64, 1024, 4096), (37, 96, 256), (1, 32, 1024), (64, 3072, 1024)])
+def test_skinny_gemm_matches_fp64(cuda, M, N, Kd, dt, ydt, rdt):
+    """ffvc_gemm_skinny (16-bit operands, K split across the eight waves of a workgroup) against fp64 math on the same 16-bit values."""
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(M, Kd, generator=g).to(dt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.05).to(dt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = None if rdt is None else torch.randn(M, N, generator=g).to(rdt).cuda()
+    y = torch.full((M, N), float("nan"), dtype=ydt, device=x.device)
+    K.gemm_skinny(x, w, y, M, N, Kd, bias=bias, residual=res)
+    ref = x.double() @ w.double().t() + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    tol = 2e-6 if ydt == torch.float32 else (2e-3 if ydt == torch.float16 else 1.6e-2)
+    assert torch.isfinite(y).all() and _rel(y, ref) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_row_split_uses_the_skinny_tail(cuda, dt, monkeypatch):
+    """64 x 257 rows through K.gemm: 16384 rows on the tiled kernel + 64 on ffvc_gemm_skinny == the single launch up to fp32 summation order;
+    launches the split does not cover (activation epilogue) are left alone."""
+    g = torch.Generator().manual_seed(20)
+    M, N, Kd = 16448, 1024, 1024
+    x = torch.randn(M, Kd, generator=g).to(dt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * 0.05).to(dt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    outs = {}
+    for split in (False, True):
+        monkeypatch.setattr(K, "_GEMM_ROWSPLIT", split)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        K.gemm(x, w, y, M, N, Kd, ldx=Kd, ldw=Kd, bias=bias, residual=res)
+        h = torch.empty(M, N, dtype=dt, device=x.device)
+        K.gemm(x, w, h, M, N, Kd, ldx=Kd, ldw=Kd, bias=bias, act=K.ACT_GELU)
+        outs[split] = (y, h)
+    ref = x.double() @ w.double().t() + bias.double() + res.double()
+    assert _rel(outs[True][0], ref) < 2e-6 and _rel(outs[False][0], ref) < 2e-6
+    assert torch.equal(outs[True][1], outs[False][1])
+
+
 def test_fp8_updates_are_batched_and_lazy(cuda):
     """fp8_next_scale only marks a stream; ONE ffvc_fp8_update_many launch folds every marked stream's amax into its scale, and a
     stream nobody flushed is updated by its next producer.  Streams that saw no tensor keep their scale."""
