@@ -121,6 +121,7 @@ _SIGNATURES = {
                                       c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                    c_int, c_float, c_void_p]),
+    "ffvc_attn_text_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ffvc_attn_small_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_attn_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ffvc_rccl_available": (c_int, []),

@@ -1114,6 +1114,23 @@ def attn_flash_ok(qkv, heads):
             os.environ.get("FFVC_ATTN_FLASH", "1") != "0")
 
 
+_ATTN_TEXT = os.environ.get("FFVC_ATTN_TEXT", "1") != "0"     # A/B: one-launch fp32 attention of the text tower
+
+
+def attn_text_ok(qkv, heads):
+    return (_ATTN_TEXT and qkv.dtype == torch.float32 and qkv.is_cuda and qkv.dim() == 3 and qkv.shape[1] <= 128 and
+            qkv.shape[2] == 3 * heads * 64)
+
+
+def attn_text_fwd(qkv, heads, scale, causal):
+    """fp32 qkv [B, T <= 128, 3*heads*64] -> fp32 [B, T, heads*64]: exact-fp32 attention in one launch (forward only)."""
+    _need_cuda(qkv)
+    B, T, D3 = qkv.shape
+    o = torch.empty(B, T, D3 // 3, dtype=torch.float32, device=qkv.device)
+    _call("ffvc_attn_text_fwd", qkv.data_ptr(), o.data_ptr(), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
+    return o
+
+
 def attn_flash_fwd(qkv, heads, scale, causal, f8=None):
     """-> (out [B,T,heads*64], lse fp32 [B*heads,T]).  f8 (an initialised Fp8Scale): -> (out, lse, out8), the output also as the fp8
     bytes fp8_quant(out, f8) would give."""

@@ -782,6 +782,9 @@ class _AttentionFn(Function):
             ctx.small = True
             return K.attn_small_fwd(qkv, heads, scale)
         ctx.small = False
+        if not ctx.needs_input_grad[0] and K.attn_text_ok(qkv, heads):
+            # forward-only fp32 attention of a short sequence (the frozen text tower): one launch instead of GEMM + softmax + GEMM
+            return K.attn_text_fwd(qkv, heads, scale, causal)
         ctx.flash = K.attn_flash_ok(qkv, heads)
         if ctx.flash:       # any length, head dim 64: online-softmax kernel, scores never reach HBM, causal blocks skipped
             f8 = None

@@ -300,6 +300,11 @@ int ffvc_attn_tiny_bwd(const void* qkv, const void* dout, void* dqkv, int dtype,
                        int64_t sb, int64_t st, int64_t sk, int64_t sh, int64_t sd, int64_t out_ld, int64_t row_len, float scale,
                        void* stream);
 
+/* Exact-fp32 attention of a short sequence (T <= 128, head_dim 64), forward only, one launch: the frozen CLIP text tower's 77 causal tokens
+ * (cloob.py:199-200,510-516; evaluated every step at main.py:733).  qkv fp32 packed as in ffvc_attn_small_fwd, out fp32 [B, T, heads*64];
+ * two-pass softmax in fp32 on the vector ALUs (the matrices are too small for the tiled GEMM + softmax + GEMM sequence it replaces). */
+int ffvc_attn_text_fwd(const float* qkv, float* out, int B, int T, int heads, int head_dim, float scale, int causal, void* stream);
+
 /* Flash-style attention for any sequence length, head_dim 64, optional causal mask: the x-transformer mapper's
  * self-attention (transformer.py:11-20 -> x-transformers Decoder, 1024 tokens at cfg4) and ViT-L/14's 257 tokens
  * (cfg5).  Same packed qkv layout as ffvc_attn_small_*.  No score matrix in HBM; causal blocks above the diagonal are

@@ -524,3 +524,18 @@ def test_attention_tiny_vs_fp64(cuda, dt, B, T, H, dh, layout, pad):
     assert rel(dqkv[:, :, :3 * H * dh], x.grad) < tol
     if pad:
         assert torch.count_nonzero(o[:, :, H * dh:]) == 0 and torch.count_nonzero(dqkv[:, :, 3 * H * dh:]) == 0
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("B,T,heads", [(3, 77, 8), (2, 128, 2), (1, 5, 1), (4, 16, 3)])
+def test_attention_text_fp32_one_launch(cuda, B, T, heads, causal):
+    """ffvc_attn_text_fwd: exact-fp32 attention of a short sequence in one launch (the frozen CLIP text tower: 77 causal tokens) against fp64."""
+    g = torch.Generator().manual_seed(23)
+    qkv = (torch.randn(B, T, 3 * heads * 64, generator=g) * 0.8).cuda()
+    o = K.attn_text_fwd(qkv, heads, 0.125, causal)
+    q, k, v = [t.double().view(B, T, heads, 64).permute(0, 2, 1, 3) for t in qkv.split(heads * 64, dim=2)]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, dtype=torch.bool, device=s.device).triu(1), float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, heads * 64)
+    assert ((o.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
