@@ -66,7 +66,7 @@ def test_load_dataset_tokenises_text_files(tk, tmp_path, monkeypatch):
 
 
 def test_unicode_letters_and_numbers_follow_clip_pattern(tk):
-    """clip.simple_tokenizer's pre-token pattern uses \p{L} / \p{N}: an accented or non-Latin word is ONE pre-token (its
+    r"""clip.simple_tokenizer's pre-token pattern uses \p{L} / \p{N}: an accented or non-Latin word is ONE pre-token (its
     UTF-8 bytes then go through the byte alphabet and BPE), every unicode digit is its own pre-token."""
     text = "café naïve 東京2024 привет's ½ x²"
     assert T._PAT.findall(text) == ["café", "naïve", "東京", "2", "0", "2", "4",
@@ -92,3 +92,48 @@ def test_basic_clean_subset_of_ftfy():
     assert T.basic_clean("a\r\nb c") == "a\nb\nc"
     assert T.basic_clean("é") == "é"                       # NFC
     assert T.basic_clean("\x93x\x94") == "\"x\""                      # C1 controls -> cp1252 curly quotes -> straight
+
+
+def test_ids_equal_hf_clip_tokenizer_on_a_synthetic_vocabulary(tmp_path):
+    """Second witness for the BPE front-end (the real vocabulary is absent offline, so the ids cannot be pinned to
+    clip.tokenize itself): HuggingFace's CLIPTokenizer — an independent port of the same OpenAI algorithm (byte alphabet, </w> marker,
+    merges by rank, the pre-token pattern, SOT / EOT framing) — given a synthetic merges file laid out the way CLIP's vocabulary is
+    (256 byte symbols, 256 word-final ones, the merges, the two specials) must produce the same ids for the same text."""
+    transformers = pytest.importorskip("transformers")
+    import json
+    import random
+    rnd = random.Random(7)
+    words = ["cat", "dog", "photo", "painting", "of", "a", "the", "red", "blue", "castle", "river", "night", "2024", "don't", "it's",
+             "sun", "sunset", "mountain", "mountains", "artstation", "trending", "oil", "on", "canvas", "hd", "4k", "ocean", "waves"]
+    # a merges table that actually fires on these words: walk each word, merge adjacent symbols left to right, in a shuffled order
+    merges, seen, joined = [], set(), set()
+    for w in words * 2:
+        sym = list(w[:-1]) + [w[-1] + "</w>"]
+        while len(sym) > 1:
+            i = rnd.randrange(len(sym) - 1)
+            pair = (sym[i], sym[i + 1])
+            if pair not in seen and "'" not in pair[0] + pair[1] and pair[0] + pair[1] not in joined:   # (joined strings unique, as in CLIP's file)
+                seen.add(pair)
+                joined.add(pair[0] + pair[1])
+                merges.append(pair)
+            sym[i:i + 2] = [sym[i] + sym[i + 1]]
+    mpath = tmp_path / "merges.txt"
+    mpath.write_text("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n", encoding="utf-8")
+    mine = T.SimpleTokenizer(str(mpath))
+    vocab = {tok: i for tok, i in mine.encoder.items()}                  # same construction rule -> same ids by definition of the format
+    assert vocab["<|startoftext|>"] == len(vocab) - 2 and vocab["<|endoftext|>"] == len(vocab) - 1
+    vpath = tmp_path / "vocab.json"
+    vpath.write_text(json.dumps(vocab), encoding="utf-8")
+    hf = transformers.CLIPTokenizer(str(vpath), str(mpath))
+    texts = ["a photo of a cat", "the red castle on the river at night, trending on artstation", "it's a dog, don't panic!",
+             "oil painting of mountains   at  sunset 2024 hd 4k", "ocean waves", "a", "sunsets over the mountain... (oil on canvas)",
+             "catdog dogcat photophoto"]
+    for t in texts:
+        ref = hf(t)["input_ids"]
+        ids = [mine.sot] + mine.encode(t) + [mine.eot]
+        assert ids == ref, (t, ids, ref)
+    out = T.tokenize(texts, context_length=32, truncate=True, tokenizer=mine)
+    ref = hf(texts, padding="max_length", max_length=32, truncation=True)["input_ids"]
+    for row, r in zip(out.tolist(), ref):
+        n = r.index(mine.eot) + 1
+        assert row[:n] == r[:n] and all(v == 0 for v in row[n:])        # clip.tokenize pads with 0, HF with its pad id
