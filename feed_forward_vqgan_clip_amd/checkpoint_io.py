@@ -14,8 +14,13 @@ Only state is recovered from stand-ins, never behaviour.  `find_class` is an ALL
 torch, numpy's array rebuilders, `collections.OrderedDict`, the builtin containers and scalars resolve to the real objects; every
 other global a pickle names — importable or not: `os.system`, `builtins.eval`, `subprocess.*`, but also `torch.nn.Linear` or an
 optimizer class — becomes an inert stand-in whose "call" returns another stand-in, so a REDUCE opcode cannot run foreign code.
+Rebuilders that would themselves unpickle a byte string with the STANDARD pickle module are not handed out as they are:
+`torch.storage._load_from_bytes` (= `torch.load(BytesIO(b), weights_only=False)`) resolves to a shim that recurses through this
+same unpickler, numpy's `scalar` / `_frombuffer` refuse object dtypes (`scalar(dtype('O'), bytes)` is `pickle.loads`), and
+`_rebuild_wrapper_subclass` (takes a class argument) is a stand-in.
 (That is a much smaller surface than plain `torch.load(weights_only=False)`; files should still come from a trusted source.)
 """
+import io
 import collections
 import pickle
 
@@ -85,16 +90,48 @@ _ALLOWED = {
     "copyreg": {"_reconstructor"}, "copy_reg": {"_reconstructor"},
     "_codecs": {"encode"},
     "numpy": {"ndarray", "dtype"},
-    "numpy.core.multiarray": {"_reconstruct", "scalar"}, "numpy._core.multiarray": {"_reconstruct", "scalar"},
-    "numpy.core.numeric": {"_frombuffer"}, "numpy._core.numeric": {"_frombuffer"},
+    "numpy.core.multiarray": {"_reconstruct"}, "numpy._core.multiarray": {"_reconstruct"},
     "torch": {"Size", "device", "dtype", "Tensor", "FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage",
               "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage", "TypedStorage"},
     "torch._utils": {"_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_tensor_v3", "_rebuild_parameter", "_rebuild_parameter_with_state",
-                     "_rebuild_qtensor", "_rebuild_device_tensor_from_numpy", "_rebuild_wrapper_subclass"},
+                     "_rebuild_qtensor", "_rebuild_device_tensor_from_numpy"},
     "torch._tensor": {"_rebuild_from_type_v2", "Tensor"},
     "torch.nn.parameter": {"Parameter", "Buffer"},
-    "torch.storage": {"_load_from_bytes", "UntypedStorage", "TypedStorage"},
+    "torch.storage": {"UntypedStorage", "TypedStorage"},
     "torch.serialization": {"_get_layout"},
+}
+
+
+def _load_from_bytes(b):
+    """Stand-in for torch.storage._load_from_bytes (legacy byte-serialised storages): the nested file goes through the SAME
+    allowlisting unpickler instead of torch.load's default pickle module."""
+    return torch.load(io.BytesIO(b), map_location="cpu", weights_only=False, pickle_module=_PickleModule)
+
+
+def _no_object_dtype(dtype):
+    import numpy as np
+    dt = np.dtype(dtype)
+    if dt.hasobject:
+        raise pickle.UnpicklingError("checkpoint_io: numpy object dtypes are not rebuilt (their payload is a nested pickle)")
+    return dt
+
+
+def _np_scalar(dtype, obj=None):
+    import numpy as np
+    dt = _no_object_dtype(dtype)
+    return np.frombuffer(obj, dtype=dt, count=1)[0] if obj is not None else dt.type()
+
+
+def _np_frombuffer(buf, dtype, shape, order="C"):
+    import numpy as np
+    return np.frombuffer(buf, dtype=_no_object_dtype(dtype)).reshape(shape, order=order)
+
+
+# names that resolve to a local shim instead of the object the pickle asked for
+_SHIMS = {
+    ("torch.storage", "_load_from_bytes"): _load_from_bytes,
+    ("numpy.core.multiarray", "scalar"): _np_scalar, ("numpy._core.multiarray", "scalar"): _np_scalar,
+    ("numpy.core.numeric", "_frombuffer"): _np_frombuffer, ("numpy._core.numeric", "_frombuffer"): _np_frombuffer,
 }
 
 
@@ -106,6 +143,9 @@ class TolerantUnpickler(pickle.Unpickler):
     _collect = None       # set by tolerant_load (thread-local would be needed for concurrent loads; tolerant_load takes a lock)
 
     def find_class(self, module, name):
+        shim = _SHIMS.get((module, name))
+        if shim is not None:
+            return shim
         if name in _ALLOWED.get(module, ()):
             try:
                 return super().find_class(module, name)           # (also applies pickle's Python-2 name mapping)

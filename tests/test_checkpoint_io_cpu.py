@@ -106,3 +106,53 @@ def test_tolerant_load_does_not_execute_importable_globals(tmp_path):
     assert not marker.exists()
     assert torch.equal(obj["state_dict"]["w"], torch.arange(6.0).view(2, 3))
     assert any(n.endswith(".system") for n in stubbed) and any(n.endswith(".eval") for n in stubbed)
+
+
+def test_tolerant_load_does_not_execute_nested_pickles(tmp_path):
+    """rebuilders that unpickle a byte string with the standard pickle module are a way around the allowlist —
+    `torch.storage._load_from_bytes(<inner pickle>)` and numpy's `scalar(dtype('O'), <inner pickle>)`.  The first goes through the
+    same unpickler (the inner os.system becomes a stand-in), the second is refused; a legitimate byte-serialised storage and a
+    numpy scalar still load."""
+    import io
+    import os
+    import pickle
+
+    import numpy as np
+
+    from feed_forward_vqgan_clip_amd import checkpoint_io as cio
+    marker = tmp_path / "pwned"
+
+    class Inner:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    buf = io.BytesIO()
+    torch.save({"x": Inner()}, buf, pickle_module=pickle)
+
+    class Nested:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (buf.getvalue(),))
+
+    good = io.BytesIO()
+    torch.save(torch.arange(4.0), good)
+
+    class GoodNested:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (good.getvalue(),))
+
+    p = tmp_path / "nested.ckpt"
+    torch.save({"evil": Nested(), "good": GoodNested(), "s": np.float32(2.5), "w": torch.ones(2)}, p, pickle_module=pickle)
+    obj, stubbed = cio.tolerant_load(p, return_stubbed=True)
+    assert not marker.exists()
+    assert any(n.endswith(".system") for n in stubbed)
+    assert torch.equal(obj["good"], torch.arange(4.0)) and float(obj["s"]) == 2.5 and torch.equal(obj["w"], torch.ones(2))
+
+    class ObjScalar:
+        def __reduce__(self):
+            return (np._core.multiarray.scalar, (np.dtype("O"), pickle.dumps(Inner())))
+
+    q = tmp_path / "objscalar.ckpt"
+    torch.save({"a": ObjScalar()}, q, pickle_module=pickle)
+    with pytest.raises(Exception):
+        cio.tolerant_load(q)
+    assert not marker.exists()
