@@ -1,6 +1,7 @@
 """bench.py — train-step images/sec of the hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (starts the N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -74,7 +75,8 @@ def build(args, device):
     opt = FusedAdam(net.parameters(), lr=cfg.lr)
     opt.loss_scale = args.loss_scale if cdt == torch.float16 else 1.0
     if hvd.is_distributed():
-        opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
+        opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None,
+                                       tail_wire_dtype=torch.bfloat16 if args.grad_wire_tail == "bf16" else None)
         hvd.broadcast_parameters(net, root_rank=0)
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
     return cfg, stepper, (mixer_sd, vq_sd, clip_sd)
@@ -253,6 +255,37 @@ def full_size_parity(args, sds, ref):
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE): start the N ranks as CHILD processes — one
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` — before this process has touched the GPU
+    (nothing above this call initialises HIP; the parent never does), relay the children's output and print rank 0's JSON line as
+    the parent's LAST stdout line.  Returns the exit code (non-zero child -> non-zero parent, also when no JSON line came back)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes); read by ROCr at hsa_init in the children
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"') and '"metric"' in ln:
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print(f"bench.py: the {n}-rank launch produced no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,7 +324,12 @@ def main():
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second timing in the other 16-bit format")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", type=int, default=0, help="print the N most expensive GEMM shapes (stderr)")
+    ap.add_argument("--grad-wire-tail", default="fp32", choices=["fp32", "bf16"],
+                    help="wire format of the exposed tail slices only (distributed.DistributedOptimizer tail policy)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     from feed_forward_vqgan_clip_amd import distributed as hvd
     from feed_forward_vqgan_clip_amd import kernels as K

@@ -121,6 +121,7 @@ def describe():
     return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env,
             "preset_applied": sorted(_STATE.get("preset", {})),
             "hsa_ipc_mode_legacy_exported_0": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0",
+            "wire": _STATE.get("wire"),
             "bucket_exchange": "ffvc_allreduce_bucket (own RCCL communicator)" if _STATE.get("native") else "torch.distributed"}
 
 
@@ -210,13 +211,17 @@ class DistributedOptimizer:
     """
 
     def __init__(self, opt, arena=None, bucket_bytes=64 << 20, wire_dtype=None, tail_bytes=None, tail_bucket_bytes=16 << 20,
-                 tail_wire_dtype=torch.bfloat16):
+                 tail_wire_dtype=None):
         """tail_*: the slices that go on the wire LAST have nothing left of the backward pass to hide behind (the Mixer's
         `proj.weight`, 134 MB, is the last gradient produced; the first block's bucket right before it).  After the first step
         the observed launch order decides which slices make up the last `tail_bytes` (default 192 MiB, FFVC_DP_TAIL_MIB; 0 = off);
         those are re-cut to `tail_bucket_bytes` (the ring pipelines several small messages over the 7 xGMI links instead of
-        serialising behind one long pass) and travel in `tail_wire_dtype` (bf16: half the exposed bytes; the other slices keep
-        `wire_dtype`).  Every rank takes the same decision (the launch order is a function of the model)."""
+        serialising behind one long pass) and travel in `tail_wire_dtype`.  Default None = the tail follows `wire_dtype` (the
+        reference exchanges fp32 without compression, main.py:627: nothing narrower goes on the wire unless the configuration
+        asks for it — `grad_wire: bf16` for every slice, `grad_wire_tail: bf16` for the exposed tail only: half its bytes, the
+        other slices keep `wire_dtype`).  The layout is rank 0's: it broadcasts the launch order it observed, every rank checks
+        its own against it (a different order means the ranks already enqueue their all-reduces in different sequences — raise
+        instead of hanging or mixing gradients) and re-cuts from that."""
         self.opt = opt
         self.arena = arena if arena is not None else opt.arena
         self.wire_dtype = wire_dtype
@@ -224,6 +229,9 @@ class DistributedOptimizer:
             tail_bytes = int(os.environ.get("FFVC_DP_TAIL_MIB", "192")) << 20
         self.tail_bytes, self.tail_bucket_bytes, self.tail_wire_dtype = int(tail_bytes), int(tail_bucket_bytes), tail_wire_dtype
         self._tail_tuned = self.tail_bytes <= 0
+        _name = lambda d: str(d or torch.float32).replace("torch.", "")
+        _STATE["wire"] = {"slices": _name(wire_dtype), "tail": _name(tail_wire_dtype if tail_wire_dtype is not None else wire_dtype),
+                          "tail_MiB": self.tail_bytes >> 20, "tail_slice_MiB": self.tail_bucket_bytes >> 20}
         self._timing = None                 # exposure instrumentation (measure_exposure)
         a = self.arena
         # buckets in reverse registration order (= the order backward produces gradients)
@@ -282,10 +290,27 @@ class DistributedOptimizer:
                 self._bucket_of.setdefault(id(a.plist[i]), []).append(b)
         self._pending = [len(idxs) for _, _, idxs in self.buckets]
 
+    def _agree_on_order(self, order):
+        """Rank 0's launch order, adopted by every rank; raises on every rank if any rank observed a different one."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return order
+        dev = self.arena.grads.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = torch.tensor(order, dtype=torch.int64, device=dev)
+        ref = mine.clone()
+        dist.broadcast(ref, src=0)
+        bad = (mine != ref).any().to(torch.int32).reshape(1)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            raise RuntimeError("DistributedOptimizer: the ranks launched their gradient slices in different orders "
+                               f"(rank {dist.get_rank()}: {order[:8]}..., rank 0: {ref.tolist()[:8]}...) — the all-reduces "
+                               "would pair up wrongly.  Causes: a data-dependent branch or an unused parameter on some ranks only")
+        return ref.tolist()
+
     def _retune_tail(self, order):
         """order: bucket indices in the launch order of the step that just ran.  Re-cut the slices that make up its last
         `tail_bytes` into `tail_bucket_bytes` pieces on the tail wire format (see __init__)."""
         self._tail_tuned = True
+        order = self._agree_on_order(order)
         tail, acc = set(), 0
         for b in reversed(order):
             if acc >= self.tail_bytes:

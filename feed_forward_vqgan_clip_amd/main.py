@@ -706,7 +706,10 @@ def train(config_file):
     log_interval = config.get("log_interval", 100)
     rank_zero = hvd.rank() == 0
     if hvd.size() > 1:
-        opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if config.get("grad_wire") == "bf16" else None)
+        # fp32 on the wire like hvd.DistributedOptimizer(opt) (main.py:627) unless the configuration asks: `grad_wire: bf16` for
+        # every slice, `grad_wire_tail: bf16` for the slices no backward work is left to hide
+        opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if config.get("grad_wire") == "bf16" else None,
+                                       tail_wire_dtype=torch.bfloat16 if config.get("grad_wire_tail") == "bf16" else None)
         hvd.broadcast_parameters(net, root_rank=0)
         hvd.broadcast_optimizer_state(opt, root_rank=0)
     scheduler = None

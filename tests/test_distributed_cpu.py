@@ -168,6 +168,87 @@ def test_dp_tail_slices_are_recut_and_travel_in_bf16_after_the_first_step():
     assert (torch.from_numpy(p0) - arena.params.detach()).abs().max().item() < 3e-3
 
 
+def _tail_default_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    from feed_forward_vqgan_clip_amd.arena import ParamArena
+    hvd.init(backend="gloo")
+    net = _model()
+    arena = ParamArena(net, torch.float32, allow_cpu=True)
+    opt = hvd.DistributedOptimizer(torch.optim.SGD(net.parameters(), lr=0.1), arena=arena, bucket_bytes=1024, tail_bytes=3000,
+                                   tail_bucket_bytes=512)                   # tail_wire_dtype left at its default
+    n0 = len(opt.buckets)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    idx = list(iter(hvd.DistributedSampler(8, shuffle=False)))
+    for _ in range(3):
+        opt.zero_grad()
+        ((net(X[idx]) - Y[idx]) ** 2).mean().backward()
+        opt.step()
+    # a rank whose observed launch order differs from rank 0's must not silently re-cut differently
+    order = list(range(len(opt.buckets)))
+    if rank == 1:
+        order[0], order[1] = order[1], order[0]
+    try:
+        opt._retune_tail(order)
+        raised = ""
+    except RuntimeError as e:
+        raised = str(e)
+    q.put((rank, arena.params.detach().numpy().copy(), n0, len(opt.buckets), [str(w) for w in opt._wire_of], raised,
+           hvd.describe()["wire"]))
+
+
+def test_dp_tail_keeps_the_fp32_wire_by_default_and_ranks_must_agree_on_the_order():
+    """Default tail policy = re-cut only: nothing narrower than `wire_dtype` goes on the wire unless asked (the reference
+    exchanges fp32, main.py:627), so the result equals the single-process one to fp32 round-off.  The re-cut layout is rank 0's
+    broadcast order; a rank that observed another order raises (on every rank) instead of enqueueing mismatched all-reduces."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tail_default_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+    (_, p0, n0, n1, wires, raised0, wire_desc), (_, p1, _, _, _, raised1, _) = res
+    assert (p0 == p1).all() and n1 > n0 and set(wires) == {"None"}
+    assert wire_desc["slices"] == "float32" and wire_desc["tail"] == "float32"
+    assert "different orders" in raised0 and "different orders" in raised1
+    from feed_forward_vqgan_clip_amd.arena import ParamArena
+    net = _model()
+    arena = ParamArena(net, torch.float32, allow_cpu=True)
+    ref = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    for _ in range(3):
+        arena.zero_grad()
+        ((net(X) - Y) ** 2).mean().backward()
+        ref.step()
+    assert (torch.from_numpy(p0) - arena.params.detach()).abs().max().item() < 1e-6
+
+
+def test_bare_bench_command_spawns_the_ranks_and_propagates_their_exit_code():
+    """`python bench.py --gpus 2` without a launcher starts two ranks as children (bench.launch_ranks).  No GPU here: both ranks
+    get through the rendezvous and stop at "needs an MI355X" — the parent relays that and exits non-zero without a JSON line
+    (the GPU leg of the same contract: tests/test_distributed_gpu.py::test_bare_bench_command_launches_its_own_ranks)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU leg of the launch contract")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("needs an MI355X") >= 1 and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
 def test_sampler_matches_torch():
     from torch.utils.data import DistributedSampler as TorchSampler
 

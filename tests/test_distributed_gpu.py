@@ -224,3 +224,22 @@ def test_bucket_exchange_through_the_own_communicator(cuda):
     summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert summary["dp"]["bucket_exchange"].startswith("ffvc_allreduce_bucket") and summary["frac_bytes_early"] > 0.85
 
+
+
+def test_bare_bench_command_launches_its_own_ranks(cuda):
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE starts its two ranks itself (bench.launch_ranks:
+    a child `torch.distributed.run`, the parent never touches the GPU) and relays rank 0's JSON line as its last stdout line.
+    Two ranks share this box's one GPU (gloo exchange, FFVC_SHARE_DEVICE=1) — the launch contract is what is under test."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FFVC_DP_BACKEND="gloo", FFVC_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--depth", "2", "--dim", "128", "--cutn", "2", "--no-cpu-baseline", "--no-alt-dtype"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
+    assert line["config"]["dp"]["ranks"] == 2 and line["value"] > 0
