@@ -62,7 +62,8 @@ def build(args, device):
     cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=args.cutn,
                        batch_size=args.batch, repeat=1, nb_noise=None, diversity_coef=0, clip_model=args.clip_model,
                        model_type=args.model_type, vq_image_size=args.vq_image_size,
-                       augs=None if args.augs == "default" else args.augs.split(","))
+                       augs=None if args.augs == "default" else args.augs.split(","),
+                       augment_sequential=not getattr(args, "augment_fused", False))
     torch.manual_seed(1234)
     net = fmain.build_model(cfg, 256)
     mixer_sd = {k: v.detach().clone() for k, v in net.state_dict().items()} if args.keep_cpu_weights else None
@@ -122,14 +123,16 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     facs = (torch.rand(cutn * B, generator=g) * 0.1).view(-1, 1, 1, 1)
     noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
     from feed_forward_vqgan_clip_amd import augment as faug
-    prm = None if augs == "R" else faug.draw_params(cutn * B, 224, faug.DEFAULT if augs == "default" else
-                                                    tuple(a for a in augs.split(",") if a != "R"), generator=g)
+    # raw kornia draws, applied by the oracle as the reference applies them (nn.Sequential, operator after operator:
+    # oracle/kornia_aug.apply_chain)
+    chain = None if augs == "R" else faug.draw_chain(cutn * B, 224, faug.DEFAULT if augs == "default" else
+                                                     tuple(a for a in augs.split(",") if a != "R"), generator=g)
 
     def one(step):
         loss, _ = ostep.train_step_loss(
             lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=len([k for k in sd if k.endswith(".0.norm.weight")])),
             params, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(),
-            facs=facs, noise=noise, aug_params=prm)
+            facs=facs, noise=noise, aug_chain=chain)
         grads = torch.autograd.grad(loss, plist)
         with torch.no_grad():
             ostep.adam_step(plist, grads, state, 1e-3, step)
@@ -149,7 +152,7 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     out = {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
            "sample": f"{n} full oracle train step(s) (fwd+loss+bwd+Adam, fp32) at batch {B}, cutn {cutn}, same cfg2 "
                      f"models/shapes; {dt:.2f} s/step"}
-    return out, {"loss": loss0, "tok": tok, "facs": facs.view(-1), "noise": noise, "aug_params": prm}
+    return out, {"loss": loss0, "tok": tok, "facs": facs.view(-1), "noise": noise, "aug_chain": chain}
 
 
 def _relrms(a, b):
@@ -184,27 +187,30 @@ def full_size_parity(args, sds, ref):
         facs = torch.rand(cutn * B, generator=g) * 0.1
         noise = torch.randn(cutn * B, 3, 224, 224, generator=g)
         names = faug.DEFAULT if augs is None else tuple(a for a in augs if a != "R")
-        prm = faug.draw_params(cutn * B, 224, names, generator=g) if names else None
-        return tok, facs, noise, prm
+        chain = faug.draw_chain(cutn * B, 224, names, generator=g) if names else None
+        return tok, facs, noise, chain
 
     def make(cdt, B):
         cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=args.dim, depth=args.depth, dropout=0, cutn=cutn,
                            batch_size=B, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32",
-                           model_type="mlp_mixer", vq_image_size=16, augs=augs)
+                           model_type="mlp_mixer", vq_image_size=16, augs=augs, augment_sequential=not args.augment_fused)
         net = fmain.build_model(cfg, 256)
         net.load_state_dict(mixer_sd)
         net = net.cuda().prepare(cdt)
         return fmain.TrainStep(cfg, net, fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt),
                                FusedAdam(net.parameters(), lr=1e-3))
 
-    def run(st, tok, facs, noise, prm, force_idx=None):
+    def run(st, tok, facs, noise, chain, force_idx=None):
+        # the HIP step consumes the SAME raw draws through the plan the timed configuration uses (default: one launch per
+        # warp = kornia's order of resamples; --augment-fused: the composed single launch)
+        segs = None if chain is None else faug.to_device(faug.plan(chain, len(facs), 224, sequential=not args.augment_fused), "cuda")
         with torch.no_grad():
-            loss, mid = st.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(),
-                                        aug_params=None if prm is None else {k: v.cuda() for k, v in prm.items()},
-                                        force_idx=force_idx)
+            loss, mid = st.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), aug_params=segs, force_idx=force_idx)
         return float(loss), mid
 
-    res = {"batch": pb, "timed_dtype": args.dtype}
+    res = {"batch": pb, "timed_dtype": args.dtype,
+           "oracle_augmentation": "kornia 0.5.10 nn.Sequential restatement (oracle/kornia_aug.apply_chain) on the same raw draws",
+           "hip_augmentation": "fused single resample (opt-in)" if args.augment_fused else "sequential plan (default): one launch per warp"}
     tok, facs, noise, prm = inputs(pb, 99)
     cb = vq_sd["quantize.embedding.weight"]
     torch.set_num_threads(effective_cores())
@@ -212,7 +218,7 @@ def full_size_parity(args, sds, ref):
         oloss, omid = ostep.train_step_loss(
             lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=args.depth), mixer_sd, vq_sd, clip_sd,
             tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(), facs=facs.view(-1, 1, 1, 1),
-            noise=noise, aug_params=prm)
+            noise=noise, aug_chain=prm)
     res["loss_oracle_fp32"] = float(oloss)
     st32 = make(torch.float32, pb)
     l32, m32 = run(st32, tok, facs, noise, prm)
@@ -235,6 +241,8 @@ def full_size_parity(args, sds, ref):
             "rel_same_codes": abs(lsc - l32) / abs(l32),
             "rel_free": abs(ll - l32) / abs(l32),
             "rel_" + args.dtype: abs(ll - float(oloss)) / abs(float(oloss)),
+            "rel_free_vs_oracle": abs(ll - float(oloss)) / abs(float(oloss)),      # timed dtype, free-running, vs the kornia-chain CPU oracle
+            "rel_same_codes_vs_oracle": abs(lsc - float(oloss)) / abs(float(oloss)),
         })
         del stl
     del st32
@@ -250,6 +258,17 @@ def full_size_parity(args, sds, ref):
         res.update({"bench_batch": args.batch, "loss_hip_fp32_bench_batch": l32, "loss_timed_bench_batch": ll,
                     "rel_free_bench_batch": abs(ll - l32) / abs(l32),
                     "vq_agree_bench_batch": float((ml["indices"] == m32["indices"]).float().mean())})
+        if not args.no_oracle_bench_batch:
+            # the CPU oracle (kornia-chain augmentations) at the benchmark's own batch, forward only (~1 min of host time)
+            t0 = time.time()
+            with torch.no_grad():
+                ol, _ = ostep.train_step_loss(
+                    lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=args.depth), mixer_sd, vq_sd, clip_sd,
+                    tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(), facs=facs.view(-1, 1, 1, 1),
+                    noise=noise, aug_chain=prm)
+            res.update({"loss_oracle_fp32_bench_batch": float(ol), "oracle_bench_batch_s": round(time.time() - t0, 1),
+                        "rel_fp32_bench_batch_vs_oracle": abs(l32 - float(ol)) / abs(float(ol)),
+                        "rel_free_bench_batch_vs_oracle": abs(ll - float(ol)) / abs(float(ol))})
         del stl
         torch.cuda.empty_cache()
     return res
@@ -306,6 +325,8 @@ def main():
                     "(e4m3 activations / filters, e5m2 gradients, per-tensor delayed scaling; cfg5); NOT the headline configuration")
     ap.add_argument("--augs", default="default", help="'default' = the reference's Af,Pe,Ji,Er (main.py:164-165), or a "
                     "comma list, e.g. 'R'")
+    ap.add_argument("--augment-fused", action="store_true", help="opt-in: compose consecutive warps (Af -> Pe) into ONE interpolation / "
+                    "launch instead of kornia's sequential resamples (config augment_sequential: false); NOT what the reference computes")
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp32"],
                     help="compute dtype of the timed step: 16-bit storage (bf16 | f16: same MFMA rate, f16 = 8x finer "
                          "mantissa + loss-scaled backward) with fp32 accumulation, or exact fp32 MFMA")
@@ -321,6 +342,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step behind the text tower as ONE captured hipGraph (TrainStep.enable_graph): "
                     "for the launch-bound mappers (VitGAN / x-transformer: ~2400 launches per step); single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-bench-batch", action="store_true", help="skip the CPU oracle forward at the benchmark's batch in the parity leg")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second timing in the other 16-bit format")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", type=int, default=0, help="print the N most expensive GEMM shapes (stderr)")
@@ -418,6 +440,7 @@ def main():
                                f"{args.clip_model}, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
                    "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire, "hip_graph": bool(args.graph),
+                   "augmentation": "fused single resample (opt-in)" if args.augment_fused else "kornia order: one resample per warp (Af | Pe+Ji+Er)",
                    "dp": hvd.describe()},
         "final_loss": float(loss.item()),
         # average engine clock over the timed steps (s_memtime / s_memrealtime): the chip clocks to its power budget, so the

@@ -18,10 +18,13 @@ Two stages:
                                 clamps, random order: csrc/augment_cj.h), then the erase rectangle.  'Sh' / 'Et' / 'Ts' are their
                                 own image -> image kernels (csrc/augment_ops.hip) between fused segments.  A new segment starts
                                 wherever the list order leaves geometry -> colour -> erase (e.g. a warp after a jitter), so the
-                                order of the reference's nn.Sequential is kept; `sequential=True` additionally gives every
-                                resampling operator its own pass (kornia's sequential bilinear resamples: two interpolations for
-                                Af -> Pe instead of one).
-  draw_params(...)              the single-segment form used by the default configurations: plan(draw_chain(...)) flattened.
+                                order of the reference's nn.Sequential is kept; `sequential=True` (the default: what the
+                                reference computes) additionally gives every resampling operator its own pass (kornia's
+                                sequential bilinear resamples: two interpolations for Af -> Pe); `sequential=False` composes
+                                consecutive warps into one interpolation (one launch for the default set; opt-in, measurably not
+                                kornia's result: profiles/r04_augment_deviation.txt).
+  draw_params(...)              the single-launch (fused, sequential=False) form: plan(draw_chain(...)) flattened — the kernel's
+                                own formula, used by the kernel-level tests.
 
 Operators (probability p per sample unless noted; kornia names in main.py:164-198):
     'Af'  RandomAffine(degrees=15, translate=0.1, p=0.7, padding_mode='border')   angle U(-15,15) deg about ((W-1)/2,(H-1)/2);
@@ -240,7 +243,7 @@ def tps_params(src, dst):
                       w[:, 7].reshape(N, 2)], dim=1).float().contiguous()
 
 
-def plan(chain, N, S, src_size=None, sequential=False):
+def plan(chain, N, S, src_size=None, sequential=True):
     """-> list of segments: ("fused", params dict with pinv/ainv/cmat/coff/cj/erase/gn + "src"/"out" sides) or
     (name in DENSE, kernel parameters: on (N,) fp32 + factor | noise | tps).  See the module docstring."""
     side = int(src_size or S)
@@ -330,10 +333,18 @@ def draw_params(N, S, augs=DEFAULT, generator=None, p=0.7, src_size=None):
     """The single-launch form: -> dict of CPU tensors pinv (N,9), ainv (N,6), cmat (N,9), coff (N,3), cj (N,8, when the chain
     jitters), erase (N,4) i32, gn (N,).  Raises for chains that need more than one launch ('Sh', 'Et', 'Ts', or an order that
     leaves geometry -> colour -> erase): MakeCutouts runs those through plan()."""
-    segs = plan(draw_chain(N, S, augs, generator, p, src_size), N, S, src_size)
+    segs = plan(draw_chain(N, S, augs, generator, p, src_size), N, S, src_size, sequential=False)
     if len(segs) != 1:
         raise NotImplementedError(f"augs={list(augs)} needs {len(segs)} launches: use augment.plan() (MakeCutouts does)")
     prm = dict(segs[0][1])
     prm.pop("src")
     prm.pop("out")
     return prm
+
+
+def to_device(plan_or_params, device):
+    """plan() segments (or one parameter dict) with every tensor on `device`."""
+    mv = lambda d: {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}   # noqa: E731
+    if isinstance(plan_or_params, dict):
+        return mv(plan_or_params)
+    return [(kind, mv(prm)) for kind, prm in plan_or_params]

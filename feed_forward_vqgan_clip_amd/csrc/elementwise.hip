@@ -484,6 +484,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     ema_w = dev_hyper[4];
   }
   if (dev_scale) gscale *= dev_scale[0];      // global-norm clip coefficient computed on the device (no host sync)
+  // a NaN coefficient = the whole step is skipped (skip_step_on_overflow): the EMA copy keeps its state as well
+  if (!(fabsf(gscale) <= 3.0e38f)) ema = nullptr;
   // Non-finite gradients (an overflowing f16 backward, or inf x the clip coefficient 0 = NaN) must never reach p / m / v / ema:
   // such an element keeps its state (no update), and the launch counts the waves that saw one in bad_count, which the host
   // reads at its next logging synchronisation to back the loss scale off (optim.FusedAdam.check_overflow).

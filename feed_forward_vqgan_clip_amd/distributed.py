@@ -529,7 +529,11 @@ class DistributedOptimizer:
 
     def step(self, closure=None):
         fused = hasattr(self.opt, "arena") and hasattr(self.opt, "grad_scale")
-        if (is_distributed() and fused and self.overlap_update and not getattr(self, "_synced", False)):
+        # skip_step_on_overflow (f16 runs of main.train): the whole-step guard needs the sum of squares of the COMPLETE reduced
+        # bucket before the first element is updated, so the update cannot start slice by slice: that mode takes the
+        # synchronise-then-update path below (the ~2 ms Adam launch is then not hidden under the tail of the exchange)
+        guard = bool(getattr(self.opt, "skip_step_on_overflow", False)) and getattr(self.opt, "loss_scale", 1.0) != 1.0
+        if (is_distributed() and fused and self.overlap_update and not guard and not getattr(self, "_synced", False)):
             # bucket-wise update as the exchanges complete (no global-norm clip pending: that needs every slice first)
             self._flush_unlaunched()
             self._set_scale()

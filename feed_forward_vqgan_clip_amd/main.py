@@ -89,11 +89,14 @@ class MakeCutouts(nn.Module):
     'R' as fused resampling launches (ffvc_augment_fwd/bwd: one launch for the default set), 'Sh','Et','Ts' (sharpness / elastic /
     thin-plate spline) as their own image -> image kernels in between (augment.plan()); the additive noise
     `U(0,noise_fac)*N(0,1)` (:222-225); with interpolate=True adaptive average pooling to interp_size (:226-228).
-    `sequential=True` (config `augment_sequential`): every resampling operator gets its own pass, as kornia's nn.Sequential
-    resamples (two bilinear interpolations for Af -> Pe instead of one); default: fused."""
+    `sequential=True` (THE DEFAULT since round 5; config `augment_sequential`): every resampling operator gets its own pass, as
+    kornia's nn.Sequential resamples (main.py:199: two bilinear interpolations for Af -> Pe) — what the reference computes.
+    `sequential=False` composes consecutive warps into one interpolation (one launch for the default set): cheaper by one
+    224x224 pass each way and measurably NOT what kornia computes (image 1.3e-2 rel-rms, loss up to 6.4e-5,
+    profiles/r04_augment_deviation.txt), so it is opt-in."""
 
     def __init__(self, cut_size, cutn, cut_pow=1.0, pool_size=None, interp_size=None, augs=None, pool=True,
-                 interpolate=False, sequential=False):
+                 interpolate=False, sequential=True):
         super().__init__()
         augs = tuple(augs) if augs else ("Af", "Pe", "Ji", "Er")      # main.py:164-165 (empty list -> defaults)
         for a in augs:
@@ -425,7 +428,7 @@ class TrainStep:
                                         pool_size=config.get("pool_size", self.clip_size),
                                         interpolate=config.get("interpolate", False),
                                         interp_size=config.get("interp_size", self.clip_size),
-                                        sequential=config.get("augment_sequential", False))
+                                        sequential=config.get("augment_sequential", True))
         if config.get("noise_fac") is not None:
             self.make_cutouts.noise_fac = config.get("noise_fac")
         if config.diversity_coef:
@@ -563,7 +566,7 @@ class TrainStep:
         self._g_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._g_stream):
             self._g_feats.copy_(self.features(warmup_tokens))
-            self._graph_body()
+            self._g_warm_out = self._graph_body()
         torch.cuda.current_stream().wait_stream(self._g_stream)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -603,13 +606,18 @@ class TrainStep:
         self.prefetch(next_inp)
         self._refresh_static_aug(self.cutn * self._g_B * self.repeat, 16 * int(self.config.vq_image_size))
         if getattr(self.opt, "loss_scale", 1.0) != self._g_ls:       # the loss scale is baked into the recorded backward
+            # re-capture.  enable_graph's eager warm-up IS a training step on `inp` (optimizer step counted once): it stands in
+            # for this call's replay, so the batch is applied once and the scheduler ticks once
             self._graph = None
             self.enable_graph(self._g_B, inp)
-        self.opt.graph_pre_step()
-        self._graph.replay()
+            out = self._g_warm_out
+        else:
+            self.opt.graph_pre_step()
+            self._graph.replay()
+            out = self._g_out
         if self.scheduler is not None:
             self.scheduler.step()
-        return self._g_out
+        return out[0].clone(), out[1]          # the captured loss tensor is overwritten by the next replay: hand out a copy
 
     def __call__(self, inp, out=None, facs=None, noise=None, aug_params=None, next_inp=None, noise_vec_in=None):
         if (self._graph is not None and out is None and facs is None and noise is None and aug_params is None and

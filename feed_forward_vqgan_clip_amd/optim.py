@@ -42,8 +42,12 @@ class FusedAdam(torch.optim.Optimizer):
         self.scale_growth_interval, self.scale_max, self.scale_min = 2000, 65536.0, 1.0
         # skip_step_on_overflow: with a loss scale != 1 and no clip_grad_norm pending, take one sum-of-squares pass over the gradient
         # bucket (1.3 GB, ~0.3 ms at cfg2) and feed the Adam kernel a NaN coefficient when it is not finite, so that an overflowed
-        # backward skips the WHOLE update (parameters, moments and EMA keep their state in every element) instead of only the
-        # elements that overflowed.  main.train() switches it on; bench.py times the step without it (stated in the line).
+        # backward skips the WHOLE update (parameters, moments and the EMA copy keep their state in every element: the kernel gates
+        # the EMA blend on the coefficient too) instead of only the elements that overflowed.  The HOST counters still advance on
+        # such a step (`_step` -> bias corrections, `_ema_updates` -> torch_ema's warm-up decay): the host does not learn of the
+        # overflow until check_overflow(), and one tick of either moves the next update by < 1e-3 relative after a few hundred
+        # steps.  Under DistributedOptimizer the guard forces the synchronise-then-update path (distributed.py::step).
+        # main.train() switches it on; bench.py times the step without it (stated in the line).
         self.skip_step_on_overflow = False
         for p in a.plist:
             o, n = a.param_range(p)

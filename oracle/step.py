@@ -93,16 +93,27 @@ def spherical_loss(embed, target_feats, cutn, coef=1.0):
 
 def train_step_loss(mapper_fn, mapper_sd, vq_sd, clip_sd, tokens, *, cutn, cut_size, z_min, z_max,
                     facs=None, noise=None, vq_cfg=ovq.F16_16384, clip_heads=(None, None),
-                    pool_size=None, text_feats=None, decode_fn=None, aug_params=None, quick_gelu=True):
+                    pool_size=None, text_feats=None, decode_fn=None, aug_params=None, quick_gelu=True, aug_chain=None):
     """Forward half of one training step (main.py:729-811,831) with repeat=1, noise_dim=0,
-    l2/tv/diversity coefficients 0.  Returns (loss, dict of intermediates)."""
+    l2/tv/diversity coefficients 0.  Returns (loss, dict of intermediates).
+
+    Augmentations: `aug_chain` = the raw per-operator draws ([(name, dict)], the layout of kornia_aug.sample_chain) applied
+    as the reference applies them — `nn.Sequential(*augment_list)` (main.py:199,219), one kornia operator after the other on
+    the previous one's output (kornia_aug.apply_chain).  This is the oracle for MakeCutouts' default path.  `aug_params`
+    (composed single-resample parameters -> augment_reference below) states the formula of the opt-in FUSED launch only."""
     if text_feats is None:
         with torch.no_grad():
             text_feats = oclip.encode_text(clip_sd, tokens, clip_heads[1], quick_gelu).float()     # main.py:733,737
     z = mapper_fn(mapper_sd, text_feats).contiguous()                                   # :754-757
     z = clamp_with_grad(z, z_min, z_max)                                                # :763
     xr = synth(vq_sd, z, vq_cfg, decode_fn)                                             # :767
-    if aug_params is None:
+    if aug_chain is not None:                                                           # main.py:212-225 with default augs
+        from . import kornia_aug
+        pooled = (F.adaptive_avg_pool2d(xr, cut_size) + F.adaptive_max_pool2d(xr, cut_size)) / 2   # :213-215
+        x = kornia_aug.apply_chain(pooled.repeat(cutn, 1, 1, 1), aug_chain)                       # :218-219
+        if facs is not None:
+            x = x + facs.view(-1, 1, 1, 1) * noise                                                 # :222-225
+    elif aug_params is None:
         x = make_cutouts(xr, cut_size=cut_size, cutn=cutn, facs=facs, noise=noise, pool_size=pool_size)  # :796
     else:                                                                               # default augs, explicit parameters
         pooled = (F.adaptive_avg_pool2d(xr, cut_size) + F.adaptive_max_pool2d(xr, cut_size)) / 2   # :217

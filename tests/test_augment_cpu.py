@@ -110,9 +110,11 @@ def test_wider_augmentation_set_parameters():
         A.draw_params(4, S, augs=("Sh",))
     kinds = lambda augs, **kw: [k for k, _ in A.plan(A.draw_chain(8, S, augs, g), 8, S, **kw)]   # noqa: E731
     assert kinds(("Ro", "Af")) == ["fused", "fused"] and kinds(("Ji", "Af")) == ["fused", "fused"]
-    assert kinds(A.DEFAULT) == ["fused"] and kinds(A.DEFAULT, sequential=True) == ["fused", "fused"]
+    # default = kornia's sequential resampling (one warp per launch); the composed single launch is the opt-in
+    assert kinds(A.DEFAULT) == ["fused", "fused"] and kinds(A.DEFAULT, sequential=False) == ["fused"]
     assert kinds(("Sh", "Af", "Et", "Ts", "Er")) == ["fused", "Sh", "fused", "Et", "Ts", "fused"]
-    assert kinds(("Af", "Pe", "Sh")) == ["fused", "Sh", "fused"]
+    assert kinds(("Af", "Pe", "Sh"), sequential=False) == ["fused", "Sh", "fused"]
+    assert kinds(("Af", "Pe", "Sh")) == ["fused", "fused", "Sh", "fused"]
 
 
 def test_fused_plan_matches_the_kornia_restatement_where_they_must_agree():

@@ -313,7 +313,10 @@ def _timed_dtype_vs_oracle(cfg, mapper_fn, clip_arch, quick, Bn, cutn, seed):
     tok = fmain.synthetic_tokens(Bn, seed=seed + 2)
     g = torch.Generator().manual_seed(seed + 6)
     facs, noise = torch.rand(cutn * Bn, generator=g) * 0.1, torch.randn(cutn * Bn, 3, 224, 224, generator=g)
-    prm = faug.draw_params(cutn * Bn, 224, generator=g)
+    # default augmentations: ONE set of raw kornia draws.  The oracle applies them as the reference does (kornia's nn.Sequential,
+    # operator after operator: oracle/kornia_aug.apply_chain), the HIP path through MakeCutouts' default (sequential) plan
+    chain = faug.draw_chain(cutn * Bn, 224, generator=g)
+    segs = faug.to_device(faug.plan(chain, cutn * Bn, 224, sequential=True), "cuda")
     res = {}
     oidx = None
     for name, cdt in (("fp32", torch.float32), ("f16", torch.float16)):
@@ -322,11 +325,12 @@ def _timed_dtype_vs_oracle(cfg, mapper_fn, clip_arch, quick, Bn, cutn, seed):
         net = net.cuda().prepare(cdt)
         vq, perceptor = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt, quick_gelu=quick)
         stepper = fmain.TrainStep(cfg, net, vq, perceptor, FusedAdam(net.parameters(), lr=cfg.lr))
-        kw = dict(facs=facs.cuda(), noise=noise.cuda(), aug_params={k: v.cuda() for k, v in prm.items()})
+        assert stepper.make_cutouts.sequential                      # the default path IS the kornia-faithful one
+        kw = dict(facs=facs.cuda(), noise=noise.cuda(), aug_params=segs)
         if oidx is None:
             with torch.no_grad():
                 oloss, omid = ostep.train_step_loss(mapper_fn, msd, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=vq.z_min,
-                                                    z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise, aug_params=prm,
+                                                    z_max=vq.z_max, facs=facs.view(-1, 1, 1, 1), noise=noise, aug_chain=chain,
                                                     quick_gelu=quick)
             oidx = ostep.vq_indices(omid["z"].movedim(1, 3), vq_sd["quantize.embedding.weight"])
             res["oracle"] = oloss.item()

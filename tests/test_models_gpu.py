@@ -373,26 +373,30 @@ def test_train_step_matches_oracle(cuda, cdt):
 
 @pytest.mark.parametrize("cdt", [F32, BF16, F16])
 def test_train_step_default_augs_matches_oracle(cuda, cdt):
-    """Same step with the reference's DEFAULT augmentation set (Af, Pe, Ji, Er; main.py:164-165), the random
-    parameters drawn once and fed to both sides."""
+    """Same step with the reference's DEFAULT augmentation set (Af, Pe, Ji, Er; main.py:164-165): ONE set of raw kornia draws.
+    The oracle applies them as the reference does — kornia's nn.Sequential, operator after operator (main.py:199,219;
+    oracle/kornia_aug.apply_chain) — the HIP step through MakeCutouts' default plan (one resample per warp, round 5)."""
     from feed_forward_vqgan_clip_amd import augment as A
     from oracle import mappers as omap
     from oracle import step as ostep
     cfg, net, vq, perceptor, opt, clip_sd, vq_sd, tok, facs, noise = _tiny_step(cdt)
     cfg.augs = None
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
-    assert stepper.make_cutouts.augs == ("Af", "Pe", "Ji", "Er")
-    prm = A.draw_params(16, 32, generator=torch.Generator().manual_seed(5))
-    prm["erase"][:] = torch.tensor([3, 4, 15, 20], dtype=torch.int32)
+    assert stepper.make_cutouts.augs == ("Af", "Pe", "Ji", "Er") and stepper.make_cutouts.sequential
+    chain = A.draw_chain(16, 32, generator=torch.Generator().manual_seed(5))
+    er = dict(chain)["Er"]                                   # a rectangle that is certainly there
+    er["on"][:] = True
+    er["xs"][:], er["ys"][:], er["widths"][:], er["heights"][:] = 3, 4, 12, 16
+    segs = A.plan(chain, 16, 32, sequential=True)
+    assert [k for k, _ in segs] == ["fused", "fused"]         # Af | Pe + Ji + Er
     msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(),
-                                     aug_params={k: v.cuda() for k, v in prm.items()})
+    loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), aug_params=A.to_device(segs, "cuda"))
     opt.zero_grad()
     loss.backward()
     osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
     oloss, omid = ostep.train_step_loss(
         lambda sd, f: omap.mixer_forward(sd, f, image_size=12, channels=64, depth=2), osd, vq_sd, clip_sd, tok,
-        cutn=4, cut_size=32, z_min=vq.z_min, z_max=vq.z_max, facs=facs, noise=noise, vq_cfg=TINY_VQ, aug_params=prm)
+        cutn=4, cut_size=32, z_min=vq.z_min, z_max=vq.z_max, facs=facs, noise=noise, vq_cfg=TINY_VQ, aug_chain=chain)
     oloss.backward()
     rel = abs(loss.item() - oloss.item()) / abs(oloss.item())
     print(f"[{cdt}] default augs: loss hip={loss.item():.7f} oracle={oloss.item():.7f} rel={rel:.2e}")

@@ -523,11 +523,13 @@ def test_adam_skips_non_finite_gradients_and_backs_the_loss_scale_off(cuda):
     assert opt.check_overflow() == 0 and opt.loss_scale == 512.0
     # with global-norm clipping the coefficient is 0 x inf = NaN for every element: the whole step is skipped, nothing is poisoned
     a.grads.copy_(g0)
-    p1 = a.params.clone()
+    p1, e1 = a.params.clone(), opt._ema.clone()
+    assert not torch.equal(e1, p1)                    # (the EMA copy lags the parameters: a blend would be visible)
     opt.clip_grad_norm_(1.0)
     opt.step()
     torch.cuda.synchronize()
     assert torch.equal(a.params, p1) and torch.isfinite(opt._v).all()
+    assert torch.equal(opt._ema, e1)                  # a skipped step leaves the EMA copy alone too
     assert opt.check_overflow() >= 1 and opt.loss_scale == 256.0
     # regrowth after an interval of clean steps
     opt.scale_growth_interval = 2
