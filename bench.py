@@ -274,6 +274,88 @@ def full_size_parity(args, sds, ref):
     return res
 
 
+HBM_ATTAINABLE_BPS = 6.3e12      # what a streaming kernel reaches of the 8 TB/s HBM3E peak on this part (MI355X_MICROARCH.md)
+
+
+def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_path=None):
+    """What the step's own kernels allow: every distinct GEMM launch of the step re-issued ALONE, back to back
+    (same pointers / epilogue / flags: kernels.REPLAY), HBM-bound kernels at algorithmic bytes / 6.3 TB/s, everything else
+    (attention, augmentation, reductions, glue) at its measured time in a SERIALISED step (weight gradients on the main stream,
+    no text prefetch: no co-running kernels).  -> dict for `roofline` + the table rows (kernel | launches | isolated us |
+    in-step us | lost ms), also written to `table_path`."""
+    from feed_forward_vqgan_clip_amd import kernels as K
+    from feed_forward_vqgan_clip_amd import ops
+    ops.set_wgrad_side_stream(False)
+    K.PROFILE, K.HBM_PROFILE, K.REPLAY = [], [], []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    stepper(tok)
+    ev1.record()
+    torch.cuda.synchronize()
+    ops.set_wgrad_side_stream(True)
+    prof_b, hbm_b, rep = K.PROFILE, K.HBM_PROFILE, K.REPLAY
+    K.PROFILE = K.HBM_PROFILE = K.REPLAY = None
+    wall_b = ev0.elapsed_time(ev1)
+    gemm_b = [e0.elapsed_time(e1) for _, _, e0, e1, _ in prof_b]
+    hbm_b_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in hbm_b)
+    rest_ms = max(0.0, wall_b - sum(gemm_b) - hbm_b_ms)
+    aligned = len(prof_instep) == len(prof_b) == len(rep)        # same program -> same launch sequence in both steps
+    rows = {}
+    for i, (cls, key, desc, keep) in enumerate(rep):
+        r = rows.setdefault((cls,) + key, {"n": 0, "instep": 0.0, "serial": 0.0, "desc": desc, "flop": 2.0 * key[0] * key[1] * key[2] * key[3]})
+        r["n"] += 1
+        if aligned:
+            r["instep"] += prof_instep[i][2].elapsed_time(prof_instep[i][3])
+            r["serial"] += gemm_b[i]
+    for r in rows.values():                                       # the isolated duration: 2 warm-up + 8 timed launches, back to back
+        K.replay_gemm(r["desc"], 2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        K.replay_gemm(r["desc"], 8)
+        e1.record()
+        torch.cuda.synchronize()
+        r["iso_us"] = e0.elapsed_time(e1) / 8 * 1e3
+    del rep
+    gemm_iso_ms = sum(r["n"] * r["iso_us"] for r in rows.values()) / 1e3
+    hb = {}
+    for name, nbytes, e0, e1 in hbm_b:
+        h = hb.setdefault(name, {"n": 0, "bytes": 0.0, "serial": 0.0})
+        h["n"] += 1
+        h["bytes"] += nbytes
+        h["serial"] += e0.elapsed_time(e1)
+    hbm_model_ms = sum(h["bytes"] for h in hb.values()) / HBM_ATTAINABLE_BPS * 1e3
+    att = gemm_iso_ms + hbm_model_ms + rest_ms
+    lines = [f"# attainable = sum(GEMM launches x isolated us) {gemm_iso_ms:.2f} ms + HBM kernels' algorithmic bytes / {HBM_ATTAINABLE_BPS / 1e12:.1f} TB/s "
+             f"{hbm_model_ms:.2f} ms + the rest as measured in a serialised step {rest_ms:.2f} ms = {att:.2f} ms; step {ms_per_step:.2f} ms "
+             f"-> frac_of_attainable {att / ms_per_step:.3f}; serialised step (no side streams) {wall_b:.2f} ms",
+             "# kernel class | M N K batch split_k flags act | launches/step | isolated us | TFLOP/s isolated | in-step us | serialised-step us | lost ms/step (in-step - isolated)"]
+    for k, r in sorted(rows.items(), key=lambda kv: -(kv[1]["instep"] - kv[1]["n"] * kv[1]["iso_us"] / 1e3)):
+        ins, ser = r["instep"] / r["n"] * 1e3, r["serial"] / r["n"] * 1e3
+        lines.append(f"{k[0]:12s} {k[1]:6d} {k[2]:6d} {k[3]:6d} b{k[4]:<3d} sk{k[5]:<2d} f{k[6]:<5d} a{k[7]} | {r['n']:4d} | {r['iso_us']:8.1f} | "
+                     f"{r['flop'] / (r['iso_us'] * 1e-6) / 1e12:7.1f} | {ins:8.1f} | {ser:8.1f} | {r['instep'] - r['n'] * r['iso_us'] / 1e3:7.3f}")
+    lines.append("# HBM-bound kernel | launches/step | MB/launch | model us (bytes / 6.3 TB/s) | in-step us | serialised-step us | lost ms/step")
+    hi = {}
+    for name, nbytes, e0, e1 in hbm_instep or []:
+        a = hi.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+    for name, h in sorted(hb.items(), key=lambda kv: -kv[1]["serial"]):
+        model = h["bytes"] / h["n"] / HBM_ATTAINABLE_BPS * 1e6
+        ins = hi.get(name, [1, 0.0])
+        lines.append(f"{name:28s} | {h['n']:4d} | {h['bytes'] / h['n'] / 1e6:8.1f} | {model:8.1f} | {ins[1] / max(ins[0], 1) * 1e3:8.1f} | "
+                     f"{h['serial'] / h['n'] * 1e3:8.1f} | {ins[1] - h['n'] * model / 1e3:7.3f}")
+    if table_path:
+        os.makedirs(os.path.dirname(os.path.abspath(table_path)), exist_ok=True)
+        with open(table_path, "w") as f:
+            f.write("\n".join(lines) + "\n")
+    return {"attainable_ms": att, "frac_of_attainable": att / ms_per_step,
+            "attainable_parts_ms": {"gemm_isolated": gemm_iso_ms, "hbm_at_6.3TBps": hbm_model_ms, "rest_serialised": rest_ms},
+            "serialised_step_ms": wall_b, "attainable_aligned": aligned,
+            "attainable_note": "every distinct GEMM launch of the step replayed alone (same descriptor), HBM kernels at bytes / 6.3 TB/s, "
+                               "everything else at its time in a serialised step; frac_of_attainable = attainable_ms / ms_per_step"}, lines
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` started bare (no WORLD_SIZE): start the N ranks as CHILD processes — one
     `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` — before this process has touched the GPU
@@ -345,6 +427,8 @@ def main():
     ap.add_argument("--no-oracle-bench-batch", action="store_true", help="skip the CPU oracle forward at the benchmark's batch in the parity leg")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second timing in the other 16-bit format")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-attainable", action="store_true", help="skip the isolated-replay leg (roofline.attainable_ms)")
+    ap.add_argument("--isolated-table", default=None, help="write the kernel | launches | isolated us | in-step us | lost ms table here")
     ap.add_argument("--gemm-shapes", type=int, default=0, help="print the N most expensive GEMM shapes (stderr)")
     ap.add_argument("--grad-wire-tail", default="fp32", choices=["fp32", "bf16"],
                     help="wire format of the exposed tail slices only (distributed.DistributedOptimizer tail policy)")
@@ -536,6 +620,11 @@ def main():
         # HBM-bound kernels of the step: algorithmic bytes / HIP-event time, against the 8 TB/s HBM3E peak
         out["hbm_kernels"] = {k_: {"launches": v[0], "ms": v[2] * 1e3, "GB/s": v[1] / max(v[2], 1e-12) / 1e9,
                                    "frac_of_8TBps": v[1] / max(v[2], 1e-12) / 8e12} for k_, v in hagg.items()}
+        if world == 1 and not args.no_attainable:
+            att, table = attainable_leg(stepper, toks[:B], prof, hb, ms_per_step, args.isolated_table)
+            out["roofline"].update(att)
+            if args.gemm_shapes:
+                print("\n".join(table), file=sys.stderr)
     if world == 1 and not args.no_alt_dtype and args.dtype in ("f16", "bf16") and not args.clip_fp8 and not args.dec_fp8:
         # the same step in the OTHER 16-bit storage format (BASELINE's bf16 when the headline is f16), same box, same inputs
         alt = "bf16" if args.dtype == "f16" else "f16"

@@ -89,6 +89,9 @@ class GemmDesc(Structure):
         ("sk_slices", c_int32),
         ("y8_state", c_void_p),
         ("y8_fmt", c_int32),
+        ("grp_n", c_int32),
+        ("grp_xoff", c_int64 * 8),
+        ("grp_woff", c_int64 * 8),
     ]
 
 

@@ -540,6 +540,13 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   if (d.x_mi) {
     FFVC_CHECK_ARG(d.x_mode == FFVC_OP_KMAJOR && mult(d.x_so, epc), "ffvc_gemm: x row map needs a K-major X and aligned x_so");
   }
+  if (d.grp_n != 0) {
+    FFVC_CHECK_ARG(d.grp_n > 0 && d.grp_n <= 8 && d.grp_n == d.batch && d.batch_inner == 1 && d.x_mode == FFVC_OP_TRANS &&
+                       d.w_mode == FFVC_OP_TRANS && d.in_dtype != FFVC_F32 && d.split_k == 1,
+                   "ffvc_gemm: grouped launch needs grp_n == batch <= 8, batch_inner 1, TRANS x TRANS 16-bit operands, split_k 1");
+    for (int i = 0; i < d.grp_n; ++i)
+      FFVC_CHECK_ARG(mult(d.grp_xoff[i], 8) && mult(d.grp_woff[i], 8), "ffvc_gemm: grouped operand offsets must keep 16-byte alignment");
+  }
   if (d.y_sm == 0 && d.y_mi == 0) d.y_sm = d.N;
   // vectorised epilogue only when every row offset keeps 16-byte (fp32) / 8-byte (bf16) alignment
   int vec_ok = mult(d.y_sm, 4) && mult(d.y_so, 4) && mult(d.ybo, 4) && mult(d.ybi, 4) &&
@@ -572,6 +579,11 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_SPLITK_INKERNEL) || d.split_k == 1,
                  "ffvc_gemm: FFVC_F_SPLITK_INKERNEL: this shape / alignment does not take an LDS-DMA kernel that implements it");
+  if (d.grp_n != 0) {
+    ffvc_set_error("ffvc_gemm: grouped launch: this shape / alignment does not take the 256x256 LDS-DMA weight-gradient kernel "
+                   "(M=%d N=%d K=%d)", d.M, d.N, d.K);
+    return FFVC_E_UNSUPPORTED;
+  }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_GN_SUMS), "ffvc_gemm: FFVC_F_GN_SUMS is only available on the bf16 LDS-DMA path");
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_COLSUM), "ffvc_gemm: FFVC_F_COLSUM is only available on the 16-bit LDS-DMA path");
   int rc;

@@ -728,6 +728,9 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     if (env_bm == 1 && d.M >= 1024 && d.N >= 1024 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.K >= 8192 && d.batch == 1 &&
         (int64_t)(d.M / 256) * (d.N / 256) * (d.split_k < 1 ? 1 : d.split_k) >= 192)
       return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
+    // grouped weight gradients (grp_n layers in one launch, full K per tile): always the 256x256 tile
+    if (d.grp_n > 0 && d.grp_n == d.batch && (d.M % 256) == 0 && (d.N % 256) == 0 && d.split_k <= 1 && d.slab_stride == 0 && vec_ok == 2)
+      return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
     return 0;
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return ffvc_gemm2_launch_nn(d, st, vec_ok, zero, cfg);

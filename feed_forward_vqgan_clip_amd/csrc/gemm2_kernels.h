@@ -628,6 +628,14 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   }
   const uint16_t* xb = (const uint16_t*)p.x + zo * p.xbo + zi * p.xbi;
   const uint16_t* wb = (const uint16_t*)p.w + zo * p.wbo + zi * p.wbi;
+  if constexpr (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS && BM == 256 && BN == 256) {
+    // grouped weight gradients (ffvc.h grp_*): every batch entry is another layer's operand pair, taken from an offset table in
+    // the kernel arguments (wave-uniform index -> scalar loads); y keeps the constant stride ybo
+    if (p.grp_n > 0) {
+      xb = (const uint16_t*)p.x + p.grp_xoff[z & 7];
+      wb = (const uint16_t*)p.w + p.grp_woff[z & 7];
+    }
+  }
 
   using XDma = typename std::conditional<
       XMODE == FFVC_OP_CONV3X3, typename std::conditional<BUF, ConvDmaB<BM, NW>, ConvDma<BM, NW>>::type,

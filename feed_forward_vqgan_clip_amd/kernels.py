@@ -31,6 +31,18 @@ _GEMM_CLASS = {(OP_KMAJOR, OP_KMAJOR): "gemm_nt", (OP_CONV3X3, OP_KMAJOR): "conv
                (OP_KMAJOR, OP_TRANS): "gemm_nn", (OP_TRANS, OP_KMAJOR): "gemm_tk"}
 
 
+# Optional capture for replay (bench.py `roofline.attainable_ms`): when REPLAY is a list, every ffvc_gemm launch appends
+# (class, key, descriptor, tensors kept alive) so that the SAME launch — same pointers, epilogue, flags — can be re-issued alone,
+# back to back, after the step (replay_gemm): its isolated duration next to the in-step one.
+REPLAY = None
+
+
+def replay_gemm(desc, n=1):
+    lib = _lib.load()
+    for _ in range(n):
+        _lib.check(lib.ffvc_gemm(byref(desc), stream_ptr()), "ffvc_gemm (replay)")
+
+
 # Optional per-launch timing of the HBM-bound kernels (bench.py `hbm_kernels`): when HBM_PROFILE is a list, the launchers
 # below bracket their kernel with HIP events on the launch stream and append (name, algorithmic bytes, events).
 HBM_PROFILE = None
@@ -165,6 +177,9 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
               x_map is None and y_map is None and r_map is None and kseg == 0 and slab_stride == 0 and alpha == 1.0 and
               (flags & ~(F_OUT_F32 | F_RES_F32)) == 0 and (ldx in (0, K)) and (ldw in (0, K)) and
               bool(lib.ffvc_gemm_skinny_ok(tail, N, K)))
+    if REPLAY is not None and not skinny:
+        REPLAY.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
+                       (M, N, K, max(1, batch), split_k, int(d.flags), int(act)), d, (x, w, y, bias, residual, aux, colsum, gn_sums)))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -995,6 +1010,47 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, in_kernel=False, atomic=
     gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
     _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
     return out
+
+
+def gemm_grouped_wgrad(dys, xs, out0, ystride, M, N, K, ldx, ldw):
+    """ONE launch for the weight gradients of len(dys) layers of the same kind (include/ffvc.h grp_*):
+        out_z[M, N] (fp32, at out0 + z * ystride elements) += dys[z][K, ldx>=M]^T @ xs[z][K, ldw>=N],   z = 0 .. len(dys) - 1,
+    every 256x256 tile with its full reduction (no split-K, no slabs, no reduce pass).  dys / xs: lists of 16-bit [rows, ld]
+    tensors (separate allocations; addressed through signed element offsets from the first one)."""
+    G = len(dys)
+    if not (2 <= G <= 8) or len(xs) != G:
+        raise ValueError("gemm_grouped_wgrad: 2..8 operand pairs")
+    _need_cuda(out0, *dys, *xs)
+    d = GemmDesc()
+    es = dys[0].element_size()
+    d.x, d.w, d.y = dys[0].data_ptr(), xs[0].data_ptr(), out0.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.x_mode, d.w_mode = OP_TRANS, OP_TRANS
+    d.in_dtype = dtype_code(dys[0].dtype)
+    d.act, d.flags, d.split_k, d.alpha = ACT_NONE, F_OUT_F32 | F_ACCUM_OUT, 1, 1.0
+    d.ldx, d.ldw = ldx, ldw
+    d.y_mi, d.y_so, d.y_sm = 0, 0, N
+    d.r_mi, d.r_so, d.r_sm = 0, 0, N
+    d.batch, d.batch_inner = G, 1
+    d.ybo = ystride
+    d.grp_n = G
+    for i in range(G):
+        if dys[i].dtype != dys[0].dtype or xs[i].dtype != dys[0].dtype:
+            raise TypeError("gemm_grouped_wgrad: operand dtypes differ")
+        dx, dw = dys[i].data_ptr() - d.x, xs[i].data_ptr() - d.w
+        if dx % es or dw % es:
+            raise ValueError("gemm_grouped_wgrad: misaligned operand")
+        d.grp_xoff[i], d.grp_woff[i] = dx // es, dw // es
+    if REPLAY is not None:
+        REPLAY.append(("gemm_tn" + {torch.float16: "_f16"}.get(dys[0].dtype, "_bf16"), (M, N, K, G, 1, int(d.flags), 0), d,
+                       (tuple(dys), tuple(xs), out0)))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm (grouped)")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("gemm_tn" + {torch.float16: "_f16"}.get(dys[0].dtype, "_bf16"), 2.0 * M * N * K * G, e0, e1, (M, N, K, G, 1)))
 
 
 class RcclComm:

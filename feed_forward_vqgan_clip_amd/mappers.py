@@ -95,6 +95,9 @@ class Mixer(_MapperBase):
             tok, ch = self.mixer[i][0], self.mixer[i][1]
             self._blocks.append((tok.norm, mk(tok.fn[0].weight, tok.fn[0].bias), mk(tok.fn[3].weight, tok.fn[3].bias),
                                  ch.norm, mk(ch.fn[0].weight, ch.fn[0].bias), mk(ch.fn[3].weight, ch.fn[3].bias)))
+        # the channel MLP's two weight gradients of consecutive blocks go out as grouped launches (ops.WgradGroup)
+        ops.group_weights([b[4] for b in self._blocks])
+        ops.group_weights([b[5] for b in self._blocks])
 
     def forward(self, x):
         self._arena()

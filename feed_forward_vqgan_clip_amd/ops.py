@@ -36,13 +36,14 @@ from .kernels import ACT_GELU, ACT_NONE, ACT_QUICKGELU  # noqa: F401
 class Weights:
     """fp32 master weight [N, K] (+ bias [N]) with compute-dtype shadows."""
 
-    __slots__ = ("weight", "bias", "sh", "sht", "N", "K", "on_grad", "fp8")
+    __slots__ = ("weight", "bias", "sh", "sht", "N", "K", "on_grad", "fp8", "group")
 
     def __init__(self, weight, bias, sh, sht, on_grad=None):
         self.weight, self.bias, self.sh, self.sht = weight, bias, sh, sht
         self.N, self.K = sh.shape[0], sh.shape[1]
         self.on_grad = on_grad
         self.fp8 = None
+        self.group = None           # (WgradGroup, index): weight gradient deferred into a grouped launch (group_weights)
 
     @staticmethod
     def frozen(weight, bias, cdt, need_dgrad=True, fp8=False):
@@ -123,11 +124,17 @@ def _end_of_backward():
     # default stream, not necessarily the stream the step runs on (a step on a side stream, a stream capture): join the stream that
     # forked the gradient work.
     _SIDE["cb"] = False
+    if _PENDING_GROUPS:
+        # (on the thread that finishes the graph task: enqueue from the stream the backward pass ran on)
+        with torch.cuda.stream(_SIDE["main"] if _SIDE["main"] is not None else torch.cuda.current_stream()):
+            flush_wgrad_groups()
     join_side_stream(_SIDE["main"])
 
 
 def join_side_stream(stream=None):
     """Make `stream` (default: the current stream) wait for all outstanding side-stream gradient work."""
+    if _PENDING_GROUPS:
+        flush_wgrad_groups()
     if _SIDE["dirty"] and _SIDE["stream"] is not None:
         (stream or torch.cuda.current_stream()).wait_stream(_SIDE["stream"])
         _SIDE["dirty"] = False
@@ -174,9 +181,111 @@ def _split_k(n_out, k_out, red, bk, big_tiles=False):
     return max(1, min((_SK_TARGET + tiles - 1) // tiles, red // (8 * bk)))
 
 
+# ---------------------------------------------------------------------------
+# grouped weight gradients (round 5)
+# ---------------------------------------------------------------------------
+# One weight gradient of the Mixer's channel MLP (1024 x 4096 from a 16384-row reduction, mlp_mixer_pytorch.py:16-23) is 64 tiles
+# of 256x256: a quarter of the chip.  Rounds 2-4 cut it 4 ways along K into fp32 slabs + one ffvc_slab_reduce (1.8x the algorithmic
+# HBM traffic, 130 extra launches per step).  Weight gradients are consumed only by the all-reduce / optimizer, so nothing forces
+# them out layer by layer: the same Linear kind of `size` consecutive layers is deferred until the last of them has its operands
+# and goes out as ONE launch of size x 64 full-K tiles straight into the flat gradient bucket (K.gemm_grouped_wgrad).  The operands
+# of the waiting layers stay alive until then (320 MB per layer at cfg2; 288 GB of HBM).  FFVC_WGRAD_GROUP=<size> (default 4;
+# 0 / 1 = one launch per layer as before).
+_WGRAD_GROUP = int(os.environ.get("FFVC_WGRAD_GROUP", "4"))
+_PENDING_GROUPS = []
+
+
+class WgradGroup:
+    def __init__(self, members):
+        self.members = list(members)
+        self.pending = {}
+
+    def add(self, idx, dy2d, x2d, rows, bias_done):
+        if idx in self.pending:                  # a second use of the same weight before the group went out: flush what is there
+            self.flush()
+        if not self.pending:
+            _PENDING_GROUPS.append(self)
+            _SIDE["main"] = torch.cuda.current_stream()
+            if not _SIDE["cb"]:                  # a backward pass that ends with a partly filled group flushes it (see _end_of_backward)
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+                    _SIDE["cb"] = True
+                except RuntimeError:
+                    pass                         # not inside a backward pass: join_side_stream() flushes
+        self.pending[idx] = (dy2d, x2d, rows, bias_done)
+        if len(self.pending) == len(self.members):
+            self.flush()
+
+    def flush(self):
+        pend, self.pending = self.pending, {}
+        if not pend:
+            return
+        if self in _PENDING_GROUPS:
+            _PENDING_GROUPS.remove(self)
+        idxs = sorted(pend)
+        Ws = [self.members[i] for i in idxs]
+        wgs = [_grad_buf(W.weight) for W in Ws]
+        rows = pend[idxs[0]][2]
+        stride = (wgs[1].data_ptr() - wgs[0].data_ptr()) // 4 if len(wgs) > 1 else 0
+        regular = (len(idxs) >= 2 and stride > 0 and all(pend[i][2] == rows for i in idxs) and
+                   all(wgs[j].data_ptr() - wgs[0].data_ptr() == 4 * stride * j for j in range(len(wgs))))
+        if not regular:                          # a lone member / irregular layout: the per-layer launches
+            for i in idxs:
+                dy2d, x2d, r, bd = pend[i]
+                _wgrad_now(dy2d, x2d, self.members[i], r, None, bd)
+            return
+        W0 = Ws[0]
+        Nr = W0.weight.shape[0]
+        Kr = W0.weight.numel() // Nr
+        dys, xs = [pend[i][0] for i in idxs], [pend[i][1] for i in idxs]
+        with _on_side(*dys, *xs):
+            K.gemm_grouped_wgrad(dys, xs, wgs[0], stride, Nr, Kr, rows, W0.N, W0.K)
+            for i, W in zip(idxs, Ws):
+                if W.bias is not None and W.bias.requires_grad and not pend[i][3]:
+                    K.colsum(pend[i][0], _grad_buf(W.bias), accumulate=True)
+        for W in reversed(Ws):                   # gradient-ready reports in the order backward produces them
+            if W.on_grad is not None:
+                W.on_grad(W)
+
+
+def group_weights(packs, size=None):
+    """Mark consecutive runs of `size` packs (the same Linear of consecutive layers, registration order) for grouped weight
+    gradients.  Only packs whose gradient takes the 256x256 LDS-DMA kernel qualify (16-bit shadows, N, K multiples of 256,
+    un-padded); others are left alone."""
+    size = _WGRAD_GROUP if size is None else int(size)
+    if size < 2:
+        return
+    size = min(size, 8)
+    ok = [W for W in packs if W.sh.dtype in K.LOWP and W.N % 256 == 0 and W.K % 256 == 0 and W.N >= 1024 and W.K >= 1024 and
+          W.weight.shape[0] == W.N and W.weight.numel() == W.N * W.K]
+    if len(ok) != len(packs):
+        return
+    for s0 in range(0, len(packs), size):
+        run = packs[s0:s0 + size]
+        if len(run) >= 2:
+            g = WgradGroup(run)
+            for i, W in enumerate(run):
+                W.group = (g, i)
+
+
+def flush_wgrad_groups():
+    """Send out every partly filled group (end of a backward pass that did not reach all members of a group)."""
+    for g in list(_PENDING_GROUPS):
+        g.flush()
+
+
 def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
     """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N).
     bias_done: the kernel that produced dy already accumulated its column sums into bias.grad."""
+    if (W.group is not None and _WGRAD_GROUP > 1 and ldy in (None, W.N) and rows >= 512 and rows % 64 == 0 and
+            dy2d.dtype in K.LOWP and dy2d.is_contiguous() and x2d.is_contiguous()):
+        g, idx = W.group
+        g.add(idx, dy2d, x2d, rows, bias_done)
+        return
+    _wgrad_now(dy2d, x2d, W, rows, ldy, bias_done)
+
+
+def _wgrad_now(dy2d, x2d, W, rows, ldy=None, bias_done=False):
     wg = _grad_buf(W.weight)
     bg = _grad_buf(W.bias) if (W.bias is not None and W.bias.requires_grad and not bias_done) else None
     bk = 64 if dy2d.dtype in K.LOWP else 32

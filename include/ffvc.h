@@ -156,6 +156,16 @@ typedef struct ffvc_gemm_desc {
    * gradient) — on the 256x256 tile; y rows are N bytes. */
   float* y8_state;
   int32_t y8_fmt;
+  /* GROUPED launch (0 = off): the weight gradients of grp_n layers of the same kind in ONE launch — batch entry z reads its
+   * operands at x + grp_xoff[z] / w + grp_woff[z] (ELEMENT offsets from the descriptor's base pointers; signed: the layers'
+   * activations are separate allocations) instead of the constant batch strides xbo / wbo, and writes y + z * ybo (the layers'
+   * gradients sit at a constant stride in the flat gradient bucket).  mlp_mixer_pytorch.py:16-23 x depth: a single weight gradient
+   * of the channel MLP has 64 tiles of 256x256 — a quarter of the chip — and needed a 4-way split-K through fp32 slabs + a reduce
+   * pass; four layers together are 256 full-K tiles.  Needs grp_n == batch <= 8, batch_inner == 1, both operands FFVC_OP_TRANS, a
+   * 16-bit dtype, offsets that keep 16-byte alignment; ffvc_gemm fails with FFVC_E_UNSUPPORTED when the shape does not take the
+   * 256x256 LDS-DMA weight-gradient kernel. */
+  int32_t grp_n;
+  int64_t grp_xoff[8], grp_woff[8];
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);

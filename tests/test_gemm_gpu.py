@@ -949,3 +949,32 @@ def test_fp8_updates_are_batched_and_lazy(cuda):
     assert not sa.pending and abs(sa.state[0].item() - 448.0 / (2 * amax * K.FP8_MARGIN)) < 1e-3 * sa.state[0].item()
     ref = (a.float() * 2 * sa.state[0]).clamp(-448, 448).to(torch.float8_e4m3fn)
     assert torch.equal(q.cpu(), ref.view(torch.uint8).cpu())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("G,M,N,rows", [(4, 1024, 1024, 1024), (3, 1024, 2048, 576), (8, 256, 512, 2048)])
+def test_grouped_weight_gradients_in_one_launch(cuda, dt, G, M, N, rows):
+    """include/ffvc.h grp_*: the weight gradients of G layers — separate operand allocations, gradients at a constant stride in
+    one bucket — in ONE launch of full-K 256x256 tiles, accumulated into what the bucket held (round 5; mlp_mixer_pytorch.py:16-23
+    x depth).  Against fp64 math; accumulation order is the only difference."""
+    pad = 192                                                  # the layers' gradients are not back to back in the bucket
+    stride = M * N + pad
+    bucket = _mk((G * stride,), torch.float32, cuda, 7, 0.1)
+    before = bucket.clone()
+    keep = []                                                  # interleaved decoys: the operands are NOT at a constant stride
+    dys, xs = [], []
+    for g in range(G):
+        dys.append(_mk((rows, M), dt, cuda, 10 + g, 0.5))
+        keep.append(torch.empty(1000 * (g + 1) + 8, dtype=dt, device=cuda))
+        xs.append(_mk((rows, N), dt, cuda, 30 + g, 0.5))
+    K.gemm_grouped_wgrad(dys, xs, bucket, stride, M, N, rows, M, N)
+    torch.cuda.synchronize()
+    for g in range(G):
+        ref = before[g * stride:g * stride + M * N].view(M, N).double() + dys[g].double().T @ xs[g].double()
+        got = bucket[g * stride:g * stride + M * N].view(M, N)
+        assert _rel(got, ref) < 2e-5, (g, _rel(got, ref))
+        assert torch.equal(bucket[g * stride + M * N:(g + 1) * stride], before[g * stride + M * N:(g + 1) * stride])   # pads untouched
+    # shapes the 256x256 weight-gradient kernel cannot take fail loudly instead of silently falling back
+    from feed_forward_vqgan_clip_amd import _lib
+    with pytest.raises(_lib.FFVCError):
+        K.gemm_grouped_wgrad([d[:, :200].contiguous() for d in dys[:2]], xs[:2], bucket, stride, 200, N, rows, 200, N)

@@ -626,3 +626,71 @@ def test_split_precision_text_tower_handles_out_of_range_checkpoints():
     assert fb.text_exact                                          # the probe saw non-finite features -> exact path
     ref = fclip.CLIP(hot, torch.float16, text_exact=True).encode_text(tok.cuda()).cpu()
     assert torch.isfinite(ref).all() and _relrms(fb.encode_text(tok.cuda()).cpu(), ref) < 1e-6
+
+
+# ----------------------------------------------------------------------------- grouped weight gradients (round 5)
+def _mixer_grads(group, depth=6, B=32, seed=3, partial=None):
+    """Gradients of a Mixer (dim 1024: the channel MLP's 1024 x 4096 weights qualify for grouping) for loss = sum(z * r)."""
+    from feed_forward_vqgan_clip_amd import mappers as fmap
+    from feed_forward_vqgan_clip_amd import ops
+    old = ops._WGRAD_GROUP
+    ops._WGRAD_GROUP = group
+    try:
+        torch.manual_seed(seed)
+        net = fmap.Mixer(input_dim=64, image_size=4, channels=32, patch_size=1, dim=1024, depth=depth).cuda().prepare(F16)
+        x = torch.randn(B, 64, generator=torch.Generator().manual_seed(seed + 1)).cuda()
+        r = torch.randn(B, 32, 4, 4, generator=torch.Generator().manual_seed(seed + 2)).cuda()
+        net._ffvc_arena.zero_grad()
+        (net(x) * r).sum().backward()
+        torch.cuda.synchronize()
+        grouped = sum(1 for b in net._blocks for W in (b[4], b[5]) if W.group is not None)
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters()}, grouped
+    finally:
+        ops._WGRAD_GROUP = old
+
+
+def test_grouped_weight_gradients_equal_the_per_layer_launches(cuda):
+    """ops.WgradGroup: the channel-MLP weight gradients of 4 consecutive Mixer blocks in one launch (blocks 0-3), the remaining
+    pair in another (4-5), against one launch per layer.  Same products, different fp32 summation order."""
+    g4, n4 = _mixer_grads(4)
+    g0, n0 = _mixer_grads(0)
+    assert n4 == 12 and n0 == 0
+    for k in g0:
+        assert torch.isfinite(g4[k]).all(), k
+        assert _relrms(g4[k], g0[k]) < 2e-5, (k, _relrms(g4[k], g0[k]))
+
+
+def test_partly_filled_weight_gradient_group_is_flushed(cuda):
+    """A group that does not fill (a backward pass that misses some of its layers, or direct calls outside autograd) goes out when
+    the side stream is joined: consecutive members as a smaller grouped launch, a gap in the run as per-layer launches."""
+    from feed_forward_vqgan_clip_amd import mappers as fmap
+    from feed_forward_vqgan_clip_amd import ops
+    torch.manual_seed(0)
+    net = fmap.Mixer(input_dim=64, image_size=4, channels=32, patch_size=1, dim=1024, depth=4).cuda().prepare(F16)
+    Ws = [b[4] for b in net._blocks]                 # fc1 of the four blocks: one group
+    assert Ws[0].group is not None and Ws[0].group[0] is Ws[3].group[0]
+    rows = 512
+    for members in ((0, 1, 2), (0, 1, 3), (2,)):
+        net._ffvc_arena.zero_grad()
+        ops_in = {}
+        for i in members:
+            dy = _mk_like((rows, Ws[i].N), 40 + i)
+            x = _mk_like((rows, Ws[i].K), 50 + i)
+            ops_in[i] = (dy, x)
+            ops._wgrad(dy, x, Ws[i], rows)
+        assert len(ops._PENDING_GROUPS) == 1        # nothing launched yet: the group is not full
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        assert not ops._PENDING_GROUPS
+        for i in range(4):
+            got = Ws[i].weight.grad
+            if i in ops_in:
+                ref = ops_in[i][0].double().T @ ops_in[i][1].double()
+                assert _relrms(got, ref) < 2e-5, (members, i)
+                assert _relrms(Ws[i].bias.grad, ops_in[i][0].double().sum(0)) < 2e-5
+            else:
+                assert float(got.abs().max()) == 0.0
+
+
+def _mk_like(shape, seed):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * 0.5).to(F16).cuda()

@@ -243,3 +243,218 @@ def test_oracle_xtransformer_matches_a_module_built_restatement(mode):
         want = out[:, L - n:].reshape(2, S, S, C).permute(0, 3, 1, 2)
     assert got.shape == want.shape
     assert ((got - want).norm() / want.norm()).item() < 2e-5
+
+
+# ----------------------------------------------------------------------------- kornia 0.5.10 restatement: PIL / colorsys witnesses
+#  oracle/kornia_aug.py is built on torch's grid_sample.  PIL's Image.transform (its own C resampler, its own
+# pixel-centre convention) evaluated with the coefficient map DERIVED BY HAND from kornia's two conventions must sample the same
+# values wherever no padding rule is involved; colorsys is the textbook HSV transform.
+def _pil_warp(img, method, data):
+    """img (3,H,W) float tensor -> PIL bilinear transform of every channel ('F' mode: float32 pixels)."""
+    from PIL import Image
+    H, W = img.shape[-2:]
+    out = [torch.from_numpy(__import__("numpy").array(
+        Image.fromarray(c.numpy().astype("float32"), mode="F").transform((W, H), method, data, resample=Image.BILINEAR))) for c in img]
+    return torch.stack(out)
+
+
+def _interior(src_x, src_y, S, margin=1.5):
+    return (src_x > margin) & (src_x < S - 1 - margin) & (src_y > margin) & (src_y < S - 1 - margin)
+
+
+def test_kornia_warp_affine_convention_matches_pil():
+    """warp_affine(M, align_corners=False) as kornia 0.5.10 runs it: the pixel matrix is normalised with the align_corners=TRUE
+    map (normalize_homography) and sampled with align_corners=FALSE.  By hand: output index i reads source index
+        T2(M^-1(T1(i))),  T1(i) = (i + .5)(W-1)/W,  T2(a) = a W/(W-1) - .5
+    PIL's AFFINE reads source index A (i + .5) + c - .5  ->  A = R, c = t W/(W-1) for M^-1 = [R | t]."""
+    from PIL import Image
+    from oracle import kornia_aug as ka
+    S = 48
+    g = torch.Generator().manual_seed(0)
+    yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float64), torch.arange(S, dtype=torch.float64), indexing="ij")
+    img = torch.stack([torch.sin(xx / 5) * torch.cos(yy / 7), (xx * yy) / S ** 2, torch.rand(S, S, generator=g, dtype=torch.float64)]).float()
+    for angle, ty in ((11.0, 3.2), (-14.0, -4.1), (0.0, 2.5)):
+        M = ka.get_affine_matrix2d(torch.tensor([angle]), torch.tensor([[0.0, ty]]), torch.tensor([[(S - 1) / 2.0, (S - 1) / 2.0]]))
+        want = ka.warp_affine(img[None], M, padding_mode="border")[0]
+        Mi = torch.linalg.inv(M[0])
+        s = S / (S - 1.0)
+        data = (Mi[0, 0].item(), Mi[0, 1].item(), Mi[0, 2].item() * s, Mi[1, 0].item(), Mi[1, 1].item(), Mi[1, 2].item() * s)
+        got = _pil_warp(img, Image.AFFINE, data)
+        sx = data[0] * (xx + .5) + data[1] * (yy + .5) + data[2] - .5
+        sy = data[3] * (xx + .5) + data[4] * (yy + .5) + data[5] - .5
+        m = _interior(sx, sy, S)
+        assert m.float().mean() > 0.4
+        assert (got - want)[:, m].abs().max().item() < 2e-5, (angle, ty)
+        # and the map is NOT the naive "M^-1 in pixel coordinates" one: that version misses by a visible margin
+        naive = _pil_warp(img, Image.AFFINE, (Mi[0, 0].item(), Mi[0, 1].item(), Mi[0, 2].item() + .5 - .5 * (Mi[0, 0] + Mi[0, 1]).item(),
+                                              Mi[1, 0].item(), Mi[1, 1].item(), Mi[1, 2].item() + .5 - .5 * (Mi[1, 0] + Mi[1, 1]).item()))
+        assert (naive - want)[:2, m].abs().max().item() > 1e-3
+
+
+def test_kornia_warp_perspective_convention_matches_pil():
+    """warp_perspective(M, align_corners=False): the destination grid is linspace(-1, 1, W) (align_corners=TRUE style, pixel i at
+    2 i/(W-1) - 1), the sampling align_corners=FALSE: output index i reads source index  T2(M^-1(i)).
+    PIL's PERSPECTIVE reads  P (i + .5) - .5  ->  P = diag(s, s, 1) . M^-1 . translate(-.5),  s = W/(W-1)."""
+    from PIL import Image
+    from oracle import kornia_aug as ka
+    S = 48
+    g = torch.Generator().manual_seed(1)
+    yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float64), torch.arange(S, dtype=torch.float64), indexing="ij")
+    img = torch.stack([torch.sin(xx / 4) + torch.cos(yy / 6), (xx - yy) / S, torch.rand(S, S, generator=g, dtype=torch.float64)]).float()
+    start = torch.tensor([[[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]]], dtype=torch.float64)
+    sign = torch.tensor([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]], dtype=torch.float64)
+    for seed in (2, 3, 4):
+        rv = torch.rand(1, 4, 2, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+        end = start + 0.7 * S / 2 * rv * sign[None]
+        M = ka.get_perspective_transform(start, end)
+        want = ka.warp_perspective(img[None], M)[0]
+        s = S / (S - 1.0)
+        P = torch.diag(torch.tensor([s, s, 1.0], dtype=torch.float64)) @ torch.linalg.inv(M[0]) @ \
+            torch.tensor([[1.0, 0, -.5], [0, 1.0, -.5], [0, 0, 1.0]], dtype=torch.float64)
+        P = P / P[2, 2]
+        data = tuple(P.reshape(-1)[:8].tolist())
+        got = _pil_warp(img, Image.PERSPECTIVE, data)
+        den = data[6] * (xx + .5) + data[7] * (yy + .5) + 1
+        sx = (data[0] * (xx + .5) + data[1] * (yy + .5) + data[2]) / den - .5
+        sy = (data[3] * (xx + .5) + data[4] * (yy + .5) + data[5]) / den - .5
+        m = _interior(sx, sy, S)
+        assert m.float().mean() > 0.2
+        assert (got - want)[:, m].abs().max().item() < 5e-5, seed
+        # a destination pixel whose source lies well outside the image is zero in both (kornia: zeros padding)
+        far = (sx < -1.5) | (sx > S + .5) | (sy < -1.5) | (sy > S + .5)
+        if far.any():
+            assert want[:, far].abs().max().item() == 0.0 and got[:, far].abs().max().item() == 0.0
+
+
+def test_kornia_hsv_round_trip_matches_colorsys():
+    """kornia/color/hsv.py as restated (hue in radians, s = delta / (v + 1e-6)) against the standard library's colorsys on random and
+    on degenerate pixels (greys, primaries, ties between channels)."""
+    import colorsys
+    import math
+    from oracle import kornia_aug as ka
+    g = torch.Generator().manual_seed(0)
+    px = torch.rand(200, 3, generator=g, dtype=torch.float64)
+    special = torch.tensor([[0, 0, 0], [1, 1, 1], [.5, .5, .5], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [0, 1, 1], [1, 0, 1],
+                            [.3, .3, .9], [.9, .3, .3], [.2, .8, .8]], dtype=torch.float64)
+    px = torch.cat([px, special])
+    img = px.t().reshape(1, 3, -1, 1)
+    hsv = ka.rgb_to_hsv(img)
+    for i, (r, gg, b) in enumerate(px.tolist()):
+        h, s, v = colorsys.rgb_to_hsv(r, gg, b)
+        assert abs(hsv[0, 2, i, 0].item() - v) < 1e-12
+        assert abs(hsv[0, 1, i, 0].item() - s) < 2e-6 * max(1.0, s / max(v, 1e-3)) + (1e-4 if v < 1e-2 else 0)      # the eps in the quotient
+        if s > 1e-9:
+            dh = abs(hsv[0, 0, i, 0].item() / (2 * math.pi) - h)
+            assert min(dh, 1 - dh) < 1e-9, (i, r, gg, b)
+    # hsv -> rgb: the piecewise form equals colorsys for hues / saturations / values over the whole cube
+    hs = torch.rand(300, 3, generator=g, dtype=torch.float64)
+    back = ka.hsv_to_rgb(torch.stack([hs[:, 0] * 2 * math.pi, hs[:, 1], hs[:, 2]]).reshape(1, 3, -1, 1))
+    for i, (h, s, v) in enumerate(hs.tolist()):
+        want = colorsys.hsv_to_rgb(h, s, v)
+        assert max(abs(back[0, c, i, 0].item() - want[c]) for c in range(3)) < 1e-12
+    # adjust_hue / adjust_saturation: the composition the ColorJitter applies, against colorsys per pixel
+    shift, fac = torch.tensor([0.07]), torch.tensor([1.08])
+    out_h = ka.adjust_hue(img, shift * 2 * math.pi)
+    out_s = ka.adjust_saturation(img, fac)
+    for i, (r, gg, b) in enumerate(px.tolist()):
+        h, s, v = colorsys.rgb_to_hsv(r, gg, b)
+        if s > 1e-6 and v > 1e-2:
+            want = colorsys.hsv_to_rgb((h + 0.07) % 1.0, s, v)
+            assert max(abs(out_h[0, c, i, 0].item() - want[c]) for c in range(3)) < 5e-6
+            want = colorsys.hsv_to_rgb(h, min(1.0, s * 1.08), v)
+            assert max(abs(out_s[0, c, i, 0].item() - want[c]) for c in range(3)) < 5e-6
+
+
+# ----------------------------------------------------------------------------- net2net prior: a module-built FORWARD flow
+def test_prior_reverse_inverts_a_module_built_forward_flow():
+    """ oracle/prior.py::reverse restates the SAMPLING direction of net2net's ConditionalFlatCouplingFlow
+    (main.py:1447-1462; net2net absent).  Its witness: the published FORWARD direction, built from torch.nn modules the way the
+    package builds it — ActNorm (h = scale * (x + loc)), InvLeakyRelu(0.9) (h = x * [1 | alpha]), the conditional double coupling
+    (x1' = x1 * exp(s(x0, c)) + t(x0, c), halves swapped before the second pair), Shuffle (x[:, forward_idx]) — loaded from the same
+    state_dict.  reverse(forward(x)) must be x, for every flow depth, and forward must actually move x."""
+    from torch import nn
+    from feed_forward_vqgan_clip_amd import prior as fprior
+    from oracle import prior as oprior
+
+    class FC(nn.Module):                                       # BasicFullyConnectedNet
+        def __init__(self, dim, depth, hidden, out, tanh):
+            super().__init__()
+            layers = [nn.Linear(dim, hidden), nn.LeakyReLU()]
+            for _ in range(depth):
+                layers += [nn.Linear(hidden, hidden), nn.LeakyReLU()]
+            layers.append(nn.Linear(hidden, out))
+            if tanh:
+                layers.append(nn.Tanh())
+            self.main = nn.Sequential(*layers)
+
+        def forward(self, x):
+            return self.main(x)
+
+    class Coupling(nn.Module):                                 # ConditionalDoubleVectorCouplingBlock.forward
+        def __init__(self, C, E, hidden, depth):
+            super().__init__()
+            self.s = nn.ModuleList([FC(C // 2 + E, depth, hidden, C // 2, True) for _ in range(2)])
+            self.t = nn.ModuleList([FC(C // 2 + E, depth, hidden, C // 2, False) for _ in range(2)])
+
+        def forward(self, x, xc):
+            for i in range(2):
+                if i % 2 != 0:
+                    x = torch.cat(torch.chunk(x, 2, dim=1)[::-1], dim=1)
+                x0, x1 = torch.chunk(x, 2, dim=1)
+                ci = torch.cat((x0, xc), dim=1)
+                x = torch.cat((x0, x1 * self.s[i](ci).exp() + self.t[i](ci)), dim=1)
+            return x
+
+    class ActNorm(nn.Module):
+        def __init__(self, C):
+            super().__init__()
+            self.loc, self.scale = nn.Parameter(torch.zeros(1, C, 1, 1)), nn.Parameter(torch.ones(1, C, 1, 1))
+            self.register_buffer("initialized", torch.tensor(1, dtype=torch.uint8))
+
+        def forward(self, x):
+            return self.scale.reshape(1, -1) * (x + self.loc.reshape(1, -1))
+
+    class Shuffle(nn.Module):
+        def __init__(self, C):
+            super().__init__()
+            self.register_buffer("forward_shuffle_idx", torch.arange(C))
+            self.register_buffer("backward_shuffle_idx", torch.arange(C))
+
+        def forward(self, x):
+            return x[:, self.forward_shuffle_idx]
+
+    class Block(nn.Module):                                    # ConditionalFlatDoubleCouplingFlowBlock.forward
+        def __init__(self, C, E, hidden, depth):
+            super().__init__()
+            self.norm_layer, self.coupling, self.shuffle = ActNorm(C), Coupling(C, E, hidden, depth), Shuffle(C)
+
+        def forward(self, x, xc):
+            h = self.norm_layer(x)
+            h = h * ((h >= 0).to(h) + (h < 0).to(h) * 0.9)    # InvLeakyRelu(alpha=0.9).forward
+            return self.shuffle(self.coupling(h, xc))
+
+    class Flow(nn.Module):                                     # ConditionalFlatCouplingFlow.forward
+        def __init__(self, C, D, E, hidden, depth, n_flows):
+            super().__init__()
+            self.embedder = FC(D, 2, 256, E, False)
+            self.sub_layers = nn.ModuleList([Block(C, E, hidden, depth) for _ in range(n_flows)])
+
+        def forward(self, x, cond):
+            emb = self.embedder(cond)
+            for blk in self.sub_layers:
+                x = blk(x, emb)
+            return x
+
+    C, D, E, hidden, depth = 32, 24, 16, 48, 2
+    for n_flows in (1, 3):
+        sd = fprior.random_state_dict(C, D, E, hidden, depth, n_flows, seed=5 + n_flows)
+        flow = Flow(C, D, E, hidden, depth, n_flows).double()
+        flow.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, strict=True)
+        g = torch.Generator().manual_seed(n_flows)
+        x = torch.randn(7, C, generator=g, dtype=torch.float64)
+        cond = torch.randn(7, D, generator=g, dtype=torch.float64)
+        with torch.no_grad():
+            z = flow(x, cond)
+            back = oprior.reverse(sd, z.float(), cond.float(), n_flows)        # (the oracle computes in fp32)
+        assert (z - x).abs().max().item() > 0.1                 # the flow does something
+        assert (back.double() - x).abs().max().item() < 5e-5, n_flows
