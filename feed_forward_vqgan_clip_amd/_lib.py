@@ -178,6 +178,9 @@ _SIGNATURES = {
     "ffvc_cutouts_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                  c_float, c_float, c_void_p]),
     "ffvc_augment_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
+    "ffvc_augment_seq_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
+    "ffvc_augment_seq_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                     c_float, c_void_p]),
     "ffvc_avgpool_patches_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_float] * 6 + [c_void_p]),
     "ffvc_avgpool_patches_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int] + [c_float] * 3 + [c_void_p]),
     "ffvc_augment_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_float,

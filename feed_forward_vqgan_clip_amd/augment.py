@@ -309,7 +309,29 @@ def plan(chain, N, S, src_size=None, sequential=True):
     close()
     if not segs or segs[-1][0] != "fused":               # the last launch writes the patch rows (+ noise): an identity resample
         segs.append(("fused", _finish(new_seg(side), N)))
-    return segs
+    return _merge_sequential(segs) if sequential else segs
+
+
+def _merge_sequential(segs):
+    """A launch that is ONLY the border-padded affine (kornia's warp_affine as its own resample) followed by a fused launch
+    without an affine slot of its own, all on one image size, becomes ONE launch in the kernel's sequential form (`seq`: the
+    homography slot interpolates an intermediate image whose integer pixels are the affine interpolation of the source,
+    ffvc_augment_seq_fwd): the same values as the two launches, without the intermediate batch in memory.  The default set
+    Af -> Pe -> Ji -> Er is one launch again, now with kornia's two interpolations."""
+    out = []
+    for kind, prm in segs:
+        prev = out[-1] if out else None
+        if (kind == "fused" and prev is not None and prev[0] == "fused" and prev[1].get("_affine_only") and not prm.get("_has_A") and
+                prev[1]["src"] == prev[1]["out"] == prm["src"] == prm["out"] and not prev[1].get("seq")):
+            merged = dict(prm)
+            merged["ainv"] = prev[1]["ainv"]
+            merged["seq"] = 1
+            merged["_has_A"] = True
+            merged["_affine_only"] = False
+            out[-1] = ("fused", merged)
+        else:
+            out.append((kind, prm))
+    return out
 
 
 def _finish(seg, N):
@@ -323,7 +345,11 @@ def _finish(seg, N):
     eye = torch.eye(3, dtype=_F64).reshape(1, 9).repeat(N, 1)
     out = {"pinv": Hi.reshape(N, 9).float().contiguous(), "ainv": ainv.float().contiguous(), "cmat": eye.float().contiguous(),
            "coff": torch.zeros(N, 3), "erase": seg["erase"].contiguous(), "gn": seg["gn"].float().contiguous(),
-           "src": seg["src"], "out": seg["out"]}
+           "src": seg["src"], "out": seg["out"],
+           # (plan-level bookkeeping for _merge_sequential; not kernel parameters)
+           "_has_A": seg["A"] is not None,
+           "_affine_only": (seg["A"] is not None and seg["n_geo"] == 1 and seg["cj"] is None and not seg["has_erase"] and
+                            not bool(seg["gn"].any()))}
     if seg["cj"] is not None:
         out["cj"] = seg["cj"].float().contiguous()
     return out
@@ -336,7 +362,7 @@ def draw_params(N, S, augs=DEFAULT, generator=None, p=0.7, src_size=None):
     segs = plan(draw_chain(N, S, augs, generator, p, src_size), N, S, src_size, sequential=False)
     if len(segs) != 1:
         raise NotImplementedError(f"augs={list(augs)} needs {len(segs)} launches: use augment.plan() (MakeCutouts does)")
-    prm = dict(segs[0][1])
+    prm = {k: v for k, v in segs[0][1].items() if not k.startswith("_")}
     prm.pop("src")
     prm.pop("out")
     return prm

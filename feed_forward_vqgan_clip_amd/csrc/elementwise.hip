@@ -768,7 +768,64 @@ __device__ __forceinline__ AugSample aug_coords(const float* __restrict__ pinv, 
   return a;
 }
 
-template <typename OT>
+// SEQUENTIAL form (round 5; kornia's nn.Sequential, main.py:199,219: RandomAffine and RandomPerspective are TWO bilinear resamples,
+// the second one reading the first one's output): the value at an output pixel is the homography slot's interpolation (zeros /
+// fade, exactly as above with an identity affine) of the INTERMEDIATE image I, and every one of its (up to) four taps I(p), p an
+// integer pixel, is itself the border-padded affine interpolation of the source: I(p) = bilinear(src, clamp(A^-1 p)).  Evaluated
+// lazily — 16 source taps per output pixel — the intermediate image never exists in memory, and the result is what the two-launch
+// form (one launch per warp) produces up to fp32 summation order.
+struct AugTaps {
+  AugSample s[4];      // source-image samples of the (up to) four intermediate pixels
+  float w[4];          // their weights (homography-slot bilinear weight x fade); 0 = unused
+};
+template <bool SEQ>
+__device__ __forceinline__ void aug_taps(const float* __restrict__ pinv, const float* __restrict__ ainv, int ox, int oy, int S,
+                                         AugTaps& t) {
+  if constexpr (!SEQ) {
+    t.s[0] = aug_coords(pinv, ainv, ox, oy, S);
+    t.w[0] = t.s[0].m;
+    t.s[0].m = 1.0f;
+    t.w[1] = t.w[2] = t.w[3] = 0.0f;
+    t.s[1] = t.s[2] = t.s[3] = t.s[0];
+  } else {
+    const float ident[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    const AugSample q = aug_coords(pinv, ident, ox, oy, S);          // position in the intermediate image (side S as well)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int px = q.x0 + (k & 1), py = q.y0 + (k >> 1);
+      t.w[k] = q.m * ((k & 1) ? q.wx : 1.0f - q.wx) * ((k >> 1) ? q.wy : 1.0f - q.wy);
+      float x0 = ainv[0] * (float)px + ainv[1] * (float)py + ainv[2];
+      float y0 = ainv[3] * (float)px + ainv[4] * (float)py + ainv[5];
+      x0 = fminf(fmaxf(x0, 0.0f), (float)(S - 1));                   // border padding of the affine warp
+      y0 = fminf(fmaxf(y0, 0.0f), (float)(S - 1));
+      AugSample a;
+      a.x0 = min((int)x0, S - 2 < 0 ? 0 : S - 2);
+      a.y0 = min((int)y0, S - 2 < 0 ? 0 : S - 2);
+      a.wx = x0 - (float)a.x0;
+      a.wy = y0 - (float)a.y0;
+      a.m = 1.0f;
+      t.s[k] = a;
+    }
+  }
+}
+// value of the resampled (pre colour) image at one output pixel, all three channels
+template <bool SEQ>
+__device__ __forceinline__ void aug_gather(const float* __restrict__ img3, int Ss, const AugTaps& t, float (&rgb)[3]) {
+  rgb[0] = rgb[1] = rgb[2] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < (SEQ ? 4 : 1); ++k) {
+    if (t.w[k] == 0.0f) continue;
+    const AugSample& a = t.s[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* src = img3 + (int64_t)c * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
+      const float v00 = src[0], v01 = src[1], v10 = src[Ss], v11 = src[Ss + 1];
+      rgb[c] += t.w[k] * ((1.f - a.wy) * ((1.f - a.wx) * v00 + a.wx * v01) + a.wy * ((1.f - a.wx) * v10 + a.wx * v11));
+    }
+  }
+}
+
+template <typename OT, bool SEQ = false>
 __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ pinv,
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                           const int* __restrict__ erase, const float* __restrict__ noise,
@@ -786,16 +843,12 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
     const int oy = (int)(t % S);
     const int n = (int)(t / S);
     const int b = n % B;
-    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, Ss);
+    AugTaps taps;
+    aug_taps<SEQ>(pinv + n * 9, ainv + n * 6, ox, oy, Ss, taps);
     const int* er = erase + n * 4;
     const bool erased = ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3];
     float rgb[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float* src = pooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
-      const float v00 = src[0], v01 = src[1], v10 = src[Ss], v11 = src[Ss + 1];
-      rgb[c] = a.m * ((1.f - a.wy) * ((1.f - a.wx) * v00 + a.wx * v01) + a.wy * ((1.f - a.wx) * v10 + a.wx * v11));
-    }
+    aug_gather<SEQ>(pooled + (int64_t)b * 3 * Ss * Ss, Ss, taps, rgb);
     const float* cm = cmat + n * 9;
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
     float col[3];
@@ -819,7 +872,7 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
 }
 
 // dpooled (pre-zeroed) += scatter of the bilinear taps (fp32 atomics: ~4 per output pixel and channel)
-template <typename GT>
+template <typename GT, bool SEQ = false>
 __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__ gout, const float* __restrict__ pinv,
                                                           const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                           const int* __restrict__ erase, const float* __restrict__ pooled,
@@ -838,8 +891,9 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
     const int b = n % B;
     const int* er = erase + n * 4;
     if (ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3]) continue;
-    const AugSample a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, Ss);
-    if (a.m == 0.0f) continue;
+    AugTaps taps;
+    aug_taps<SEQ>(pinv + n * 9, ainv + n * 6, ox, oy, Ss, taps);
+    if (taps.w[0] == 0.0f && taps.w[1] == 0.0f && taps.w[2] == 0.0f && taps.w[3] == 0.0f) continue;
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
     float g[3];
 #pragma unroll
@@ -848,16 +902,10 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
       g[c] = ElemTraits<GT>::load(gout + (int64_t)n * per_img + prow) * istd[c];
     }
     const float* cm = cmat + n * 9;
-    const float w00 = a.m * (1.f - a.wy) * (1.f - a.wx), w01 = a.m * (1.f - a.wy) * a.wx, w10 = a.m * a.wy * (1.f - a.wx),
-                w11 = a.m * a.wy * a.wx;
     if (cj && cj[n * 8] != 0.0f) {
       // the jitter is not linear: recompute this pixel's forward value up to the jitter's input, then g <- J^T g
       float rgb[3], col[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float* src = pooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
-        rgb[c] = w00 * src[0] + w01 * src[1] + w10 * src[Ss] + w11 * src[Ss + 1];
-      }
+      aug_gather<SEQ>(pooled + (int64_t)b * 3 * Ss * Ss, Ss, taps, rgb);
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[c] = cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
       float J[3][3], o[3];
@@ -869,11 +917,17 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float gc = cm[c] * g[0] + cm[3 + c] * g[1] + cm[6 + c] * g[2];          // transpose of the colour matrix
-      float* dst = dpooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
-      atomicAdd(dst, gc * w00);
-      atomicAdd(dst + 1, gc * w01);
-      atomicAdd(dst + Ss, gc * w10);
-      atomicAdd(dst + Ss + 1, gc * w11);
+#pragma unroll
+      for (int k = 0; k < (SEQ ? 4 : 1); ++k) {
+        if (taps.w[k] == 0.0f) continue;
+        const AugSample& a = taps.s[k];
+        const float gk = gc * taps.w[k];
+        float* dst = dpooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
+        atomicAdd(dst, gk * (1.f - a.wy) * (1.f - a.wx));
+        atomicAdd(dst + 1, gk * (1.f - a.wy) * a.wx);
+        atomicAdd(dst + Ss, gk * a.wy * (1.f - a.wx));
+        atomicAdd(dst + Ss + 1, gk * a.wy * a.wx);
+      }
     }
   }
 }
@@ -884,7 +938,7 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
 // of four per output pixel and channel (~3x fewer L2 atomics; 308 M per step at cfg2 before).  Tiles whose footprint does not
 // fit the LDS image (strong perspective) fall back to direct global atomics.
 constexpr int AUGT = 16, AUG_CAP = 2048;      // tile side; source pixels of the LDS image (x 3 channels x 4 B = 24 KiB)
-template <typename GT>
+template <typename GT, bool SEQ = false>
 __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __restrict__ gout, const float* __restrict__ pinv,
                                                                 const float* __restrict__ ainv, const float* __restrict__ cmat,
                                                                 const int* __restrict__ erase, const float* __restrict__ pooled,
@@ -893,6 +947,7 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
                                                                 float s0, float s1, float s2) {
   __shared__ float img[3 * AUG_CAP];
   __shared__ int bb[4];
+  constexpr int NK = SEQ ? 4 : 1;
   const int n = blockIdx.y, b = n % B;
   const int tiles_x = (S + AUGT - 1) / AUGT;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -907,19 +962,22 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
   for (int i = threadIdx.x; i < 3 * AUG_CAP; i += 256) img[i] = 0.0f;
   __syncthreads();
   bool live = ox < S && oy < S;
-  AugSample a;
-  a.x0 = a.y0 = 0;
-  a.wx = a.wy = a.m = 0.0f;
+  AugTaps taps;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    taps.w[k] = 0.0f;
+    taps.s[k].x0 = taps.s[k].y0 = 0;
+    taps.s[k].wx = taps.s[k].wy = taps.s[k].m = 0.0f;
+  }
   float gc[3] = {0.f, 0.f, 0.f};
   if (live) {
     const int* er = erase + n * 4;
     if (ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3]) live = false;
   }
   if (live) {
-    a = aug_coords(pinv + n * 9, ainv + n * 6, ox, oy, Ss);
-    if (a.m == 0.0f) live = false;
+    aug_taps<SEQ>(pinv + n * 9, ainv + n * 6, ox, oy, Ss, taps);
+    if (taps.w[0] == 0.0f && taps.w[1] == 0.0f && taps.w[2] == 0.0f && taps.w[3] == 0.0f) live = false;
   }
-  float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
   if (live) {
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
     float g[3];
@@ -929,17 +987,9 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
       g[c] = ElemTraits<GT>::load(gout + (int64_t)n * per_img + prow) * istd[c];
     }
     const float* cm = cmat + n * 9;
-    w00 = a.m * (1.f - a.wy) * (1.f - a.wx);
-    w01 = a.m * (1.f - a.wy) * a.wx;
-    w10 = a.m * a.wy * (1.f - a.wx);
-    w11 = a.m * a.wy * a.wx;
     if (cj && cj[n * 8] != 0.0f) {
       float rgb[3], col[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float* src = pooled + ((int64_t)b * 3 + c) * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
-        rgb[c] = w00 * src[0] + w01 * src[1] + w10 * src[Ss] + w11 * src[Ss + 1];
-      }
+      aug_gather<SEQ>(pooled + (int64_t)b * 3 * Ss * Ss, Ss, taps, rgb);
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[c] = cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
       float J[3][3], o[3];
@@ -950,10 +1000,14 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) gc[c] = cm[c] * g[0] + cm[3 + c] * g[1] + cm[6 + c] * g[2];          // transpose of the colour matrix
-    atomicMin(&bb[0], a.x0);
-    atomicMin(&bb[1], a.y0);
-    atomicMax(&bb[2], a.x0 + 1);
-    atomicMax(&bb[3], a.y0 + 1);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      if (taps.w[k] == 0.0f) continue;
+      atomicMin(&bb[0], taps.s[k].x0);
+      atomicMin(&bb[1], taps.s[k].y0);
+      atomicMax(&bb[2], taps.s[k].x0 + 1);
+      atomicMax(&bb[3], taps.s[k].y0 + 1);
+    }
   }
   __syncthreads();
   const int bx0 = bb[0], by0 = bb[1], bw = bb[2] - bb[0] + 1, bh = bb[3] - bb[1] + 1;
@@ -961,14 +1015,21 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
   float* dimg = dpooled + (int64_t)b * 3 * Ss * Ss;
   if (bw * bh <= AUG_CAP) {
     if (live) {
-      const int o = (a.y0 - by0) * bw + (a.x0 - bx0);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float* t = img + c * AUG_CAP + o;
-        atomicAdd(t, gc[c] * w00);
-        atomicAdd(t + 1, gc[c] * w01);
-        atomicAdd(t + bw, gc[c] * w10);
-        atomicAdd(t + bw + 1, gc[c] * w11);
+      for (int k = 0; k < NK; ++k) {
+        if (taps.w[k] == 0.0f) continue;
+        const AugSample& a = taps.s[k];
+        const int o = (a.y0 - by0) * bw + (a.x0 - bx0);
+        const float w00 = taps.w[k] * (1.f - a.wy) * (1.f - a.wx), w01 = taps.w[k] * (1.f - a.wy) * a.wx,
+                    w10 = taps.w[k] * a.wy * (1.f - a.wx), w11 = taps.w[k] * a.wy * a.wx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float* t = img + c * AUG_CAP + o;
+          atomicAdd(t, gc[c] * w00);
+          atomicAdd(t + 1, gc[c] * w01);
+          atomicAdd(t + bw, gc[c] * w10);
+          atomicAdd(t + bw + 1, gc[c] * w11);
+        }
       }
     }
     __syncthreads();
@@ -982,12 +1043,19 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
     }
   } else if (live) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float* dst = dimg + (int64_t)c * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
-      atomicAdd(dst, gc[c] * w00);
-      atomicAdd(dst + 1, gc[c] * w01);
-      atomicAdd(dst + Ss, gc[c] * w10);
-      atomicAdd(dst + Ss + 1, gc[c] * w11);
+    for (int k = 0; k < NK; ++k) {
+      if (taps.w[k] == 0.0f) continue;
+      const AugSample& a = taps.s[k];
+      const float w00 = taps.w[k] * (1.f - a.wy) * (1.f - a.wx), w01 = taps.w[k] * (1.f - a.wy) * a.wx,
+                  w10 = taps.w[k] * a.wy * (1.f - a.wx), w11 = taps.w[k] * a.wy * a.wx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float* dst = dimg + (int64_t)c * Ss * Ss + (int64_t)a.y0 * Ss + a.x0;
+        atomicAdd(dst, gc[c] * w00);
+        atomicAdd(dst + 1, gc[c] * w01);
+        atomicAdd(dst + Ss, gc[c] * w10);
+        atomicAdd(dst + Ss + 1, gc[c] * w11);
+      }
     }
   }
 }
@@ -1464,26 +1532,48 @@ extern "C" int ffvc_slab_reduce(const float* slabs, float* y, int64_t n, int nsl
   return 0;
 }
 
-extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
-                                const float* cj, const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
-                                int S, int S_src, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
-                                float std_g, float std_b, void* stream) {
+static int augment_fwd_impl(bool seq, const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
+                            const float* cj, const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
+                            int S, int S_src, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
+                            float std_g, float std_b, void* stream) {
   FFVC_CHECK_ARG(pooled && pinv && ainv && cmat && erase && out, "ffvc_augment_fwd: null pointer");
   FFVC_CHECK_ARG(B > 0 && S > 1 && S_src > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_fwd: bad geometry");
   FFVC_CHECK_ARG((noise == nullptr) == (facs == nullptr), "ffvc_augment_fwd: noise and facs go together");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)cutn * B * S * S;
-  DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
-                                                pinv, ainv, cmat, erase, noise, facs, coff, cj, (OT*)out, B, S, S_src, cutn, patch, mean_r,
-                                                mean_g, mean_b, std_r, std_g, std_b));
+  if (seq) {
+    DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT, true>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
+                                                  pinv, ainv, cmat, erase, noise, facs, coff, cj, (OT*)out, B, S, S_src, cutn, patch, mean_r,
+                                                  mean_g, mean_b, std_r, std_g, std_b));
+  } else {
+    DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT, false>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
+                                                  pinv, ainv, cmat, erase, noise, facs, coff, cj, (OT*)out, B, S, S_src, cutn, patch, mean_r,
+                                                  mean_g, mean_b, std_r, std_g, std_b));
+  }
   FFVC_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
-                                const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled,
-                                int B, int S, int S_src, int cutn, int patch, float std_r, float std_g, float std_b,
-                                void* stream) {
+extern "C" int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
+                                const float* cj, const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B,
+                                int S, int S_src, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
+                                float std_g, float std_b, void* stream) {
+  return augment_fwd_impl(false, pooled, pinv, ainv, cmat, coff, cj, erase, noise, facs, out, out_dtype, B, S, S_src, cutn, patch, mean_r, mean_g,
+                          mean_b, std_r, std_g, std_b, stream);
+}
+
+extern "C" int ffvc_augment_seq_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff,
+                                    const float* cj, const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype,
+                                    int B, int S, int S_src, int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r,
+                                    float std_g, float std_b, void* stream) {
+  return augment_fwd_impl(true, pooled, pinv, ainv, cmat, coff, cj, erase, noise, facs, out, out_dtype, B, S, S_src, cutn, patch, mean_r, mean_g,
+                          mean_b, std_r, std_g, std_b, stream);
+}
+
+static int augment_bwd_impl(bool seq, const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
+                            const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled,
+                            int B, int S, int S_src, int cutn, int patch, float std_r, float std_g, float std_b,
+                            void* stream) {
   FFVC_CHECK_ARG(gout && pinv && ainv && cmat && erase && dpooled, "ffvc_augment_bwd: null pointer");
   FFVC_CHECK_ARG(cj == nullptr || pooled != nullptr, "ffvc_augment_bwd: the colour jitter's backward needs the forward's source image");
   FFVC_CHECK_ARG(B > 0 && S > 1 && S_src > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_bwd: bad geometry");
@@ -1501,15 +1591,39 @@ extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv
   }
   const int tiles = ((S + AUGT - 1) / AUGT) * ((S + AUGT - 1) / AUGT);
   if (tiled && (int64_t)cutn * B <= 65535) {
-    DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_tiled_kernel<GT>), dim3(tiles, cutn * B), dim3(256), 0, st, (const GT*)gout, pinv,
-                                                ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, patch, std_r, std_g, std_b));
+    if (seq) {
+      DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_tiled_kernel<GT, true>), dim3(tiles, cutn * B), dim3(256), 0, st, (const GT*)gout, pinv,
+                                                  ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, patch, std_r, std_g, std_b));
+    } else {
+      DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_tiled_kernel<GT, false>), dim3(tiles, cutn * B), dim3(256), 0, st, (const GT*)gout, pinv,
+                                                  ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, patch, std_r, std_g, std_b));
+    }
+  } else if (seq) {
+    DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_kernel<GT, true>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
+                                                (const GT*)gout, pinv, ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, cutn, patch, std_r,
+                                                std_g, std_b));
   } else {
-  DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
-                                              (const GT*)gout, pinv, ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, cutn, patch, std_r,
-                                              std_g, std_b));
+    DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_kernel<GT, false>), dim3(ew_grid(n, 256)), dim3(256), 0, st,
+                                                (const GT*)gout, pinv, ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, cutn, patch, std_r,
+                                                std_g, std_b));
   }
   FFVC_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
+                                const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled,
+                                int B, int S, int S_src, int cutn, int patch, float std_r, float std_g, float std_b, void* stream) {
+  return augment_bwd_impl(false, gout, g_dtype, pinv, ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, cutn, patch, std_r, std_g, std_b,
+                          stream);
+}
+
+extern "C" int ffvc_augment_seq_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
+                                    const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled,
+                                    int B, int S, int S_src, int cutn, int patch, float std_r, float std_g, float std_b, void* stream) {
+  FFVC_CHECK_ARG(S == S_src, "ffvc_augment_seq_bwd: the sequential form needs source, intermediate and output images of one size");
+  return augment_bwd_impl(true, gout, g_dtype, pinv, ainv, cmat, erase, pooled, coff, cj, dpooled, B, S, S_src, cutn, patch, std_r, std_g, std_b,
+                          stream);
 }
 
 extern "C" int ffvc_avgpool_patches_fwd(const float* x, void* out, int out_dtype, int N, int S, int So, int patch, float mean_r,

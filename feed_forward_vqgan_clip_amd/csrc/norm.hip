@@ -471,13 +471,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws, int HW,
                                                        int C, int G, int rows_per_chunk) {
   constexpr int EPC = ElemTraits<T>::kPerChunk;  // 8 bf16 / 4 f32 channels per thread-load
+  // round 5: the per-thread partial sums meet in a FIXED order (one LDS slot per thread, then a serial sum per channel in
+  // fp64) instead of through LDS float atomics — the atomics' arrival order changed the fp32 sums in their last bits from
+  // run to run, and a deep 16-bit decoder amplifies any such difference to the size of its rounding noise (run-to-run 7e-4
+  // rel-rms in the decoded image, 4-6e-2 in the gradients behind the max-pool's argmax: tools/r5/grad_spread.py)
   __shared__ float s_sum[1024], s_sq[1024];
+  __shared__ float s_p1[256 * EPC], s_p2[256 * EPC];
   const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
   const int cpr = C / EPC;           // 16-B columns per pixel
   const int rpp = 256 / cpr;         // pixels per pass
   const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
-  for (int i = threadIdx.x; i < C; i += 256) s_sum[i] = s_sq[i] = 0.f;
-  __syncthreads();
   float a1[EPC], a2[EPC];
 #pragma unroll
   for (int j = 0; j < EPC; ++j) a1[j] = a2[j] = 0.f;
@@ -503,9 +506,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
-      atomicAdd(&s_sum[cc * EPC + j], a1[j]);
-      atomicAdd(&s_sq[cc * EPC + j], a2[j]);
+      s_p1[threadIdx.x * EPC + j] = a1[j];
+      s_p2[threadIdx.x * EPC + j] = a2[j];
     }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {       // channel c: its rpp row-threads, in row order
+    const int ccx = c / EPC, j = c - ccx * EPC;
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < rpp; ++r) {
+      t1 += (double)s_p1[(r * cpr + ccx) * EPC + j];
+      t2 += (double)s_p2[(r * cpr + ccx) * EPC + j];
+    }
+    s_sum[c] = (float)t1;
+    s_sq[c] = (float)t2;
   }
   __syncthreads();
   const int cpg = C / G;
@@ -618,12 +632,11 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
                                                            int HW, int C, int G, int swish, int rows_per_chunk, int nslots = 0) {
   constexpr int EPC = ElemTraits<T>::kPerChunk;
   __shared__ float s_1[1024], s_2[1024];
+  __shared__ float s_p1[256 * EPC], s_p2[256 * EPC];      // fixed-order combine of the row-threads (see gn_stats_kernel)
   const int b = blockIdx.y, chunk = blockIdx.x, nch = ACCUM ? nslots : gridDim.x;
   const int cpg = C / G;
   const int cpr = C / EPC, rpp = 256 / cpr;
   const int cc = threadIdx.x % cpr, rr = threadIdx.x / cpr;
-  for (int i = threadIdx.x; i < C; i += 256) s_1[i] = s_2[i] = 0.f;
-  __syncthreads();
   if (rr < rpp) {
     float gm[EPC], bt[EPC], mu[EPC], rs[EPC], a1[EPC], a2[EPC];
 #pragma unroll
@@ -666,9 +679,20 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
     }
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
-      atomicAdd(&s_1[cc * EPC + j], a1[j]);
-      atomicAdd(&s_2[cc * EPC + j], a2[j]);
+      s_p1[threadIdx.x * EPC + j] = a1[j];
+      s_p2[threadIdx.x * EPC + j] = a2[j];
     }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int ccx = c / EPC, j = c - ccx * EPC;
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < rpp; ++r) {
+      t1 += (double)s_p1[(r * cpr + ccx) * EPC + j];
+      t2 += (double)s_p2[(r * cpr + ccx) * EPC + j];
+    }
+    s_1[c] = (float)t1;
+    s_2[c] = (float)t2;
   }
   __syncthreads();
   for (int g = threadIdx.x; g < G; g += 256) {

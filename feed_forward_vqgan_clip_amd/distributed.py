@@ -229,6 +229,7 @@ class DistributedOptimizer:
             tail_bytes = int(os.environ.get("FFVC_DP_TAIL_MIB", "192")) << 20
         self.tail_bytes, self.tail_bucket_bytes, self.tail_wire_dtype = int(tail_bytes), int(tail_bucket_bytes), tail_wire_dtype
         self._tail_tuned = self.tail_bytes <= 0
+        self.tail_slices = set()
         _name = lambda d: str(d or torch.float32).replace("torch.", "")
         _STATE["wire"] = {"slices": _name(wire_dtype), "tail": _name(tail_wire_dtype if tail_wire_dtype is not None else wire_dtype),
                           "tail_MiB": self.tail_bytes >> 20, "tail_slice_MiB": self.tail_bucket_bytes >> 20}
@@ -320,11 +321,13 @@ class DistributedOptimizer:
         if not tail:
             return
         nb, nw = [], []
+        self.tail_slices = set()                               # indices (new list) of the re-cut tail slices
         per = max(64, self.tail_bucket_bytes // 4 // 64 * 64)
         for b, (s, e, idxs) in enumerate(self.buckets):
             if b in tail:
                 cuts = list(range(s, e, per)) + [e]
                 for k in reversed(range(len(cuts) - 1)):       # highest addresses first, like the slices of one large tensor
+                    self.tail_slices.add(len(nb))
                     nb.append((cuts[k], cuts[k + 1], idxs))
                     nw.append(self.tail_wire_dtype if self.tail_wire_dtype is not None else self._wire_of[b])
             else:
@@ -359,6 +362,8 @@ class DistributedOptimizer:
         # autograd's own notification.  The engine also runs the AccumulateGrad node (and this hook) of a parameter whose
         # gradient a fused kernel already wrote (its Function returned None for it): that repeat is not a second use —
         # within ONE backward pass.  A hook that fires after that pass has ended is a second backward() before step().
+        if getattr(p, "_ffvc_deferred", False):
+            return                           # its weight gradient waits in a grouped launch (ops.WgradGroup): flush() reports it
         if getattr(self, "_backward_done", False) and is_distributed():
             self._refuse(p)
         if id(p) not in self._seen:

@@ -1281,28 +1281,31 @@ def set_option(name, value):
 
 
 def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=None, facs=None, coff=None,
-                out_size=None, cj=None):
+                out_size=None, cj=None, seq=False):
     """pooled (B,3,Ss,Ss) fp32 -> patch rows of cutn*B cutouts of side out_size (default Ss).  cj (N,8): kornia ColorJitter
-    parameters per cutout (augment.py), applied after cmat / coff."""
+    parameters per cutout (augment.py), applied after cmat / coff.  seq: the affine slot is its own bilinear resample at the
+    integer pixels of an intermediate image the homography slot then samples (kornia's two sequential warps, ffvc_augment_seq_fwd)."""
     _req_f32(pooled, pinv, ainv, cmat, noise, facs, coff, cj)
     _req(torch.int32, erase)
     B, _, Ss, _ = pooled.shape
     S = out_size or Ss
     g = S // patch
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
-    _call("ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), _ptr(cj),
+    if seq and S != Ss:
+        raise ValueError("augment_fwd(seq=True): source and output side must be equal")
+    _call("ffvc_augment_seq_fwd" if seq else "ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), _ptr(cj),
           erase.data_ptr(), _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, Ss, cutn, patch, mean[0], mean[1],
           mean[2], std[0], std[1], std[2], stream_ptr())
     return out
 
 
-def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=None, pooled=None, coff=None, cj=None):
+def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=None, pooled=None, coff=None, cj=None, seq=False):
     _req_f32(pinv, ainv, cmat, pooled, coff, cj)
     _req(torch.int32, erase)
     _need_cuda(gout)
     Ss = src_size or S
     dpooled = torch.empty(B, 3, Ss, Ss, dtype=torch.float32, device=gout.device)
-    _call("ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
+    _call("ffvc_augment_seq_bwd" if seq else "ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
           erase.data_ptr(), _ptr(pooled), _ptr(coff), _ptr(cj), dpooled.data_ptr(), B, S, Ss, cutn, patch, std[0], std[1], std[2],
           stream_ptr())
     return dpooled

@@ -213,6 +213,12 @@ class WgradGroup:
                 except RuntimeError:
                     pass                         # not inside a backward pass: join_side_stream() flushes
         self.pending[idx] = (dy2d, x2d, rows, bias_done)
+        # autograd still runs the AccumulateGrad hooks of this layer's parameters when its backward returns: a gradient-ready
+        # listener (distributed.DistributedOptimizer) must not take that for "written" — the report comes from flush()
+        W = self.members[idx]
+        W.weight._ffvc_deferred = True
+        if W.bias is not None:
+            W.bias._ffvc_deferred = True
         if len(self.pending) == len(self.members):
             self.flush()
 
@@ -224,6 +230,10 @@ class WgradGroup:
             _PENDING_GROUPS.remove(self)
         idxs = sorted(pend)
         Ws = [self.members[i] for i in idxs]
+        for W in Ws:
+            W.weight._ffvc_deferred = False
+            if W.bias is not None:
+                W.bias._ffvc_deferred = False
         wgs = [_grad_buf(W.weight) for W in Ws]
         rows = pend[idxs[0]][2]
         stride = (wgs[1].data_ptr() - wgs[0].data_ptr()) // 4 if len(wgs) > 1 else 0
@@ -246,6 +256,10 @@ class WgradGroup:
         for W in reversed(Ws):                   # gradient-ready reports in the order backward produces them
             if W.on_grad is not None:
                 W.on_grad(W)
+
+
+def wgrad_group_size():
+    return min(_WGRAD_GROUP, 8) if _WGRAD_GROUP > 1 else 0
 
 
 def group_weights(packs, size=None):
@@ -1074,27 +1088,28 @@ class _AugmentFn(Function):
     """Fused augmentation chain on the pooled image (kernels.augment_fwd / augment_bwd)."""
 
     @staticmethod
-    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None, out_size=None, cj=None):
+    def forward(ctx, pooled, noise, facs, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, coff=None, out_size=None, cj=None,
+                seq=False):
         pooled = _contig(pooled)
         # the colour jitter is not linear: its backward re-evaluates the forward up to the jitter (needs the source image)
         ctx.save_for_backward(pinv, ainv, cmat, erase, pooled if cj is not None else None, coff if cj is not None else None, cj)
-        ctx.cfg = (pooled.shape[0], out_size or pooled.shape[2], pooled.shape[2], cutn, patch, std)
+        ctx.cfg = (pooled.shape[0], out_size or pooled.shape[2], pooled.shape[2], cutn, patch, std, bool(seq))
         return K.augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dtype, noise=noise, facs=facs,
-                             coff=coff, out_size=out_size, cj=cj)
+                             coff=coff, out_size=out_size, cj=cj, seq=bool(seq))
 
     @staticmethod
     def backward(ctx, g):
         pinv, ainv, cmat, erase, pooled, coff, cj = ctx.saved_tensors
-        B, S, Ss, cutn, patch, std = ctx.cfg
+        B, S, Ss, cutn, patch, std, seq = ctx.cfg
         return (K.augment_bwd(_contig(g), pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=Ss, pooled=pooled, coff=coff,
-                              cj=cj),) + (None,) * 14
+                              cj=cj, seq=seq),) + (None,) * 15
 
 
 def augment(pooled, params, cutn, patch, mean, std, out_dtype, noise=None, facs=None, out_size=None):
     """pooled: (B,3,Ss,Ss) fp32 -> ViT patch rows (cutn*B, (S/patch)^2, 3*patch^2), S = out_size or Ss; params from
     augment.draw_params / augment.plan (drawn for that source / output size pair)."""
     return _AugmentFn.apply(pooled, noise, facs, params["pinv"], params["ainv"], params["cmat"], params["erase"], cutn,
-                            patch, mean, std, out_dtype, params.get("coff"), out_size, params.get("cj"))
+                            patch, mean, std, out_dtype, params.get("coff"), out_size, params.get("cj"), bool(params.get("seq", 0)))
 
 
 class _SharpnessFn(Function):

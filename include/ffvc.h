@@ -404,6 +404,18 @@ int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, 
 int ffvc_augment_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
                      const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled, int B, int S,
                      int S_src, int cutn, int patch, float std_r, float std_g, float std_b, void* stream);
+/* The same launch in the SEQUENTIAL form (round 5): kornia's nn.Sequential (main.py:199,219) runs RandomAffine and RandomPerspective
+ * as TWO bilinear resamples, the second reading the first one's output.  Here the value at an output pixel is the homography slot's
+ * interpolation (pinv; zeros / fade as above) of the intermediate image I, whose integer pixels are themselves the border-padded
+ * affine interpolation of the source, I(p) = bilinear(pooled, clamp(A^-1 p)) (ainv) — evaluated lazily (16 source taps per output
+ * pixel), so the intermediate image never exists in memory and the result equals the two-launch form (ffvc_augment_fwd with the
+ * affine alone, then with the rest) up to fp32 summation order.  S == S_src. */
+int ffvc_augment_seq_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff, const float* cj,
+                         const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int S_src,
+                         int cutn, int patch, float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+int ffvc_augment_seq_bwd(const void* gout, int g_dtype, const float* pinv, const float* ainv, const float* cmat,
+                         const int32_t* erase, const float* pooled, const float* coff, const float* cj, float* dpooled, int B, int S,
+                         int S_src, int cutn, int patch, float std_r, float std_g, float std_b, void* stream);
 /* S = side of the cutouts written, S_src = side of the source image `pooled` [B,3,S_src,S_src]: they differ when the chain
  * holds a resize / crop ('R','Re','Cr','Cc' on a pool_size != cut_size or pool=False source, main.py:203-221), which is then
  * part of pinv.  MakeCutouts(interpolate=True) (main.py:226-228): adaptive average pooling of the augmented batch

@@ -138,12 +138,20 @@ def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-8):
         p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None, out_size=None, cj=None):
+def augment_reference(pooled, pinv, ainv, cmat, erase, cutn, facs=None, noise=None, coff=None, out_size=None, cj=None, seq=False):
     """Plain-PyTorch statement of ffvc_augment_fwd (the fused Af -> Pe -> Ji -> Er chain of main.py:164-198 with
     explicit per-cutout parameters): returns (cutn*B, 3, S, S) BEFORE mean/std normalisation.  This pins the HIP kernel to
     its documented single-resample formula; kornia's own sequential form is restated in oracle/kornia_aug.py, and
     tools/augment_deviation.py measures one against the other.  cj (N,8): ColorJitter parameters as augment.plan() lays them
     out ([on, brightness, contrast, saturation, hue, order code]), applied with oracle/kornia_aug.color_jitter."""
+    if seq:
+        # the kernel's sequential form (ffvc_augment_seq_fwd): the affine slot as its own resample (an intermediate image at the
+        # integer pixels), then everything else sampling that image with an identity affine
+        N0 = cutn * pooled.shape[0]
+        eye9 = torch.eye(3, dtype=pinv.dtype).reshape(1, 9).repeat(N0, 1)
+        ident6 = torch.tensor([1.0, 0, 0, 0, 1.0, 0], dtype=ainv.dtype).repeat(N0, 1)
+        inter = augment_reference(pooled, eye9, ainv, eye9.to(cmat.dtype), torch.zeros(N0, 4, dtype=erase.dtype), cutn)
+        return augment_reference(inter, pinv, ident6, cmat, erase, 1, facs, noise, coff, out_size, cj)
     B, _, S, _ = pooled.shape                      # S: side of the source frame; So: side of the cutouts (a resize / crop in
     So = out_size or S                             # the chain is part of pinv)
     N = cutn * B

@@ -111,10 +111,15 @@ def test_wider_augmentation_set_parameters():
     kinds = lambda augs, **kw: [k for k, _ in A.plan(A.draw_chain(8, S, augs, g), 8, S, **kw)]   # noqa: E731
     assert kinds(("Ro", "Af")) == ["fused", "fused"] and kinds(("Ji", "Af")) == ["fused", "fused"]
     # default = kornia's sequential resampling (one warp per launch); the composed single launch is the opt-in
-    assert kinds(A.DEFAULT) == ["fused", "fused"] and kinds(A.DEFAULT, sequential=False) == ["fused"]
+    # default = kornia's sequential resampling: the affine as its own interpolation.  Where the affine launch is followed by a fused
+    # launch on the same image size the two become ONE launch in the kernel's sequential form (`seq`: 16 source taps per pixel)
+    seqs = lambda augs, **kw: [(k, int(p.get("seq", 0))) for k, p in A.plan(A.draw_chain(8, S, augs, g), 8, S, **kw)]   # noqa: E731
+    assert seqs(A.DEFAULT) == [("fused", 1)] and seqs(A.DEFAULT, sequential=False) == [("fused", 0)]
+    assert seqs(("Af", "Ro")) == [("fused", 1)] and seqs(("Ro", "Af")) == [("fused", 0), ("fused", 0)]   # a warp BEHIND the affine merges
     assert kinds(("Sh", "Af", "Et", "Ts", "Er")) == ["fused", "Sh", "fused", "Et", "Ts", "fused"]
     assert kinds(("Af", "Pe", "Sh"), sequential=False) == ["fused", "Sh", "fused"]
-    assert kinds(("Af", "Pe", "Sh")) == ["fused", "fused", "Sh", "fused"]
+    assert seqs(("Af", "Pe", "Sh")) == [("fused", 1), ("Sh", 0), ("fused", 0)]
+    assert seqs(("Af", "Re")) == [("fused", 0), ("fused", 0)]              # a resize changes the image size: two launches
 
 
 def test_fused_plan_matches_the_kornia_restatement_where_they_must_agree():
@@ -134,7 +139,7 @@ def test_fused_plan_matches_the_kornia_restatement_where_they_must_agree():
         for kind, prm in A.plan(chain, N, S, sequential=True):
             assert kind == "fused"
             x = ostep.augment_reference(x, prm["pinv"].double(), prm["ainv"].double(), prm["cmat"].double(), prm["erase"], 1,
-                                        coff=prm["coff"].double(), cj=prm.get("cj"))
+                                        coff=prm["coff"].double(), cj=prm.get("cj"), seq=bool(prm.get("seq", 0)))
         assert (x - want).abs().max() < 2e-5, (augs, (x - want).abs().max())
 
 

@@ -120,7 +120,7 @@ def _cut_oracle(x, mc, prm, facs, noise):
         last = i == len(segs) - 1
         batch = ostep.augment_reference(batch, q["pinv"], q["ainv"], q["cmat"], q["erase"], cutn, facs=facs if last else None,
                                         noise=noise if last else None, coff=q.get("coff"), out_size=size if last else q.get("out"),
-                                        cj=q.get("cj"))
+                                        cj=q.get("cj"), seq=bool(q.get("seq", 0)))
         cutn = 1
     if mc.interpolate:
         batch = F.adaptive_avg_pool2d(batch, mc.interp_size)
@@ -183,11 +183,13 @@ def test_resize_only_cutouts_equal_torch_interpolate(cuda):
     assert _relmax(up(x.cuda()), F.interpolate(x, (64, 64), mode="bilinear")) < 1e-5
 
 
-@pytest.mark.parametrize("augs", [["Sh"], ["Af", "Sh", "Pe"], ["Et"], ["Ts"], ["Af", "Pe", "Ji", "Er", "Sh", "Et", "Ts"], ["Ji2", "Ts", "Er2"]])
+@pytest.mark.parametrize("augs", [["Sh"], ["Af", "Sh", "Pe"], ["Et"], ["Ts"], ["Af", "Pe", "Ji", "Er", "Sh", "Et", "Ts"], ["Ji2", "Ts", "Er2"],
+                                  ["Af", "Pe", "Ji", "Er"], ["Af", "Ro", "Ji2"], ["Af", "Pe"]])
 def test_sharpness_elastic_tps_match_the_kornia_restatement(cuda, augs):
-    """'Sh' / 'Et' / 'Ts' (main.py:169,179,181) run as their own kernels between fused launches.  With one warp per launch
-    (`sequential=True`) the whole chain is, operator by operator, what kornia's nn.Sequential computes: checked against
-    oracle/kornia_aug.apply_chain on the SAME raw draws, forward and gradient."""
+    """'Sh' / 'Et' / 'Ts' (main.py:169,179,181) run as their own kernels between fused launches.  With one resample per warp
+    (`sequential=True`, the default) the whole chain is, operator by operator, what kornia's nn.Sequential computes: checked against
+    oracle/kornia_aug.apply_chain on the SAME raw draws, forward and gradient.  The last three lists are the ones whose two warps
+    run as ONE launch in the kernel's sequential form (ffvc_augment_seq_fwd / _bwd: the default set among them)."""
     from feed_forward_vqgan_clip_amd import augment as A
     from oracle import kornia_aug as ka
     B, cut, cutn = 2, 32, 3
@@ -198,6 +200,8 @@ def test_sharpness_elastic_tps_match_the_kornia_restatement(cuda, augs):
     x = torch.rand(B, 3, 64, 64, generator=g)
     chain = A.draw_chain(n, cut, tuple(augs), g, p=0.8)
     segs = A.plan(chain, n, cut, cut, sequential=True)
+    if augs[0] == "Af" and augs[1] in ("Pe", "Ro"):
+        assert segs[0][1].get("seq") == 1
     xo = x.double().requires_grad_(True)
     import torch.nn.functional as F
     pooled = (F.adaptive_avg_pool2d(xo, cut) + F.adaptive_max_pool2d(xo, cut)) / 2
@@ -221,3 +225,44 @@ def test_every_reference_augmentation_name_is_built(cuda):
         assert tuple(out.shape) == (4, 3, 32, 32) and torch.isfinite(out).all()
     with pytest.raises(NotImplementedError):
         fmain.MakeCutouts(32, 2, augs=["Xx"])
+
+
+def test_sequential_form_in_one_launch_equals_the_two_launches(cuda):
+    """ffvc_augment_seq_fwd / _bwd (round 5): the affine as its own interpolation, evaluated lazily inside the launch that does the
+    rest, against the same two resamples as two launches (affine alone -> fp32 image batch -> everything else).  Same values up to
+    fp32 summation order, forward and gradient, with the colour jitter (non-linear: the backward re-evaluates the forward), an
+    erase rectangle, noise and the patch layout."""
+    from feed_forward_vqgan_clip_amd import augment as A
+    from feed_forward_vqgan_clip_amd import ops
+    B, S, cutn, P = 3, 64, 4, 16
+    n = B * cutn
+    g = torch.Generator().manual_seed(5)
+    chain = A.draw_chain(n, S, A.DEFAULT, g, p=0.9)
+    one = A.plan(chain, n, S, S, sequential=True)
+    assert len(one) == 1 and one[0][1]["seq"] == 1
+    # the un-merged plan: the same planner with the merge step switched off
+    import feed_forward_vqgan_clip_amd.augment as Amod
+    keep, Amod._merge_sequential = Amod._merge_sequential, (lambda segs: segs)
+    try:
+        two = A.plan(chain, n, S, S, sequential=True)
+    finally:
+        Amod._merge_sequential = keep
+    assert len(two) == 2
+    pooled = torch.rand(B, 3, S, S, generator=g)
+    facs, noise = torch.rand(n, generator=g) * 0.1, torch.randn(n, 3, S, S, generator=g)
+    gw = torch.randn(n, (S // P) ** 2, 3 * P * P, generator=g).cuda()
+    mean, std = (0.48, 0.45, 0.40), (0.26, 0.26, 0.27)
+    res = []
+    for segs in (one, two):
+        x = pooled.cuda().requires_grad_(True)
+        cur, c = x, cutn
+        for i, (_, prm) in enumerate(A.to_device(segs, "cuda")):
+            if i == len(segs) - 1:
+                out = ops.augment(cur, prm, c, P, mean, std, torch.float32, noise=noise.cuda(), facs=facs.cuda(), out_size=S)
+            else:
+                cur = ops.augment(cur, prm, c, S, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), torch.float32, out_size=S).view(n, 3, S, S)
+                c = 1
+        (out * gw).sum().backward()
+        res.append((out.detach(), x.grad.detach()))
+    assert _relmax(res[0][0], res[1][0]) < 1e-5
+    assert _relmax(res[0][1], res[1][1]) < 1e-4

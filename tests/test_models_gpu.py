@@ -629,7 +629,7 @@ def test_split_precision_text_tower_handles_out_of_range_checkpoints():
 
 
 # ----------------------------------------------------------------------------- grouped weight gradients (round 5)
-def _mixer_grads(group, depth=6, B=32, seed=3, partial=None):
+def _mixer_grads(group, depth=10, B=32, seed=3, partial=None):
     """Gradients of a Mixer (dim 1024: the channel MLP's 1024 x 4096 weights qualify for grouping) for loss = sum(z * r)."""
     from feed_forward_vqgan_clip_amd import mappers as fmap
     from feed_forward_vqgan_clip_amd import ops
@@ -650,8 +650,9 @@ def _mixer_grads(group, depth=6, B=32, seed=3, partial=None):
 
 
 def test_grouped_weight_gradients_equal_the_per_layer_launches(cuda):
-    """ops.WgradGroup: the channel-MLP weight gradients of 4 consecutive Mixer blocks in one launch (blocks 0-3), the remaining
-    pair in another (4-5), against one launch per layer.  Same products, different fp32 summation order."""
+    """ops.WgradGroup: the channel-MLP weight gradients of 4 consecutive Mixer blocks in one launch (blocks 4-7; the first four stay
+    on per-layer launches, mappers.Mixer._build_packs), the remaining pair in another (8-9), against one launch per layer.  Same
+    products, different fp32 summation order."""
     g4, n4 = _mixer_grads(4)
     g0, n0 = _mixer_grads(0)
     assert n4 == 12 and n0 == 0

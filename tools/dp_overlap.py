@@ -91,10 +91,10 @@ def main():
                "MiB_done_before_last_2pct_of_backward": early, "frac_bytes_early": early / (total / 2**20), "late": late,
                "first_parameter": first, "dp": hvd.describe()}
     print(json.dumps(summary))
-    # the tail of the launch order = what DistributedOptimizer itself re-cut onto the bf16 wire after the first step (the last
+    # the tail of the launch order = what DistributedOptimizer itself re-cut into 16 MiB pieces after the first step (the last
     # ~192 MiB of gradients the pass produces: proj.weight's slices, the first block's bucket) plus the tiny slice in front of them
     order = sorted(range(len(opt.buckets)), key=lambda b: -rows[b][2] if rows[b][2] == rows[b][2] else 1e9)   # earliest finished first
-    tail = {b for b in range(len(opt.buckets)) if opt._wire_of[b] is not None} | set(order[-2:])
+    tail = set(opt.tail_slices) | set(order[-2:])
     bad = [r for r in rows if not r[3]] + [r for r in rows if not (r[2] == r[2] and r[2] > 0.02 * bwd_ms) and r[0] not in tail]
     if bad:
         print("FAIL: slices outside the tail of the launch order that were late / not enqueued inside backward:", bad)
