@@ -286,16 +286,23 @@ def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_pat
     from feed_forward_vqgan_clip_amd import kernels as K
     from feed_forward_vqgan_clip_amd import ops
     ops.set_wgrad_side_stream(False)
-    K.PROFILE, K.HBM_PROFILE, K.REPLAY = [], [], []
+    stepper(tok)                                  # (untimed: the serialised order allocates differently, let the allocator settle)
+    K.PROFILE, K.HBM_PROFILE = [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     ev0.record()
     stepper(tok)
     ev1.record()
     torch.cuda.synchronize()
+    prof_b, hbm_b = K.PROFILE, K.HBM_PROFILE
+    K.PROFILE = K.HBM_PROFILE = None
+    # a third pass only CAPTURES the launches (kernels.REPLAY keeps every operand of the step alive, which sends the allocator to
+    # hipMalloc: that pass is not timed)
+    K.REPLAY = []
+    stepper(tok)
+    torch.cuda.synchronize()
+    rep, K.REPLAY = K.REPLAY, None
     ops.set_wgrad_side_stream(True)
-    prof_b, hbm_b, rep = K.PROFILE, K.HBM_PROFILE, K.REPLAY
-    K.PROFILE = K.HBM_PROFILE = K.REPLAY = None
     wall_b = ev0.elapsed_time(ev1)
     gemm_b = [e0.elapsed_time(e1) for _, _, e0, e1, _ in prof_b]
     hbm_b_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in hbm_b)

@@ -311,9 +311,14 @@ def _tiny_step(cdt, seed=11):
 # itself (a code flips when the two nearest codes are closer than the mapper's rounding error), so the end-to-end
 # comparison is made twice: free-running (codes may differ: loose bound, agreement rate asserted) and with the
 # reference's codes handed to the decoder (`force_idx`), where the north-star tolerance on the loss applies.
-# (bf16 `grad`: the worst tensor — a bias gradient of the tiny model — measures 0.11-0.13 run to run, the spread being the order of the fp32 atomics
-# that combine it under bf16 rounding; one full-suite run in twelve crossed the former 0.15)
-LOWP_TOL = {BF16: dict(z=3e-2, agree=0.97, xr=3e-2, loss_same_codes=2e-3, loss_free=2e-2, grad=2.5e-1),
+# (bf16 `grad`: rounds 2-4 saw the worst tensor — a bias gradient of the tiny model — move between 0.11 and 0.15+ from run to run and
+# round 4 widened the bound to 0.25.  Root cause, round 5 (tools/r5/grad_spread.py, profiles/r05_grad_spread.txt): NOT a gradient
+# reduction — the decoded image itself differed between runs (3.7e-3 rel-rms in bf16) because the GroupNorm statistics kernels combined
+# their row-threads through LDS float atomics (arrival order -> last bits of the fp32 sums -> 1-ulp flips that a deep 16-bit decoder
+# amplifies to its rounding-noise level), and the (avg + max) pooling's argmax routed the gradient differently for near-ties: 6e-2
+# run-to-run in d(xr), 4e-2 in every mapper gradient.  With the fixed-order combine (csrc/norm.hip) image, embedding, d(xr) and d(z)
+# are bit-identical between runs and the worst gradient measures 0.1181 every time: the bound is back at 0.15.)
+LOWP_TOL = {BF16: dict(z=3e-2, agree=0.97, xr=3e-2, loss_same_codes=2e-3, loss_free=2e-2, grad=1.5e-1),
             F16: dict(z=4e-3, agree=0.99, xr=4e-3, loss_same_codes=1e-4, loss_free=5e-3, grad=8e-2)}   # worst: bias gradients of the tiny model
 
 
