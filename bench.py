@@ -434,6 +434,7 @@ def main():
     ap.add_argument("--no-oracle-bench-batch", action="store_true", help="skip the CPU oracle forward at the benchmark's batch in the parity leg")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second timing in the other 16-bit format")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-batch-invariant", action="store_true", help="skip the FFVC_SK_FIXUP=0 timing (a child process)")
     ap.add_argument("--no-attainable", action="store_true", help="skip the isolated-replay leg (roofline.attainable_ms)")
     ap.add_argument("--isolated-table", default=None, help="write the kernel | launches | isolated us | in-step us | lost ms table here")
     ap.add_argument("--gemm-shapes", type=int, default=0, help="print the N most expensive GEMM shapes (stderr)")
@@ -661,6 +662,23 @@ def main():
         out["cpu_baseline"], ref = cpu_baseline(sds, args.cutn, augs=args.augs)
         out["parity_full_size"] = full_size_parity(args, sds, ref)
         out["parity_full_size"]["loss_oracle_fp32_cpu_baseline_step"] = ref["loss"]      # first (batch-4) step of the CPU baseline
+    if rank == 0 and world == 1 and not args.no_batch_invariant and not args.no_cpu_baseline:
+        # what the `batch_invariant` mode costs: the same step with FFVC_SK_FIXUP=0 (no shape-dependent in-kernel
+        # split-K: every mapper output element is summed in an order fixed by (N, K) alone).  The switch is read once per process
+        # -> a child process; this one is idle meanwhile.
+        import subprocess
+        stepper = None
+        torch.cuda.empty_cache()
+        env = dict(os.environ, FFVC_SK_FIXUP="0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-alt-dtype", "--no-roofline",
+               "--batch", str(args.batch), "--dtype", args.dtype, "--cutn", str(args.cutn), "--dim", str(args.dim), "--depth", str(args.depth)]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["batch_invariant"] = {"ms_per_step": child["ms_per_step"], "value": child["value"], "steps": 6,
+                                      "note": "same step with FFVC_SK_FIXUP=0 (config batch_invariant): bit-identical latents whatever the batch size"}
+        except Exception as e:        # noqa: BLE001 — a diagnostic leg must not cost the line
+            out["batch_invariant"] = {"error": repr(e)[:200]}
     if rank == 0:
         # libraries that write to C stdio (RCCL's NCCL_DEBUG=VERSION banner) flush at exit, i.e. AFTER Python's own buffer:
         # push their text out first so that the JSON line is the last line of stdout

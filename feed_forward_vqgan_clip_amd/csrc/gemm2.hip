@@ -587,7 +587,8 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
   const int env_bm = opt_value(g_opt_gemm2_tile, "FFVC_GEMM2_BM", 1);
   if (env_bm == 0) return 0;
-  int cfg = (env_bm == 128 || env_bm == 256 || env_bm == 512) ? env_bm : 0;
+  int cfg = (env_bm == 64 || env_bm == 128 || env_bm == 256 || env_bm == 512) ? env_bm : 0;
+  if (cfg == 64 && !(d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR)) cfg = 128;     // the 64x128 tile exists K-major x K-major only
   if (!cfg) {
     // Every variant occupies a CU with 8 waves; what differs is FLOP per L2 byte (64 / 85 / 128) and grid granularity.
     // Pick the largest tile whose grid still fills whole rounds of workgroup slots (profiles/r01_gemm_tile_ab.txt).
@@ -618,6 +619,15 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       if (d.N > 128 && (t512 >= 70 || (t512 >= 24 && longk))) cfg = 512;
       else if (t256 >= 192) cfg = 256;
       else cfg = 128;
+      // small-M linears (VitGAN / x-transformer mappers at 16-32 samples per GPU: 512 rows x 1024..4096 columns): 128x128 tiles
+      // leave half of the chip idle or need a deeper in-kernel split; 64-row tiles double the grid (two workgroups per CU).
+      // FFVC_SMALLM=0: off (A/B)
+      static int smallm = -1;
+      if (smallm < 0) {
+        const char* e = getenv("FFVC_SMALLM");
+        smallm = e ? atoi(e) : 1;
+      }
+      if (smallm && cfg == 128 && d.M > 64 && d.M <= 2048 && t128 <= 160 && d.batch == 1 && (d.split_k <= 1) && d.slab_stride == 0) cfg = 64;
     }
     // short reductions are epilogue-dominated: keep two (smaller) workgroups per CU so one's epilogue overlaps the
     // other's K loop (threshold via FFVC_SHORTK for A/B runs)

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   // in-kernel split-K (see the combine in front of the epilogue): uniform mode = blockIdx.z is the K slice of every tile;
   // tail mode (p.sk_slices > 1, 1-D grid) = work items below p.sk_full are whole tiles, the rest are K slices of the tiles of
   // the last, partly filled round
-  constexpr bool SKFIX = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256))) ||
+  constexpr bool SKFIX = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM <= 128 && BN == 128) || (BM == 256 && BN == 256))) ||
                          (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS && BM == 256 && BN == 256);        // + weight gradients
   int wl = blockIdx.x, sk_slice = blockIdx.z, sk_n = gridDim.z;
   if constexpr (SKFIX) {
@@ -1326,7 +1326,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
   const int n_tiles = tiles_m * tiles_n;
   int split = d.split_k < 1 ? 1 : d.split_k;
   const int ksteps = ceil_div(d.K, BK);
-  if constexpr (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM == 128 && BN == 128) {
+  if constexpr (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && BM <= 128 && BN == 128) {
     // Under-filled grid with a long reduction (VitGAN / x-transformer linears at a per-GPU batch of 16-32 samples: 512 rows):
     // 32 workgroups walking K = 4096 leave 7/8 of the chip idle (52 TFLOP/s).  Split K inside the launch; FFVC_SK_FIXUP=0 off.
     static int fix_opt = -1;
@@ -1335,7 +1335,8 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
       fix_opt = e ? atoi(e) : 1;
     }
     const int64_t wgs = (int64_t)n_tiles * d.batch;
-    if (fix_opt && split == 1 && d.slab_stride == 0 && wgs <= 64 && ksteps >= 16 && dma_operand_ok<XMODE>(d, true) &&
+    // (64x128 tiles, round 5: two workgroups fit a CU and a tile is half the work -> split up to 128 tiles)
+    if (fix_opt && split == 1 && d.slab_stride == 0 && wgs <= (BM == 64 ? 128 : 64) && ksteps >= 16 && dma_operand_ok<XMODE>(d, true) &&
         dma_operand_ok<WMODE>(d, false)) {
       int want = (int)((fix_opt > 1 ? fix_opt : 256) / wgs);     // ~one workgroup per CU
       if (want > ksteps / 4) want = ksteps / 4;                   // at least 4 K steps (256 deep) per slice
@@ -1382,7 +1383,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
   }
   if (d.flags & FFVC_F_SPLITK_INKERNEL) {
     // the caller's explicit form: d.split_k K slices per tile, combined inside the launch (weight gradients: 64 tiles x 4)
-    constexpr bool CAP = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM == 128 && BN == 128) || (BM == 256 && BN == 256))) ||
+    constexpr bool CAP = (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR && ((BM <= 128 && BN == 128) || (BM == 256 && BN == 256))) ||
                          (XMODE == FFVC_OP_TRANS && WMODE == FFVC_OP_TRANS && BM == 256 && BN == 256);
     constexpr int SMAXH = (BM == 256) ? 8 : 16;
     if (split > 1) {
@@ -1636,9 +1637,13 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
   return 1;
 }
 
-// cfg: 128 -> 128x128, 256 -> 256x128, 512 -> 256x256
+// cfg: 128 -> 128x128, 256 -> 256x128, 512 -> 256x256, 64 -> 64x128 (K-major x K-major only: the small-M linears of the
+// VitGAN / x-transformer mappers, a few hundred rows against 2-8 MB of weights)
 template <typename L, int XMODE, int WMODE>
 int launch2_cfg_t(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg) {
+  if constexpr (FFVC_MFMA16 && XMODE == FFVC_OP_KMAJOR && WMODE == FFVC_OP_KMAJOR) {
+    if (cfg == 64) return launch2<L, XMODE, WMODE, 64, 128>(d, st, vec_ok, zero);
+  }
   if (cfg == 512) return launch2<L, XMODE, WMODE, 256, 256>(d, st, vec_ok, zero);
   if (cfg == 256) return launch2<L, XMODE, WMODE, 256, 128>(d, st, vec_ok, zero);
   return launch2<L, XMODE, WMODE, 128, 128>(d, st, vec_ok, zero);
