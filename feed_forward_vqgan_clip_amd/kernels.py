@@ -230,6 +230,19 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args), name)
 
 
+# the `f8_only` outputs of the normalisation kernels are buffers the kernel does NOT write (their one consumer takes the
+# fp8 bytes).  FFVC_DEBUG_F8_NAN=1 fills them with NaN, so that anything that does read one — a view or clone that lost the
+# `_ffvc_f8` attribute, an autograd accumulation — poisons the loss visibly instead of consuming uninitialised memory
+# (tests/test_models_gpu.py runs the fp8 models under it).
+DEBUG_F8_NAN = os.environ.get("FFVC_DEBUG_F8_NAN", "0") != "0"
+
+
+def _unwritten(t, only):
+    if only and DEBUG_F8_NAN:
+        t.fill_(float("nan"))
+    return t
+
+
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, f8=None, f8_only=False):
     """x: (..., dim) fp32|bf16 contiguous -> (y[out_dtype], mean, rstd).
     f8 (an initialised Fp8Scale, 16-bit out_dtype, dim % 4 == 0): -> (y, mean, rstd, y8) with y8 = the fp8 bytes fp8_quant(y, f8) would
@@ -250,7 +263,7 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, f8=None, f8_only=False):
             _call("ffvc_layernorm_fwd_f8", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(),
                   0 if f8_only else y.data_ptr(), dtype_code(out_dtype), y8.data_ptr(), f8.state.data_ptr(), f8.fmt, mean.data_ptr(),
                   rstd.data_ptr(), rows, dim, eps, stream_ptr())
-        return y, mean, rstd, y8
+        return _unwritten(y, f8_only), mean, rstd, y8
     with _hbm("layernorm_fwd", x.numel() * (x.element_size() + y.element_size())):
         _call("ffvc_layernorm_fwd", x.data_ptr(), dtype_code(x.dtype), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
               dtype_code(out_dtype), mean.data_ptr(), rstd.data_ptr(), rows, dim, eps, stream_ptr())
@@ -568,7 +581,7 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None, f8=None
             _call("ffvc_groupnorm_fwd_f8", x.data_ptr(), 0 if f8_only else y.data_ptr(), y8.data_ptr(), f8.state.data_ptr(), f8.fmt,
                   gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(ws), _ptr(sums), B, HW, C, G, eps, int(swish),
                   dtype_code(x.dtype), stream_ptr())
-        return y, mean, rstd, y8
+        return _unwritten(y, f8_only), mean, rstd, y8
     if sums is not None:
         if sums.dtype != torch.float64 or tuple(sums.shape) != (B, G, 2):
             raise TypeError("groupnorm_fwd: sums must be fp64 [B, G, 2]")
@@ -602,7 +615,7 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True, f
             _call("ffvc_groupnorm_bwd_f8", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                   _ptr(dres), 0 if f8_only else dx.data_ptr(), dx8.data_ptr(), f8.state.data_ptr(), f8.fmt, ws.data_ptr(), B, HW, C, G,
                   int(swish), dtype_code(x.dtype), stream_ptr())
-        return dx, dx8
+        return _unwritten(dx, f8_only), dx8
     # algorithmic bytes of the two-pass backward: statistics (dy, x) + apply (dy, x, dres, dx)
     with _hbm("groupnorm_bwd", x.numel() * x.element_size() * (5 + (1 if dres is not None else 0))):
         _call("ffvc_groupnorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),

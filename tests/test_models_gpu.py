@@ -190,6 +190,19 @@ def test_fp8_producer_side_quantisation_changes_nothing(cuda, what, monkeypatch)
     # decoder: two runs of the SAME path already differ by ~10 % rms (measured, tools/f8_debug.py): the GroupNorm-backward partial sums
     # meet in LDS atomics, and a 1-ulp change that flips an e5m2 rounding (2 mantissa bits) moves that element by 25 %, which the next
     # layer's quantiser amplifies again — the spread IS the e5m2 quantisation noise, so the bound is that noise level plus direction.
+    # with the producer-side quantisation on, some 16-bit tensors are NOT written (`f8_only`).  Fill those buffers with
+    # NaN (kernels.DEBUG_F8_NAN) and run again: a finite output and gradient prove that nothing reads them
+    monkeypatch.setattr(ops, "_F8_PRODUCER", True)
+    monkeypatch.setattr(K, "DEBUG_F8_NAN", True)
+    model = make()
+    for x, gw in zip(inputs, gws):
+        xi = x.clone().requires_grad_(True)
+        K.fp8_flush_updates()
+        y = run(model, xi)
+        (y.float() * gw).sum().backward()
+        assert torch.isfinite(y).all() and torch.isfinite(xi.grad).all(), "an unwritten (fp8-only) buffer was read"
+    del model
+    monkeypatch.setattr(K, "DEBUG_F8_NAN", False)
     for it, ((ya, ga), (yb, gb)) in enumerate(zip(results[False], results[True])):
         assert torch.isfinite(yb).all() and torch.isfinite(gb).all()
         ey, eg = _relrms(yb, ya), _relrms(gb, ga)
