@@ -406,7 +406,7 @@ def test_train_step_default_augs_matches_oracle(cuda, cdt):
     er["on"][:] = True
     er["xs"][:], er["ys"][:], er["widths"][:], er["heights"][:] = 3, 4, 12, 16
     segs = A.plan(chain, 16, 32, sequential=True)
-    assert [k for k, _ in segs] == ["fused", "fused"]         # Af | Pe + Ji + Er
+    assert [k for k, _ in segs] == ["fused"] and segs[0][1]["seq"] == 1     # Af, then Pe + Ji + Er: two interpolations, one launch
     msd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     loss, mid = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), aug_params=A.to_device(segs, "cuda"))
     opt.zero_grad()
