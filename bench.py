@@ -592,7 +592,7 @@ def main():
         try:
             import hashlib
             from feed_forward_vqgan_clip_amd import _lib as flib
-            pmc_name = next((n for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_pmc_traffic.json")
+            pmc_name = next((n for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_pmc_traffic.json")
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             cls = name.rsplit("_", 1)[0]
             if cls in pmc:

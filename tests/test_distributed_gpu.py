@@ -64,7 +64,7 @@ def _inputs():
     return tok, facs, noise
 
 
-def _run(rank, world, steps=2, big=False):
+def _run(rank, world, steps=2, big=False, shard_of=None):
     """-> flat parameter vector after `steps` optimizer steps on this rank's shard.  big: a Mixer wide and deep enough for the
     grouped weight gradients (dim 1024, 10 blocks, 16 x 16 tokens: blocks 4-7 and 8-9 go out as grouped launches)."""
     from feed_forward_vqgan_clip_amd import clip as fclip
@@ -75,6 +75,8 @@ def _run(rank, world, steps=2, big=False):
     cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=1024 if big else 64, depth=10 if big else 2, dropout=0, cutn=CUTN,
                        batch_size=B // world, repeat=1, nb_noise=None, diversity_coef=0, clip_model="ViT-B/32", clip_dim=32, clip_size=32,
                        model_type="mlp_mixer", vq_image_size=16 if big else 12, augs=["R"])
+    if shard_of is not None:                          # single process standing in for rank `shard_of[0]` of `shard_of[1]`: no exchange
+        cfg.batch_size = B // shard_of[1]
     torch.manual_seed(5 + rank)                       # replicas start DIFFERENT: the broadcast has to repair them
     cdt = torch.float16 if big else torch.float32             # (the grouped launch is a 16-bit kernel)
     net = fmain.build_model(cfg, 64).cuda().prepare(cdt)
@@ -93,6 +95,8 @@ def _run(rank, world, steps=2, big=False):
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
     tok, facs, noise = _inputs()
     shard = slice(rank * (B // world), (rank + 1) * (B // world))
+    if shard_of is not None:
+        shard = slice(shard_of[0] * (B // shard_of[1]), (shard_of[0] + 1) * (B // shard_of[1]))
     args = dict(facs=facs[:, shard].reshape(-1).cuda(), noise=noise[:, shard].reshape(-1, 3, 32, 32).cuda())
     # step 1 by hand, to look at the exchanged gradient (the bucket holds the SUM over ranks; 1/N lives in Adam)
     loss, _ = stepper.forward_loss(tok[shard].cuda(), **args)
@@ -186,14 +190,14 @@ def test_dp_world2_with_grouped_weight_gradients(cuda):
         res = _two_ranks_once(400.0, big=True)
     assert (res[0][1] == res[1][1]).all(), "replicas diverged"
     assert (res[0][3] == res[1][3]).all(), "exchanged gradients differ between ranks"
-    torch.manual_seed(0)
-    ref, ref_loss, ref_grads = _run(0, 1, big=True)
-    g, rg = torch.from_numpy(res[0][3]).double(), torch.from_numpy(ref_grads).double()
+    # Reference without an exchange: ONE process runs the two shards one after the other from rank 0's weights (the same shapes,
+    # hence the same kernels and roundings as the ranks) and averages.  (Against the full batch of 4 in one pass the f16 step differs
+    # by ~20 % rms: other split-K shapes -> other roundings -> other VQ codes; that comparison is made in fp32 by the test above.)
+    shards = [_run(0, 1, steps=1, big=True, shard_of=(r, 2)) for r in range(2)]
+    rg = (torch.from_numpy(shards[0][2]).double() + torch.from_numpy(shards[1][2]).double()) / 2
+    g = torch.from_numpy(res[0][3]).double()
     relrms = ((g - rg).pow(2).mean().sqrt() / rg.pow(2).mean().sqrt()).item()
-    # f16 step, batch split 2 + 2 vs 4: each side carries the tiny random-weight model's f16 gradient noise (2-5 % against the fp32
-    # oracle, tests/test_models_gpu.py); a bucket exchanged before its deferred gradient was written would be off by O(1)
-    assert relrms < 1e-1, relrms
-    assert abs(res[0][2] - ref_loss) < 5e-3 * abs(ref_loss) + 1e-6, (res[0][2], ref_loss)
+    assert relrms < 1e-5, relrms                               # (the LayerNorm / bias column sums meet in fp32 atomics: 1e-8)
 
 
 @pytest.mark.parametrize("kind", ["mlp_mixer", "vitgan"])
