@@ -277,7 +277,8 @@ def plan(chain, N, S, src_size=None, sequential=True):
         need_new = cur is None or stage < cur["stage"] or (stage == 1 and cur["cj"] is not None) or (stage == 2 and cur["has_erase"])
         if name in GEOMETRIC and cur is not None and not need_new:
             # a border-padded affine only keeps its padding as the FIRST warp of a segment; `sequential`: one warp per pass
-            if (name == "Af" and cur["n_geo"] > 0) or (sequential and cur["n_geo"] > 0 and name in ("Af", "Pe", "Ro")):
+            # (kornia's RandomResizedCrop and Resize interpolate too; the integer crops 'Cr' / 'Cc' do not: composing them is exact)
+            if (name == "Af" and cur["n_geo"] > 0) or (sequential and cur["n_geo"] > 0 and name in ("Af", "Pe", "Ro", "Re", "Re2", "R")):
                 need_new = True
         if need_new:
             close()

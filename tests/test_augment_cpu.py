@@ -119,7 +119,10 @@ def test_wider_augmentation_set_parameters():
     assert kinds(("Sh", "Af", "Et", "Ts", "Er")) == ["fused", "Sh", "fused", "Et", "Ts", "fused"]
     assert kinds(("Af", "Pe", "Sh"), sequential=False) == ["fused", "Sh", "fused"]
     assert seqs(("Af", "Pe", "Sh")) == [("fused", 1), ("Sh", 0), ("fused", 0)]
-    assert seqs(("Af", "Re")) == [("fused", 0), ("fused", 0)]              # a resize changes the image size: two launches
+    assert seqs(("Af", "Re")) == [("fused", 1)]                             # kornia's RandomResizedCrop interpolates too (same size: merged)
+    big = lambda augs, **kw: [(k, int(p.get("seq", 0))) for k, p in A.plan(A.draw_chain(8, S, augs, g, src_size=2 * S), 8, S, 2 * S, **kw)]   # noqa: E731
+    assert big(("Af", "R")) == [("fused", 0), ("fused", 0)]                 # a resize that changes the image size: two launches
+    assert big(("Af", "R"), sequential=False) == [("fused", 0)] and big(("Af", "Cc")) == [("fused", 0)]   # composed / exact integer crop
 
 
 def test_fused_plan_matches_the_kornia_restatement_where_they_must_agree():
