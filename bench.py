@@ -670,12 +670,12 @@ def main():
         stepper = None
         torch.cuda.empty_cache()
         env = dict(os.environ, FFVC_SK_FIXUP="0")
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-alt-dtype", "--no-roofline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-alt-dtype", "--no-roofline",
                "--batch", str(args.batch), "--dtype", args.dtype, "--cutn", str(args.cutn), "--dim", str(args.dim), "--depth", str(args.depth)]
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            out["batch_invariant"] = {"ms_per_step": child["ms_per_step"], "value": child["value"], "steps": 6,
+            out["batch_invariant"] = {"ms_per_step": child["ms_per_step"], "value": child["value"], "steps": 10,
                                       "note": "same step with FFVC_SK_FIXUP=0 (config batch_invariant): bit-identical latents whatever the batch size"}
         except Exception as e:        # noqa: BLE001 — a diagnostic leg must not cost the line
             out["batch_invariant"] = {"error": repr(e)[:200]}
