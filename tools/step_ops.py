@@ -16,6 +16,7 @@ class A:
     dtype, dim, depth, cutn, batch, model_type, vq_image_size, augs, grad_wire, keep_cpu_weights = \
         "f16", 1024, 32, 8, 64, "mlp_mixer", 16, "default", "fp32", False
     clip_model, clip_fp8, loss_scale, prefetch_text, dec_fp8 = "ViT-B/32", False, 4096.0, True, False
+    grad_wire_tail, augment_fused = "fp32", False
 
 
 dev = torch.device("cuda:0")
