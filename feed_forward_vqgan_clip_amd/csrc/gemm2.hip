@@ -738,6 +738,20 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     if (env_bm == 1 && d.M >= 1024 && d.N >= 1024 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.K >= 8192 && d.batch == 1 &&
         (int64_t)(d.M / 256) * (d.N / 256) * (d.split_k < 1 ? 1 : d.split_k) >= 192)
       return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
+    // short reductions (the weight gradients of the small-M mappers: 512 rows per GPU): the 128x128 LDS-DMA tile beats the
+    // register-staged kernel there (4096x1024 from 512 rows: 15.6 vs 19.5 us, 1024x1024: 12.0 vs 17.0; profiles/r05_small_m_gemm.txt);
+    // FFVC_SMALLM=0 keeps them on gemm.hip
+    {
+      static int smallm_tt = -1;
+      if (smallm_tt < 0) {
+        const char* e = getenv("FFVC_SMALLM_TT");
+        if (!e) e = getenv("FFVC_SMALLM");
+        smallm_tt = e ? atoi(e) : 1;
+      }
+      if (smallm_tt && env_bm == 1 && d.K <= 1024 && d.batch == 1 && d.split_k <= 1 && d.slab_stride == 0 && d.grp_n == 0 &&
+          (d.M % 8) == 0 && (d.N % 8) == 0 && (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) >= 16)
+        return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 128);
+    }
     // grouped weight gradients (grp_n layers in one launch, full K per tile): always the 256x256 tile
     if (d.grp_n > 0 && d.grp_n == d.batch && (d.M % 256) == 0 && (d.N % 256) == 0 && d.split_k <= 1 && d.slab_stride == 0 && vec_ok == 2)
       return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
