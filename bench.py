@@ -77,7 +77,7 @@ def build(args, device):
     opt.loss_scale = args.loss_scale if cdt == torch.float16 else 1.0
     if hvd.is_distributed():
         opt = hvd.DistributedOptimizer(opt, wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None,
-                                       tail_wire_dtype=torch.bfloat16 if args.grad_wire_tail == "bf16" else None)
+                                       tail_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_tail", "fp32") == "bf16" else None)
         hvd.broadcast_parameters(net, root_rank=0)
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
     return cfg, stepper, (mixer_sd, vq_sd, clip_sd)
