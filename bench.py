@@ -1,6 +1,6 @@
 """bench.py — train-step images/sec of the hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 4
     python bench.py --gpus N --steps K --warmup W          (starts the N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -397,8 +397,9 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps first: torch's caching allocator settles on the step's allocation pattern "
+                    "within the first four steps (a default of 2 put a one-off 140 ms hipMalloc stall into the timed region)")
     ap.add_argument("--batch", type=int, default=64, help="per-GPU prompts per step")
     ap.add_argument("--cutn", type=int, default=8)
     ap.add_argument("--dim", type=int, default=1024)
