@@ -128,12 +128,19 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     chain = None if augs == "R" else faug.draw_chain(cutn * B, 224, faug.DEFAULT if augs == "default" else
                                                      tuple(a for a in augs.split(",") if a != "R"), generator=g)
 
+    first_step = {}
+
     def one(step):
-        loss, _ = ostep.train_step_loss(
+        loss, mid = ostep.train_step_loss(
             lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=len([k for k in sd if k.endswith(".0.norm.weight")])),
             params, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=cb.min().item(), z_max=cb.max().item(),
             facs=facs, noise=noise, aug_chain=chain)
         grads = torch.autograd.grad(loss, plist)
+        if step == 1:
+            # the reference's step is zero_grad -> backward -> step (main.py:825-837): keep what the FIRST oracle step produced — the
+            # gradient of every mapper parameter and the codes it decoded — for the full-size gradient parity leg (full_size_parity)
+            first_step["grads"] = {k: g_.detach().clone() for k, g_ in zip(params, grads)}
+            first_step["oidx"] = ostep.vq_indices(mid["z"].detach().movedim(1, 3), cb).view(-1)
         with torch.no_grad():
             ostep.adam_step(plist, grads, state, 1e-3, step)
         return float(loss.detach())
@@ -152,7 +159,8 @@ def cpu_baseline(sds, cutn, seconds_budget=30.0, augs="default"):
     out = {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
            "sample": f"{n} full oracle train step(s) (fwd+loss+bwd+Adam, fp32) at batch {B}, cutn {cutn}, same cfg2 "
                      f"models/shapes; {dt:.2f} s/step"}
-    return out, {"loss": loss0, "tok": tok, "facs": facs.view(-1), "noise": noise, "aug_chain": chain}
+    return out, {"loss": loss0, "tok": tok, "facs": facs.view(-1), "noise": noise, "aug_chain": chain,
+                 "grads": first_step.get("grads"), "oidx": first_step.get("oidx"), "lr": 1e-3}
 
 
 def _relrms(a, b):
@@ -210,7 +218,7 @@ def full_size_parity(args, sds, ref):
 
     res = {"batch": pb, "timed_dtype": args.dtype,
            "oracle_augmentation": "kornia 0.5.10 nn.Sequential restatement (oracle/kornia_aug.apply_chain) on the same raw draws",
-           "hip_augmentation": "fused single resample (opt-in)" if args.augment_fused else "sequential plan (default): one launch per warp"}
+           "hip_augmentation": "fused single resample (opt-in)" if args.augment_fused else "sequential plan (default): kornia's two resamples evaluated in ONE launch (ffvc_augment_seq_*)"}
     tok, facs, noise, prm = inputs(pb, 99)
     cb = vq_sd["quantize.embedding.weight"]
     torch.set_num_threads(effective_cores())
@@ -247,6 +255,13 @@ def full_size_parity(args, sds, ref):
         del stl
     del st32
     torch.cuda.empty_cache()
+    if ref is not None and ref.get("grads") is not None and pb == len(ref["tok"]):
+        # (2b) GRADIENT parity at full model size in the timed dtype (reference: zero_grad -> backward -> step, main.py:825-837).
+        # The CPU baseline's first oracle step (batch 4, same weights) left its mapper gradients behind; the HIP step runs on the SAME
+        # prompts / draws / noise with the oracle's codes handed to the decoder (the argmin is a discontinuity of the reference
+        # itself), loss-scaled backward as in the timed step, then ONE Adam update.
+        res["grad_parity"] = grad_parity(make, lo, args, ref)
+        torch.cuda.empty_cache()
     if lo != torch.float32 and args.batch > pb:  # (3) the benchmark's own batch, free-running
         tok, facs, noise, prm = inputs(args.batch, 123)
         st32 = make(torch.float32, args.batch)
@@ -274,28 +289,91 @@ def full_size_parity(args, sds, ref):
     return res
 
 
+def grad_parity(make, cdt, args, ref):
+    """HIP backward of the timed dtype vs the oracle's gradients (see full_size_parity (2b)) -> dict for the bench line."""
+    from feed_forward_vqgan_clip_amd import augment as faug
+    from feed_forward_vqgan_clip_amd import ops
+    tok, facs, noise, chain = ref["tok"], ref["facs"], ref["noise"], ref["aug_chain"]
+    st = make(cdt, len(tok))
+    ls = float(args.loss_scale) if cdt == torch.float16 else 1.0
+    st.opt.loss_scale = ls
+    segs = None if chain is None else faug.to_device(faug.plan(chain, len(facs), 224, sequential=not args.augment_fused), "cuda")
+    loss, _ = st.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), aug_params=segs, force_idx=ref["oidx"].cuda())
+    st.opt.zero_grad()
+    (loss if ls == 1.0 else loss * ls).backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    named = dict(st.net.named_parameters())
+    before = {k: p.detach().float().cpu().clone() for k, p in named.items()}
+    dot = nh = no = 0.0
+    worst = ("", 0.0)
+    per = {}
+    for k, go in ref["grads"].items():
+        gh = named[k].grad.detach().float().cpu().double() / ls
+        go = go.double()
+        dot += float((gh * go).sum())
+        nh += float(gh.pow(2).sum())
+        no += float(go.pow(2).sum())
+        r = float((gh - go).pow(2).sum().sqrt() / go.pow(2).sum().sqrt().clamp_min(1e-30))
+        per[k] = r
+        if r > worst[1]:
+            worst = (k, r)
+    st.opt.step()                                   # the update itself (fused Adam, step 1)
+    torch.cuda.synchronize()
+    lr, eps = ref.get("lr", 1e-3), 1e-8
+    dd = do = agree = cnt = 0.0
+    for k, go in ref["grads"].items():
+        d_h = named[k].detach().float().cpu().double() - before[k].double()
+        go = go.double()
+        d_o = -lr * go / (go.abs() + eps)           # torch.optim.Adam, step 1: m_hat = g, v_hat = g^2 (oracle/step.py::adam_step)
+        dd += float((d_h - d_o).pow(2).sum())
+        do += float(d_o.pow(2).sum())
+        agree += float((torch.sign(d_h) == torch.sign(d_o)).sum())
+        cnt += d_o.numel()
+    rs = sorted(per.values())
+    out = {"batch": len(tok), "dtype": {torch.float16: "f16", torch.bfloat16: "bf16"}.get(cdt, "fp32"), "loss_scale": ls,
+           "codes": "the oracle's (forced)", "loss_hip": float(loss), "loss_oracle": ref["loss"],
+           "grad_cosine": dot / max((nh * no) ** 0.5, 1e-300), "grad_flat_relrms": (max(nh + no - 2 * dot, 0.0) / max(no, 1e-300)) ** 0.5,
+           "grad_norm_ratio": (nh / max(no, 1e-300)) ** 0.5, "worst_tensor": worst[0], "worst_tensor_relrms": worst[1],
+           "median_tensor_relrms": rs[len(rs) // 2], "tensors": len(rs),
+           "adam_delta_relrms": (dd / max(do, 1e-300)) ** 0.5, "adam_delta_sign_agreement": agree / max(cnt, 1.0),
+           "note": "oracle gradients = first CPU-baseline step (fp32, batch 4); HIP = timed dtype, loss-scaled backward, same weights / "
+                   "prompts / draws; Adam step 1 moves every element by ~lr*sign(g): adam_delta_* compare the update elementwise"}
+    del st
+    return out
+
+
 HBM_ATTAINABLE_BPS = 6.3e12      # what a streaming kernel reaches of the 8 TB/s HBM3E peak on this part (MI355X_MICROARCH.md; VERDICT r4 #4)
 
 
 def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_path=None):
-    """What the step's own kernels allow: every distinct GEMM launch of the step re-issued ALONE, back to back
-    (same pointers / epilogue / flags: kernels.REPLAY), HBM-bound kernels at algorithmic bytes / 6.3 TB/s, everything else
-    (attention, augmentation, reductions, glue) at its measured time in a SERIALISED step (weight gradients on the main stream,
-    no text prefetch: no co-running kernels).  -> dict for `roofline` + the table rows (kernel | launches | isolated us |
-    in-step us | lost ms), also written to `table_path`."""
+    """Two bounds beside the measured step.
+
+    `attainable_ms` — what the step's OWN kernels allow: every distinct GEMM launch of the step re-issued ALONE, back to back (same
+    pointers / epilogue / flags: kernels.REPLAY; row-split + skinny remainders and the fp8 entry points replay as the launch group
+    they are), HBM-bound kernels at their algorithmic bytes / 6.3 TB/s, everything else at its measured time in a SERIALISED step
+    (weight gradients on the main stream, no text prefetch).  It is a scheduling statement: "the step is the sum of its kernels".
+
+    `hw_bound_ms` — what the HARDWARE allows for the same work: every GEMM's FLOPs at the best sustained rate any launch of this
+    replay reached (stated: `hw_bound_gemm_rate_tflops`, the power-capped library ceiling on this box), HBM-bound kernels at their
+    MINIMAL bytes (each operand once) / 6.3 TB/s, the fused token-mixing / attention / augmentation / reduction kernels at
+    max(FLOPs / that rate, minimal bytes / 6.3 TB/s), and what has no model at its measured time (`unmodelled`).  The table's
+    gap column = (isolated or serialised us - bound us) x launches: milliseconds recoverable per kernel, sorted.
+    """
     from feed_forward_vqgan_clip_amd import kernels as K
     from feed_forward_vqgan_clip_amd import ops
     ops.set_wgrad_side_stream(False)
     stepper(tok)                                  # (untimed: the serialised order allocates differently, let the allocator settle)
-    K.PROFILE, K.HBM_PROFILE = [], []
+    K.PROFILE, K.HBM_PROFILE, K.AUX_PROFILE = [], [], []
+    del K.HBM_MIN_BYTES[:]
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     ev0.record()
     stepper(tok)
     ev1.record()
     torch.cuda.synchronize()
-    prof_b, hbm_b = K.PROFILE, K.HBM_PROFILE
-    K.PROFILE = K.HBM_PROFILE = None
+    prof_b, hbm_b, aux_b, hbm_min = K.PROFILE, K.HBM_PROFILE, K.AUX_PROFILE, list(K.HBM_MIN_BYTES)
+    K.PROFILE = K.HBM_PROFILE = K.AUX_PROFILE = None
     # a third pass only CAPTURES the launches (kernels.REPLAY keeps every operand of the step alive, which sends the allocator to
     # hipMalloc: that pass is not timed)
     K.REPLAY = []
@@ -306,8 +384,10 @@ def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_pat
     wall_b = ev0.elapsed_time(ev1)
     gemm_b = [e0.elapsed_time(e1) for _, _, e0, e1, _ in prof_b]
     hbm_b_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in hbm_b)
-    rest_ms = max(0.0, wall_b - sum(gemm_b) - hbm_b_ms)
-    aligned = len(prof_instep) == len(prof_b) == len(rep)        # same program -> same launch sequence in both steps
+    aux_b_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in aux_b)
+    rest_ms = max(0.0, wall_b - sum(gemm_b) - hbm_b_ms)            # everything that is neither a GEMM launch nor an HBM-profiled kernel
+    unmodelled_ms = max(0.0, rest_ms - aux_b_ms)                   # ... of which no model exists (glue, torch ops, launch gaps)
+    aligned = len(prof_instep) == len(prof_b) == len(rep)          # same program -> same launch sequence in both steps
     rows = {}
     for i, (cls, key, desc, keep) in enumerate(rep):
         r = rows.setdefault((cls,) + key, {"n": 0, "instep": 0.0, "serial": 0.0, "desc": desc, "flop": 2.0 * key[0] * key[1] * key[2] * key[3]})
@@ -326,41 +406,92 @@ def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_pat
     del rep
     gemm_iso_ms = sum(r["n"] * r["iso_us"] for r in rows.values()) / 1e3
     hb = {}
-    for name, nbytes, e0, e1 in hbm_b:
-        h = hb.setdefault(name, {"n": 0, "bytes": 0.0, "serial": 0.0})
+    for (name, nbytes, e0, e1), mb in zip(hbm_b, hbm_min):
+        h = hb.setdefault(name, {"n": 0, "bytes": 0.0, "min_bytes": 0.0, "serial": 0.0})
         h["n"] += 1
         h["bytes"] += nbytes
+        h["min_bytes"] += mb
         h["serial"] += e0.elapsed_time(e1)
     hbm_model_ms = sum(h["bytes"] for h in hb.values()) / HBM_ATTAINABLE_BPS * 1e3
     att = gemm_iso_ms + hbm_model_ms + rest_ms
+    # ---- the hardware bound -------------------------------------------------------------------------------------------------
+    # best sustained isolated rate of this replay: launches of at least 50 GFLOP (shorter ones are dominated by launch / ramp)
+    big = [r["flop"] / (r["iso_us"] * 1e-6) / 1e12 for k, r in rows.items() if r["flop"] >= 5e10 and not k[0].endswith("f32")]
+    best_rate = max(big) if big else max([r["flop"] / (r["iso_us"] * 1e-6) / 1e12 for r in rows.values()] + [1.0])
+    f32_rates = [r["flop"] / (r["iso_us"] * 1e-6) / 1e12 for k, r in rows.items() if k[0].endswith("f32")]
+
+    def gemm_bound_us(k, r):
+        rate = 157.3 if k[0].endswith("f32") else (2.0 * best_rate if k[0].endswith("fp8") else best_rate)
+        return r["flop"] / (rate * 1e12) * 1e6
+    gemm_bound_ms = sum(r["n"] * gemm_bound_us(k, r) for k, r in rows.items()) / 1e3
+    hbm_min_ms = sum(h["min_bytes"] for h in hb.values()) / HBM_ATTAINABLE_BPS * 1e3
+    ax = {}
+    for name, flops, nbytes, e0, e1 in aux_b:
+        a = ax.setdefault(name, {"n": 0, "flops": 0.0, "bytes": 0.0, "serial": 0.0})
+        a["n"] += 1
+        a["flops"] += flops
+        a["bytes"] += nbytes
+        a["serial"] += e0.elapsed_time(e1)
+    for a in ax.values():
+        a["bound_ms"] = max(a["flops"] / (best_rate * 1e12), a["bytes"] / HBM_ATTAINABLE_BPS) * 1e3
+    aux_bound_ms = sum(a["bound_ms"] for a in ax.values())
+    hw_bound = gemm_bound_ms + hbm_min_ms + aux_bound_ms + unmodelled_ms
+    gaps = []                                     # (gap ms, label)
     lines = [f"# attainable = sum(GEMM launches x isolated us) {gemm_iso_ms:.2f} ms + HBM kernels' algorithmic bytes / {HBM_ATTAINABLE_BPS / 1e12:.1f} TB/s "
              f"{hbm_model_ms:.2f} ms + the rest as measured in a serialised step {rest_ms:.2f} ms = {att:.2f} ms; step {ms_per_step:.2f} ms "
              f"-> frac_of_attainable {att / ms_per_step:.3f}; serialised step (no side streams) {wall_b:.2f} ms",
-             "# kernel class | M N K batch split_k flags act | launches/step | isolated us | TFLOP/s isolated | in-step us | serialised-step us | lost ms/step (in-step - isolated)"]
-    for k, r in sorted(rows.items(), key=lambda kv: -(kv[1]["instep"] - kv[1]["n"] * kv[1]["iso_us"] / 1e3)):
+             f"# hw_bound = GEMM FLOPs at the best sustained isolated rate of this replay ({best_rate:.0f} TFLOP/s; fp32 MFMA launches at 157.3, fp8 at 2x) "
+             f"{gemm_bound_ms:.2f} ms + HBM kernels' MINIMAL bytes / {HBM_ATTAINABLE_BPS / 1e12:.1f} TB/s {hbm_min_ms:.2f} ms + token-mix / attention / augmentation / "
+             f"reduction kernels at max(FLOPs / that rate, bytes / {HBM_ATTAINABLE_BPS / 1e12:.1f} TB/s) {aux_bound_ms:.2f} ms + unmodelled (glue, torch ops, gaps; measured) "
+             f"{unmodelled_ms:.2f} ms = {hw_bound:.2f} ms; step {ms_per_step:.2f} ms -> step / hw_bound {ms_per_step / hw_bound:.2f}",
+             "# kernel class | M N K batch split_k flags act | launches/step | isolated us | TFLOP/s isolated | in-step us | serialised-step us | lost ms/step (in-step - isolated) | bound us | gap ms/step ((isolated - bound) x launches)"]
+    for k, r in sorted(rows.items(), key=lambda kv: -(kv[1]["n"] * (kv[1]["iso_us"] - gemm_bound_us(kv[0], kv[1])))):
         ins, ser = r["instep"] / r["n"] * 1e3, r["serial"] / r["n"] * 1e3
+        bnd = gemm_bound_us(k, r)
+        gap = r["n"] * (r["iso_us"] - bnd) / 1e3
+        gaps.append((gap, f"{k[0]} {k[1]}x{k[2]}x{k[3]} b{k[4]} f{k[6]} a{k[7]}"))
         lines.append(f"{k[0]:12s} {k[1]:6d} {k[2]:6d} {k[3]:6d} b{k[4]:<3d} sk{k[5]:<2d} f{k[6]:<5d} a{k[7]} | {r['n']:4d} | {r['iso_us']:8.1f} | "
-                     f"{r['flop'] / (r['iso_us'] * 1e-6) / 1e12:7.1f} | {ins:8.1f} | {ser:8.1f} | {r['instep'] - r['n'] * r['iso_us'] / 1e3:7.3f}")
-    lines.append("# HBM-bound kernel | launches/step | MB/launch | model us (bytes / 6.3 TB/s) | in-step us | serialised-step us | lost ms/step")
+                     f"{r['flop'] / (r['iso_us'] * 1e-6) / 1e12:7.1f} | {ins:8.1f} | {ser:8.1f} | {r['instep'] - r['n'] * r['iso_us'] / 1e3:7.3f} | {bnd:8.1f} | {gap:7.3f}")
+    lines.append("# HBM-bound kernel | launches/step | MB/launch | model us (bytes / 6.3 TB/s) | in-step us | serialised-step us | lost ms/step | minimal MB/launch | bound us | gap ms/step ((serialised - bound) x launches)")
     hi = {}
     for name, nbytes, e0, e1 in hbm_instep or []:
         a = hi.setdefault(name, [0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
-    for name, h in sorted(hb.items(), key=lambda kv: -kv[1]["serial"]):
+    for name, h in sorted(hb.items(), key=lambda kv: -(kv[1]["serial"] - kv[1]["min_bytes"] / HBM_ATTAINABLE_BPS * 1e3)):
         model = h["bytes"] / h["n"] / HBM_ATTAINABLE_BPS * 1e6
+        bnd = h["min_bytes"] / h["n"] / HBM_ATTAINABLE_BPS * 1e6
         ins = hi.get(name, [1, 0.0])
+        gap = h["serial"] - h["n"] * bnd / 1e3
+        gaps.append((gap, name))
         lines.append(f"{name:28s} | {h['n']:4d} | {h['bytes'] / h['n'] / 1e6:8.1f} | {model:8.1f} | {ins[1] / max(ins[0], 1) * 1e3:8.1f} | "
-                     f"{h['serial'] / h['n'] * 1e3:8.1f} | {ins[1] - h['n'] * model / 1e3:7.3f}")
+                     f"{h['serial'] / h['n'] * 1e3:8.1f} | {ins[1] - h['n'] * model / 1e3:7.3f} | {h['min_bytes'] / h['n'] / 1e6:8.1f} | {bnd:8.1f} | {gap:7.3f}")
+    lines.append("# other kernel | launches/step | GFLOP/launch | MB/launch | serialised-step us | bound us (max(FLOPs / best rate, bytes / 6.3 TB/s)) | gap ms/step")
+    for name, a in sorted(ax.items(), key=lambda kv: -(kv[1]["serial"] - kv[1]["bound_ms"])):
+        gap = a["serial"] - a["bound_ms"]
+        gaps.append((gap, name))
+        lines.append(f"{name:28s} | {a['n']:4d} | {a['flops'] / a['n'] / 1e9:8.2f} | {a['bytes'] / a['n'] / 1e6:8.1f} | {a['serial'] / a['n'] * 1e3:8.1f} | "
+                     f"{a['bound_ms'] / a['n'] * 1e3:8.1f} | {gap:7.3f}")
+    lines.append(f"# unmodelled (measured, serialised step): {unmodelled_ms:.2f} ms")
     if table_path:
         os.makedirs(os.path.dirname(os.path.abspath(table_path)), exist_ok=True)
         with open(table_path, "w") as f:
             f.write("\n".join(lines) + "\n")
+    gaps.sort(key=lambda g: -g[0])
     return {"attainable_ms": att, "frac_of_attainable": att / ms_per_step,
             "attainable_parts_ms": {"gemm_isolated": gemm_iso_ms, "hbm_at_6.3TBps": hbm_model_ms, "rest_serialised": rest_ms},
             "serialised_step_ms": wall_b, "attainable_aligned": aligned,
             "attainable_note": "every distinct GEMM launch of the step replayed alone (same descriptor), HBM kernels at bytes / 6.3 TB/s, "
-                               "everything else at its time in a serialised step; frac_of_attainable = attainable_ms / ms_per_step"}, lines
+                               "everything else at its time in a serialised step (rest_serialised: measured, i.e. self-referential by "
+                               "construction); frac_of_attainable = attainable_ms / ms_per_step",
+            "hw_bound_ms": hw_bound, "step_over_hw_bound": ms_per_step / hw_bound,
+            "hw_bound_parts_ms": {"gemm_flops_at_best_rate": gemm_bound_ms, "hbm_min_bytes_at_6.3TBps": hbm_min_ms,
+                                  "tokmix_attention_augment_reductions_modelled": aux_bound_ms, "unmodelled_measured": unmodelled_ms},
+            "hw_bound_gemm_rate_tflops": best_rate, "hw_bound_fp32_mfma_rate_seen_tflops": max(f32_rates) if f32_rates else None,
+            "hw_bound_note": "GEMM FLOPs / the best sustained isolated rate of this replay (the library's power-capped ceiling on this box) + HBM "
+                             "kernels at minimal bytes / 6.3 TB/s + token-mix / attention / augmentation / reductions at max(FLOP, byte) model + "
+                             "unmodelled glue at its measured time",
+            "top_gaps_ms": [{"kernel": lbl, "gap_ms": round(g, 3)} for g, lbl in gaps[:10]]}, lines
 
 
 def launch_ranks(n):
@@ -495,11 +626,20 @@ def main():
     sync()
     clk0 = K.clock_sample()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU time (diagnostic only)
+    # did any timed f16 step trip the non-finite guard?  The Adam kernel counts wavefront-level overflow events on the device
+    # (FusedAdam._bad); a 4-byte device-to-device snapshot per step (no host synchronisation) tells afterwards WHICH steps did.
+    inner_opt = getattr(stepper.opt, "opt", stepper.opt)
+    bad_dev = getattr(inner_opt, "_bad", None)
+    bad_hist = torch.zeros(args.steps + 1, dtype=bad_dev.dtype, device=device) if bad_dev is not None else None
+    if bad_hist is not None:
+        bad_hist[0:1].copy_(bad_dev.view(-1)[0:1])
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         loss, _ = stepper(batches[it], next_inp=batches[it + 1] if args.prefetch_text else None)
         marks[i + 1].record()
+        if bad_hist is not None:
+            bad_hist[i + 1:i + 2].copy_(bad_dev.view(-1)[0:1])
         it += 1
     clk1 = K.clock_sample()
     sync()
@@ -533,9 +673,13 @@ def main():
                                f"{args.clip_model}, per-GPU batch {B}, cutn {args.cutn}, augs {args.augs} + noise, full step "
                                "(fwd+loss+bwd+all-reduce+Adam)",
                    "global_batch": B * world, "parallelism": f"dp{world}", "grad_wire": args.grad_wire, "hip_graph": bool(args.graph),
-                   "augmentation": "fused single resample (opt-in)" if args.augment_fused else "kornia order: one resample per warp (Af | Pe+Ji+Er)",
+                   "augmentation": "fused single resample (opt-in)" if args.augment_fused else "kornia order: one resample per warp (Af, then Pe+Ji+Er), both inside one launch",
                    "dp": hvd.describe()},
         "final_loss": float(loss.item()),
+        # timed steps whose backward produced a non-finite scaled gradient (the Adam kernel's device-side guard): must be 0 for the
+        # line to be 20 real updates
+        "overflow_steps": (int((bad_hist[1:] != bad_hist[:-1]).sum().item()) if bad_hist is not None else None),
+        "overflow_events": (int((bad_hist[-1] - bad_hist[0]).item()) if bad_hist is not None else None),
         # average engine clock over the timed steps (s_memtime / s_memrealtime): the chip clocks to its power budget, so the
         # MFMA peak actually available is PEAK x sclk / 2400 (profiles/r03_power_ceiling.txt)
         "sclk_mhz_effective": sclk_mhz,
@@ -562,8 +706,14 @@ def main():
         torch.cuda.synchronize()
         if dp_opt is not None and rank == 0:
             rep = dp_opt.exposure_report() or []
+            bw = [r["busbw_GBps"] for r in rep if r.get("busbw_GBps")]
             out["dp_exposure"] = {"slices": len(rep), "exposed_ms": max([r["ms_after_backward"] or 0.0 for r in rep] + [0.0]),
-                                  "late_slices": [r for r in rep if (r["ms_after_backward"] or 0.0) > 0.0][-8:]}
+                                  "late_slices": [r for r in rep if (r["ms_after_backward"] or 0.0) > 0.0][-8:],
+                                  # achieved all-reduce bus bandwidth per slice (payload x 2(N-1)/N / time on the wire): against 7 xGMI
+                                  # links x ~153 GB/s per GPU; the slowest and the median slice, and every slice's figure
+                                  "busbw_GBps": {"min": min(bw), "median": sorted(bw)[len(bw) // 2], "max": max(bw)} if bw else None,
+                                  "busbw_GBps_per_slice": [(r["slice"], r["MiB"], r.get("busbw_GBps")) for r in rep],
+                                  "rccl_preset_enabled": os.environ.get("FFVC_RCCL_PRESET", "1") != "0"}
         if dp_opt is not None:
             dp_opt.measure_exposure(False)
     if rank == 0 and not args.no_roofline:
@@ -593,7 +743,7 @@ def main():
         try:
             import hashlib
             from feed_forward_vqgan_clip_amd import _lib as flib
-            pmc_name = next((n for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_pmc_traffic.json")
+            pmc_name = next((n for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_pmc_traffic.json")
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             cls = name.rsplit("_", 1)[0]
             if cls in pmc:
@@ -671,8 +821,23 @@ def main():
         stepper = None
         torch.cuda.empty_cache()
         env = dict(os.environ, FFVC_SK_FIXUP="0")
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-alt-dtype", "--no-roofline",
-               "--batch", str(args.batch), "--dtype", args.dtype, "--cutn", str(args.cutn), "--dim", str(args.dim), "--depth", str(args.depth)]
+        # the child times THIS run's configuration: its argv minus the step counts and the diagnostic legs
+        keep, skip = [], False
+        for a_ in sys.argv[1:]:
+            if skip:
+                skip = False
+                continue
+            if a_ in ("--steps", "--warmup", "--isolated-table", "--gemm-shapes", "--gpus"):
+                skip = True
+                continue
+            if a_.split("=")[0] in ("--steps", "--warmup", "--isolated-table", "--gemm-shapes", "--gpus", "--no-cpu-baseline", "--no-alt-dtype", "--no-roofline"):
+                continue
+            keep.append(a_)
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-alt-dtype", "--no-roofline"] + keep
+        sds = ref = None                      # the parent keeps nothing on the GPU while the child is timed
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -95,6 +95,7 @@ class ParamArena:
     def zero_grad(self):
         if self.grads.is_cuda:
             from . import ops
+            ops.discard_wgrad_groups()   # leftovers of a backward pass that never finished must not reach the fresh bucket
             ops.join_side_stream()
         self.grads.zero_()
         for p in self.plist:            # someone (e.g. optimizer.zero_grad(set_to_none=True)) may have dropped the views

@@ -30,6 +30,9 @@ int ffvc_gemm2_launch_conv(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, 
 int ffvc_gemm2_launch_nn(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
 int ffvc_gemm2_launch_tn(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
 int ffvc_gemm2_launch_tt(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
+// gemm3.hip: the 256x128 ring kernel with two workgroups per CU (epilogue-heavy K-major x K-major launches)
+int ffvc_gemm3_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, int mode);
+int g_opt_gemm3 = -100;     // ffvc_set_option("gemm3", v): -1 never | 0 heuristic | 1 every eligible launch; unset -> FFVC_GEMM3 (default 0)
 
 namespace {
 
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
     // the row-store pads alias the X tile (all X / W reads retired behind the barrier that closed the last step)
     if constexpr (M16) {
       if (vec_ok == 2)
-        ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
+        ffvc_gemm_detail::gemm_epilogue_out16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
       else
         ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc16, m0, n0, wm, wn, lane, 0, 0, 1);
     } else {
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_row_kernel(const ffvc_gemm_desc p
   }
   if constexpr (M16) {
     if (vec_ok == 2)
-      ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
+      ffvc_gemm_detail::gemm_epilogue_out16<L, MT, EPI>(p, acc16, m0, n0, wm, wn, lane, 0, 0, smem + XTILE + WTILE + wid * 4096);
     else
       ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc16, m0, n0, wm, wn, lane, 0, 0, 1);
   } else {
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void conv_row2_kernel(const ffvc_gemm_desc 
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last MFMAs' results before the VALU reads them
   __builtin_amdgcn_s_barrier();                              // every wave is done with the X tiles: the pads may alias X0
   if (vec_ok == 2)
-    ffvc_gemm_detail::gemm_epilogue_rows16<L, MT, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
+    ffvc_gemm_detail::gemm_epilogue_out16<L, MT, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem + wid * 4096);
   else
     ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc, m0, n0, wm, wn, lane, 0, 0, 1);
 #ifdef FFVC_CR_TIMING
@@ -638,7 +641,18 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     }
     if (d.K <= shortk && cfg != 128) cfg = 128;
   }
-  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) return ffvc_gemm2_launch_kk(d, st, vec_ok, zero, cfg);
+  if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR) {
+    if (env_bm == 1) {         // no tile forced: the two-workgroups-per-CU kernel takes the launches it is built for (gemm3.hip)
+      static int g3_env = -100;
+      if (g3_env == -100) {
+        const char* e = getenv("FFVC_GEMM3");
+        g3_env = e ? atoi(e) : 0;
+      }
+      const int r3 = ffvc_gemm3_try(d, st, vec_ok, g_opt_gemm3 != -100 ? g_opt_gemm3 : g3_env);
+      if (r3 != 0) return r3;
+    }
+    return ffvc_gemm2_launch_kk(d, st, vec_ok, zero, cfg);
+  }
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR) {
     const int env_row = opt_value(g_opt_conv_row, "FFVC_CONV_ROW", 1);
     const int W = d.conv_W;
@@ -730,6 +744,14 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
     // (3 workgroups/CU) vs 551 on the 128x128 DMA tile -> keep it on gemm.hip unless forced
     // round 2 (profiles/r02_wgrad_ab.txt): with 256x256 tiles and a 4-way slab split-K the DMA path passes it on the big
     // square-ish weight gradients (4096x1024x16384: 856 vs 640 TFLOP/s); narrow outputs / short reductions stay on v1.
+    // grouped weight gradients (grp_n layers in one launch, full K per tile) FIRST: only the 256x256 tile reads the per-entry offset
+    // table, so neither a forced tile (FFVC_GEMM2_BM) nor any heuristic below may route them elsewhere — a descriptor the 256x256
+    // kernel cannot take is refused (0 -> ffvc_gemm raises FFVC_E_UNSUPPORTED), never run on layer 0's operands
+    if (d.grp_n > 0) {
+      const bool gok = d.grp_n == d.batch && d.grp_n <= 8 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.split_k <= 1 && d.slab_stride == 0 &&
+                       vec_ok == 2;      // (launch2 itself picks buffer-descriptor or global-address DMA per operand range)
+      return gok ? ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512) : 0;
+    }
     if (env_bm == 128 || env_bm == 256 || env_bm == 512) return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, cfg);
     // FFVC_F_SPLITK_INKERNEL: the caller asked for the kernel that combines its K slices itself — the 256x256 tile, whatever the
     // fill heuristic below thinks of the grid
@@ -752,9 +774,6 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
           (d.M % 8) == 0 && (d.N % 8) == 0 && (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) >= 16)
         return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 128);
     }
-    // grouped weight gradients (grp_n layers in one launch, full K per tile): always the 256x256 tile
-    if (d.grp_n > 0 && d.grp_n == d.batch && (d.M % 256) == 0 && (d.N % 256) == 0 && d.split_k <= 1 && d.slab_stride == 0 && vec_ok == 2)
-      return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 512);
     return 0;
   }
   if (d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_TRANS) return ffvc_gemm2_launch_nn(d, st, vec_ok, zero, cfg);
@@ -781,6 +800,10 @@ extern "C" int ffvc_set_option(const char* name, int value) {
   if (!name) return FFVC_E_BADARG;
   if (!strcmp(name, "gemm8")) {
     g_force_gemm8 = value;
+    return 0;
+  }
+  if (!strcmp(name, "gemm3")) {
+    g_opt_gemm3 = value;
     return 0;
   }
   if (!strcmp(name, "gemm2_tile")) {

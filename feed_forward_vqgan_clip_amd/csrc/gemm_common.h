@@ -549,4 +549,203 @@ __device__ __forceinline__ void gemm_epilogue_rows16(const ffvc_gemm_desc& p, f3
       m0, n0, wm, wn, lane, zo, zi, pad, zs);
 }
 
+// ---- register-exchange epilogue for 16x16x32 accumulators (round 6) --------------------------------------------------
+// The row-store epilogue above moves every 32x32 block through a wave-private LDS pad (4 ds_write_b128 + 4 ds_read_b128 per lane
+// and block, two wave barriers, 4 KiB of LDS per wave) only to turn "4 consecutive n per lane" into "8 consecutive n per lane".
+// For 16x16x32 accumulators ONE v_permlane16_swap per register does the same: acc[a][b] gives lane (l15, g4) the columns
+// 16 a + 4 g4 .. + 3 of row 16 b + l15; swapping the odd 16-lane rows of acc[2p][b] with the even rows of acc[2p + 1][b] leaves
+// lane group g4 with the 8 consecutive columns 32 p + {0, 16, 8, 24}[g4] .. + 7 (first four in the register that held acc[2p][b],
+// the next four in the one that held acc[2p + 1][b]).  One store instruction then covers 16 rows x 64 contiguous bytes (16-bit
+// output), exactly the pad version's granularity, with no LDS traffic, no barrier and no 4 KiB pads — which is what lets two
+// workgroups of the 256x128 ring kernel (gemm3_kernel) fit a CU and keeps the partner workgroup's fragment reads undisturbed.
+// Without fences in the way, the side input of the next 8-column group (aux of the multiply kinds, the fp32 residual of the
+// projection kinds) is requested before the current group is finished: the epilogue no longer pays one memory round trip per group.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_oct_pre(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, const f32x8& pre) {
+  if constexpr ((EPI & EPI_K_MULAUX) != 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] *= pre.v[j];
+    store8((T*)p.y + yrow + n, v);
+  } else {           // EPI_O_F32R: column bias (when present), + fp32 residual, fp32 store
+    if (p.bias) {
+      const f32x8 b = load8(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v.v[j] += b.v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] += pre.v[j];
+    store8((float*)p.y + yrow + n, v);
+  }
+}
+
+template <typename T, int MT, int EPI = EPI_ALL>
+__device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f32x4_t (&acc)[4][2 * MT], int m0, int n0, int wm,
+                                                     int wn, int lane, int zo, int zi, int zs = -1) {
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int cofs = ((g4 & 1) << 4) | ((g4 & 2) << 2);          // {0, 16, 8, 24}[g4]
+  const int flags = p.flags;
+  if (zs < 0) zs = blockIdx.z;
+  const int64_t ybz = zo * p.ybo + zi * p.ybi + (int64_t)zs * p.slab_stride;
+  const int64_t rbz = zo * p.rbo + zi * p.rbi;
+  const int64_t abz = zo * p.abo + zi * p.abi;
+  const bool gn = (EPI & EPI_GN) && (flags & FFVC_F_GN_SUMS);
+  float gs1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gs2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [p][4-channel half]
+  float f8_amax = 0.0f, f8_scale = 1.0f;
+  if constexpr ((EPI & EPI_O_F8) != 0) f8_scale = p.y8_state[0];
+  (void)f8_amax;
+  (void)f8_scale;
+  const bool cs_on = (EPI & (EPI_ACT | EPI_K_BWD | EPI_K_MULAUX)) && (flags & FFVC_F_COLSUM);
+  float cs[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[q][j] = 0.f;
+  constexpr bool PRE = (EPI & (EPI_K_MULAUX | EPI_O_F32R)) != 0;        // kinds with exactly one streamed side input
+  constexpr int NIT = 2 * MT * 2;                                       // (b, p) groups of 16 rows x 32 columns
+  auto rowof = [&](int it, bool& mok, int64_t& yrow, int64_t& rrow, int64_t& arow) {
+    const int b = it >> 1;
+    const int m = m0 + wm * (32 * MT) + 16 * b + l15;
+    mok = m < p.M;
+    const int mm = mok ? m : 0;
+    yrow = ybz + (p.y_mi ? (int64_t)(mm / p.y_mi) * p.y_so + (int64_t)(mm % p.y_mi) * p.y_sm : (int64_t)mm * p.y_sm);
+    rrow = rbz + (p.r_mi ? (int64_t)(mm / p.r_mi) * p.r_so + (int64_t)(mm % p.r_mi) * p.r_sm : (int64_t)mm * p.r_sm);
+    arow = abz + (int64_t)mm * p.ldaux;
+  };
+  auto colof = [&](int it) { return n0 + wn * 64 + 32 * (it & 1) + cofs; };
+  auto side = [&](int it) -> f32x8 {
+    f32x8 r;
+    bool mok;
+    int64_t yrow, rrow, arow;
+    rowof(it, mok, yrow, rrow, arow);
+    const int n = colof(it);
+    if (mok && n < p.N) {
+      if constexpr ((EPI & EPI_K_MULAUX) != 0) r = load8((const T*)p.aux + arow + n);
+      else r = load8((const float*)p.residual + rrow + n);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[j] = 0.f;
+    }
+    return r;
+  };
+  f32x8 pre_cur, pre_nxt;
+  if constexpr (PRE) pre_cur = side(0);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int b = it >> 1, pp = it & 1;
+    if constexpr (PRE) {
+      if (it + 1 < NIT) pre_nxt = side(it + 1);
+    }
+    bool mok;
+    int64_t yrow, rrow, arow;
+    rowof(it, mok, yrow, rrow, arow);
+    const int n = colof(it);
+    float bias_m = 0.0f;
+    if constexpr ((EPI & EPI_K_ANY) == 0)
+      if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(m0 + wm * (32 * MT) + 16 * b + l15, p.M - 1)];
+    f32x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // bias along M is a per-row constant: it may be added before the exchange (the row does not change, only the columns)
+      const float x0 = acc[2 * pp][b][e] * p.alpha + bias_m, x1 = acc[2 * pp + 1][b][e] * p.alpha + bias_m;
+      const u32x2_t s = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+      v.v[e] = __uint_as_float(s[0]);
+      v.v[4 + e] = __uint_as_float(s[1]);
+    }
+    if (mok && n < p.N) {
+      if constexpr (PRE) epilogue_oct_pre<T, EPI>(p, v, n, yrow, pre_cur);
+      else epilogue_oct<T, EPI>(p, v, n, yrow, rrow, arow, flags);
+      if constexpr ((EPI & EPI_O_F8) != 0) {
+        constexpr float LIM = (EPI & EPI_O_F8E4) ? 448.0f : 57344.0f;
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f8_amax = fmaxf(f8_amax, fabsf(v.v[j]));
+          const float s = v.v[j] * f8_scale;
+          q[j] = s != s ? s : fminf(fmaxf(s, -LIM), LIM);
+        }
+        int lo = 0, hi = 0;
+        if constexpr ((EPI & EPI_O_F8E4) != 0) {
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], lo, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], hi, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+        } else {
+          lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], lo, false);
+          lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], lo, true);
+          hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], hi, false);
+          hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], hi, true);
+        }
+        *(u32x2_t*)((unsigned char*)p.y + yrow + n) = u32x2_t{(uint32_t)lo, (uint32_t)hi};
+      }
+      if (gn) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          gs1[pp][j >> 2] += v.v[j];
+          gs2[pp][j >> 2] += v.v[j] * v.v[j];
+        }
+      }
+      if (cs_on) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[pp][j] += v.v[j];
+      }
+    }
+    if constexpr (PRE) pre_cur = pre_nxt;
+  }
+  if constexpr ((EPI & EPI_O_F8) != 0) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) f8_amax = fmaxf(f8_amax, __shfl_xor(f8_amax, o, 64));
+    if (lane == 0 && f8_amax > 0.0f) atomicMax((unsigned int*)(p.y8_state + 1), __float_as_uint(f8_amax));
+  }
+  if (cs_on) {
+    // column sums of everything this wave stored: the 16 lanes of a lane group own the same 8 columns -> fold them, one fp32
+    // atomic per column and wave
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = n0 + wn * 64 + 32 * q + cofs;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = cs[q][j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (l15 == 0 && n < p.N) atomicAdd(p.colsum + n + j, a);
+      }
+    }
+  }
+  if (gn) {
+    const int64_t img = (int64_t)(m0 / p.gn_hw) * (p.N / p.gn_cpg);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float a = gs1[q][hf], b = gs2[q][hf];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        const int n = n0 + wn * 64 + 32 * q + cofs + 4 * hf;
+        if (l15 == 0 && n < p.N) {
+          double* o2 = p.gn_sums + (img + n / p.gn_cpg) * 2;
+          atomicAdd(o2, (double)a);
+          atomicAdd(o2 + 1, (double)b);
+        }
+      }
+  }
+}
+
+// The epilogue the 16x16x32 kernels use: register exchange (default) or the LDS pads of rounds 1-5 (-DFFVC_EPI_PERM=0, A/B builds).
+#ifndef FFVC_EPI_PERM
+#define FFVC_EPI_PERM 1
+#endif
+template <typename T, int MT, int EPI = EPI_ALL>
+__device__ __forceinline__ void gemm_epilogue_out16(const ffvc_gemm_desc& p, f32x4_t (&acc)[4][2 * MT], int m0, int n0, int wm,
+                                                    int wn, int lane, int zo, int zi, unsigned char* pad, int zs = -1) {
+#if FFVC_EPI_PERM
+  (void)pad;
+  gemm_epilogue_perm16<T, MT, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, zs);
+#else
+  gemm_epilogue_rows16<T, MT, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, pad, zs);
+#endif
+}
+
 }  // namespace ffvc_gemm_detail

@@ -120,6 +120,7 @@ def describe():
         return {"backend": None, "ranks": 1, "env": env}
     return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "env": env,
             "preset_applied": sorted(_STATE.get("preset", {})),
+            "preset_enabled": os.environ.get("FFVC_RCCL_PRESET", "1") != "0",        # FFVC_RCCL_PRESET=0: A/B against RCCL's own defaults
             "hsa_ipc_mode_legacy_exported_0": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0",
             "wire": _STATE.get("wire"),
             "bucket_exchange": "ffvc_allreduce_bucket (own RCCL communicator)" if _STATE.get("native") else "torch.distributed"}
@@ -346,15 +347,33 @@ class DistributedOptimizer:
         t = self._timing
         if not t or t.get("last") is None:
             return None
-        done, end, order, buckets, wire = t["last"]
+        done, end, order, buckets, wire = t["last"][:5]
+        start = t["last"][5] if len(t["last"]) > 5 else {}
+        n = size()
+        bus = 2.0 * (n - 1) / n if n > 1 else 1.0          # ring all-reduce: bytes each link carries per payload byte
+        prev_done = None
         names = {id(p): n for n, p in self.arena.module.named_parameters()} if hasattr(self.arena, "module") else {}
         out = []
         for b in sorted(done, key=lambda k: order.get(k, 1 << 30)):
             s, e, idxs = buckets[b]
             pn = [names.get(id(self.arena.plist[i]), str(i)) for i in idxs]
-            out.append({"slice": b, "MiB": round((e - s) * 4 / 2 ** 20, 1), "wire": str(wire[b] or torch.float32).replace("torch.", ""),
-                        "params": pn[0] if len(pn) == 1 else f"{pn[-1]} .. {pn[0]}",
-                        "ms_after_backward": round(end.elapsed_time(done[b]), 3) if end is not None else None})
+            row = {"slice": b, "MiB": round((e - s) * 4 / 2 ** 20, 1), "wire": str(wire[b] or torch.float32).replace("torch.", ""),
+                   "params": pn[0] if len(pn) == 1 else f"{pn[-1]} .. {pn[0]}",
+                   "ms_after_backward": round(end.elapsed_time(done[b]), 3) if end is not None else None}
+            # achieved bus bandwidth of this slice: payload x 2(N-1)/N over the time the exchange had the wire to itself — from the
+            # later of (handed to the exchange, previous slice finished) to its own completion event
+            try:
+                if b in start:
+                    dur = start[b].elapsed_time(done[b])
+                    if prev_done is not None:
+                        dur = min(dur, max(prev_done.elapsed_time(done[b]), 1e-3))
+                    wbytes = (e - s) * (2 if wire[b] in (torch.bfloat16, torch.float16) else 4)
+                    row["exchange_ms"] = round(dur, 3)
+                    row["busbw_GBps"] = round(bus * wbytes / max(dur, 1e-6) / 1e6, 1)
+            except (RuntimeError, ValueError):
+                pass
+            prev_done = done[b]
+            out.append(row)
         return out
 
     # -- gradient-ready plumbing ------------------------------------------------
@@ -430,6 +449,10 @@ class DistributedOptimizer:
 
     def _enqueue(self, b, g):
         self._order[b] = len(self._order)
+        if self._timing is not None and g.is_cuda:
+            ev0 = torch.cuda.Event(enable_timing=True)     # when the slice was handed to the exchange (enqueuing stream)
+            ev0.record()
+            self._timing.setdefault("start", {})[b] = ev0
         t = g
         wd = self._wire_of[b]
         if wd is not None and wd != g.dtype:
@@ -558,8 +581,9 @@ class DistributedOptimizer:
     def _after_step(self):
         order = sorted(self._order, key=self._order.get)
         if self._timing is not None:
-            self._timing["last"] = (self._timing["done"], self._timing["bwd_end"], dict(self._order), list(self.buckets), list(self._wire_of))
-            self._timing["done"], self._timing["bwd_end"] = {}, None
+            self._timing["last"] = (self._timing["done"], self._timing["bwd_end"], dict(self._order), list(self.buckets), list(self._wire_of),
+                                    self._timing.get("start", {}))
+            self._timing["done"], self._timing["bwd_end"], self._timing["start"] = {}, None, {}
         self._reset()
         self._order = {}
         if not self._tail_tuned and is_distributed() and len(order) == len(self.buckets):

@@ -38,6 +38,12 @@ REPLAY = None
 
 
 def replay_gemm(desc, n=1):
+    """Re-issue a captured launch n times: `desc` is a GemmDesc (plain ffvc_gemm) or a zero-argument callable that performs the
+    whole launch group (row-split + skinny remainder, the fp8 entry points)."""
+    if callable(desc):
+        for _ in range(n):
+            desc()
+        return
     lib = _lib.load()
     for _ in range(n):
         _lib.check(lib.ffvc_gemm(byref(desc), stream_ptr()), "ffvc_gemm (replay)")
@@ -49,8 +55,12 @@ HBM_PROFILE = None
 
 
 class _hbm:
-    def __init__(self, name, nbytes):
+    """nbytes = algorithmic bytes of the kernel AS BUILT; min_bytes = what any implementation has to move (every operand read
+    once, every result written once) — bench.py's roofline.hw_bound_ms prices the kernel at min_bytes."""
+
+    def __init__(self, name, nbytes, min_bytes=None):
         self.name, self.nbytes = name, nbytes
+        self.min_bytes = nbytes if min_bytes is None else min_bytes
 
     def __enter__(self):
         if HBM_PROFILE is not None:
@@ -62,6 +72,31 @@ class _hbm:
         if HBM_PROFILE is not None:
             self.e1.record()
             HBM_PROFILE.append((self.name, float(self.nbytes), self.e0, self.e1))
+            HBM_MIN_BYTES.append(float(self.min_bytes))
+        return False
+
+
+# The remaining kernels of a step (fused token-mixing MLP, attention, augmentation, reductions, glue): when AUX_PROFILE is a list
+# their launchers append (name, algorithmic FLOPs, minimal bytes, events) — bench.py's hardware bound prices each at
+# max(FLOPs / best sustained GEMM rate, bytes / 6.3 TB/s) next to its measured time.
+AUX_PROFILE = None
+HBM_MIN_BYTES = []         # parallel to HBM_PROFILE (kept separate: the 4-tuple layout of HBM_PROFILE is read in several places)
+
+
+class _aux:
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, float(flops), float(nbytes)
+
+    def __enter__(self):
+        if AUX_PROFILE is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if AUX_PROFILE is not None:
+            self.e1.record()
+            AUX_PROFILE.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
         return False
 
 
@@ -177,22 +212,26 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
               x_map is None and y_map is None and r_map is None and kseg == 0 and slab_stride == 0 and alpha == 1.0 and
               (flags & ~(F_OUT_F32 | F_RES_F32)) == 0 and (ldx in (0, K)) and (ldw in (0, K)) and
               bool(lib.ffvc_gemm_skinny_ok(tail, N, K)))
-    if REPLAY is not None and not skinny:
+    if skinny:
+        d.M = M0
+
+    def issue():
+        _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
+        if skinny:
+            _lib.check(lib.ffvc_gemm_skinny(x.data_ptr() + M0 * K * x.element_size(), w.data_ptr(), dtype_code(x.dtype),
+                                            y.data_ptr() + M0 * N * y.element_size(), dtype_code(y.dtype), _ptr(bias),
+                                            (residual.data_ptr() + M0 * N * residual.element_size()) if residual is not None else None,
+                                            dtype_code(residual.dtype) if residual is not None else 0, tail, N, K, stream_ptr()),
+                       "ffvc_gemm_skinny")
+
+    if REPLAY is not None:       # EVERY profiled launch has a replay entry (bench.attainable_leg aligns the two lists index by index)
         REPLAY.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
-                       (M, N, K, max(1, batch), split_k, int(d.flags), int(act)), d, (x, w, y, bias, residual, aux, colsum, gn_sums)))
+                       (M, N, K, max(1, batch), split_k, int(d.flags), int(act)), issue if skinny else d,
+                       (x, w, y, bias, residual, aux, colsum, gn_sums)))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if skinny:
-        d.M = M0
-        _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
-        _lib.check(lib.ffvc_gemm_skinny(x.data_ptr() + M0 * K * x.element_size(), w.data_ptr(), dtype_code(x.dtype),
-                                        y.data_ptr() + M0 * N * y.element_size(), dtype_code(y.dtype), _ptr(bias),
-                                        (residual.data_ptr() + M0 * N * residual.element_size()) if residual is not None else None,
-                                        dtype_code(residual.dtype) if residual is not None else 0, tail, N, K, stream_ptr()),
-                   "ffvc_gemm_skinny")
-    else:
-        _lib.check(lib.ffvc_gemm(byref(d), stream_ptr()), "ffvc_gemm")
+    issue()
     if PROFILE is not None:
         e1.record()
         PROFILE.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
@@ -502,22 +541,29 @@ def gemm_fp8(x8, w8, y, M, N, K, sx, sw, *, lo_dtype, bias=None, residual=None, 
         segs = ((0, M),)
         skinny = False
     base = (d.x, d.y, d.residual, d.aux)
-    for r0, rows in segs:
-        if skinny and r0:
-            _lib.check(lib.ffvc_gemm_fp8_skinny(base[0] + r0 * K, d.w, base[1] + r0 * N * y.element_size(), dtype_code(y.dtype), _ptr(bias),
-                                                (base[2] + r0 * N * residual.element_size()) if residual is not None else None,
-                                                dtype_code(residual.dtype) if residual is not None else 0, rows, N, K, sx.fmt,
-                                                sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()), "ffvc_gemm_fp8_skinny")
-            continue
-        d.M = rows
-        d.x = base[0] + r0 * K
-        d.y = base[1] + r0 * N * y.element_size()
-        if residual is not None:
-            d.residual = base[2] + r0 * N * residual.element_size()
-        if aux is not None:
-            d.aux = base[3] + r0 * ldaux * aux.element_size()
-        _lib.check(lib.ffvc_gemm_fp8(byref(d), sx.fmt, dtype_code(lo_dtype), sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()),
-                   "ffvc_gemm_fp8")
+
+    def issue():
+        for r0, rows in segs:
+            if skinny and r0:
+                _lib.check(lib.ffvc_gemm_fp8_skinny(base[0] + r0 * K, d.w, base[1] + r0 * N * y.element_size(), dtype_code(y.dtype), _ptr(bias),
+                                                    (base[2] + r0 * N * residual.element_size()) if residual is not None else None,
+                                                    dtype_code(residual.dtype) if residual is not None else 0, rows, N, K, sx.fmt,
+                                                    sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()), "ffvc_gemm_fp8_skinny")
+                continue
+            d.M = rows
+            d.x = base[0] + r0 * K
+            d.y = base[1] + r0 * N * y.element_size()
+            if residual is not None:
+                d.residual = base[2] + r0 * N * residual.element_size()
+            if aux is not None:
+                d.aux = base[3] + r0 * ldaux * aux.element_size()
+            _lib.check(lib.ffvc_gemm_fp8(byref(d), sx.fmt, dtype_code(lo_dtype), sx.inv.data_ptr(), sw.inv.data_ptr(), stream_ptr()),
+                       "ffvc_gemm_fp8")
+
+    if REPLAY is not None:
+        REPLAY.append(("conv3x3_fp8" if conv is not None else "gemm_nt_fp8", (M, N, K, 1, 1, int(flags), int(act)), issue,
+                       (x8, w8, y, bias, residual, aux, colsum, sx, sw, out_scale)))
+    issue()
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("conv3x3_fp8" if conv is not None else "gemm_nt_fp8", 2.0 * M * N * K, e0, e1, (M, N, K, 1, 1)))
@@ -617,7 +663,8 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True, f
                   int(swish), dtype_code(x.dtype), stream_ptr())
         return _unwritten(dx, f8_only), dx8
     # algorithmic bytes of the two-pass backward: statistics (dy, x) + apply (dy, x, dres, dx)
-    with _hbm("groupnorm_bwd", x.numel() * x.element_size() * (5 + (1 if dres is not None else 0))):
+    with _hbm("groupnorm_bwd", x.numel() * x.element_size() * (5 + (1 if dres is not None else 0)),
+              min_bytes=x.numel() * x.element_size() * (3 + (1 if dres is not None else 0))):
         _call("ffvc_groupnorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), _ptr(dres), dx.data_ptr(), ws.data_ptr(), B, HW, C, G, int(swish), dtype_code(x.dtype),
               stream_ptr())
@@ -775,7 +822,8 @@ def split3(x, dtype=torch.float16, weight_order=False, out=None):
         raise ValueError("split3: contiguous input expected")
     if out is None:
         out = torch.empty(*x.shape[:-1], 3 * Kd, dtype=dtype, device=x.device)
-    _call("ffvc_split3", x.data_ptr(), out.data_ptr(), dtype_code(out.dtype), rows, Kd, Kd, int(weight_order), stream_ptr())
+    with _aux("split3", 0.0, x.numel() * 4 + out.numel() * out.element_size()):
+        _call("ffvc_split3", x.data_ptr(), out.data_ptr(), dtype_code(out.dtype), rows, Kd, Kd, int(weight_order), stream_ptr())
     return out
 
 
@@ -786,8 +834,9 @@ def colsum(x, out, accumulate=False, ld=None):
         raise ValueError('colsum: out is shorter than the number of columns')
     rows, cols = x.shape[0], x.shape[-1]
     rows = x.numel() // cols
-    _call("ffvc_colsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), rows, cols, ld or cols, int(accumulate),
-          stream_ptr())
+    with _aux("colsum", 0.0, rows * cols * x.element_size()):
+        _call("ffvc_colsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), rows, cols, ld or cols, int(accumulate),
+              stream_ptr())
     return out
 
 
@@ -827,8 +876,9 @@ def vq_argmin(dot, xnorm, cnorm):
     _req_f32(dot, xnorm, cnorm)
     rows, ncodes = dot.shape
     idx = torch.empty(rows, dtype=torch.int64, device=dot.device)
-    _call("ffvc_vq_argmin", dot.data_ptr(), xnorm.data_ptr(), cnorm.data_ptr(), idx.data_ptr(), rows, ncodes, ncodes,
-          stream_ptr())
+    with _aux("vq_argmin", 0.0, dot.numel() * 4):
+        _call("ffvc_vq_argmin", dot.data_ptr(), xnorm.data_ptr(), cnorm.data_ptr(), idx.data_ptr(), rows, ncodes, ncodes,
+              stream_ptr())
     return idx
 
 
@@ -863,8 +913,9 @@ def cutouts_bwd(xr, gout, cut, cutn, patch, std):
     _need_cuda(gout)
     B, H, W, _ = xr.shape
     dxr = torch.empty_like(xr)
-    _call("ffvc_cutouts_bwd", xr.data_ptr(), gout.data_ptr(), dtype_code(gout.dtype), dxr.data_ptr(), B, H, W, cut, cutn,
-          patch, std[0], std[1], std[2], stream_ptr())
+    with _aux("cutouts_bwd", 0.0, gout.numel() * gout.element_size() + 2 * xr.numel() * 4):
+        _call("ffvc_cutouts_bwd", xr.data_ptr(), gout.data_ptr(), dtype_code(gout.dtype), dxr.data_ptr(), B, H, W, cut, cutn,
+              patch, std[0], std[1], std[2], stream_ptr())
     return dxr
 
 
@@ -982,8 +1033,9 @@ def rowsum(x, out, period, accumulate=False):
     if out.numel() < period:
         raise ValueError('rowsum: out is shorter than the period')
     cols = x.shape[-1]
-    _call("ffvc_rowsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), x.numel() // cols, cols, period,
-          int(accumulate), stream_ptr())
+    with _aux("rowsum", 0.0, x.numel() * x.element_size()):
+        _call("ffvc_rowsum", x.data_ptr(), dtype_code(x.dtype), out.data_ptr(), x.numel() // cols, cols, period,
+              int(accumulate), stream_ptr())
     return out
 
 
@@ -1021,7 +1073,8 @@ def gemm_splitk_accumulate(x, w, out, M, N, K, split_k, in_kernel=False, atomic=
         return gemm(x, w, out, M, N, K, split_k=split_k, flags=kw.pop("flags", 0) | F_ATOMIC_OUT, **kw)
     slabs = torch.empty(split_k, M, N, dtype=torch.float32, device=out.device)
     gemm(x, w, slabs, M, N, K, split_k=split_k, slab_stride=M * N, **kw)
-    _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
+    with _aux("slab_reduce", 0.0, 4.0 * M * N * (split_k + 2)):
+        _call("ffvc_slab_reduce", slabs.data_ptr(), out.data_ptr(), M * N, split_k, 1, stream_ptr())
     return out
 
 
@@ -1114,8 +1167,9 @@ def attn_small_fwd(qkv, heads, scale):
     _req(qkv.dtype if qkv.dtype in LOWP else torch.bfloat16, qkv)
     B, T, D3 = qkv.shape
     o = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
-    _call("ffvc_attn_small_fwd", qkv.data_ptr(), o.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64, float(scale),
-          stream_ptr())
+    with _aux("attn_small_fwd", 4.0 * B * heads * T * T * 64, (qkv.numel() + o.numel()) * qkv.element_size()):
+        _call("ffvc_attn_small_fwd", qkv.data_ptr(), o.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64, float(scale),
+              stream_ptr())
     return o
 
 
@@ -1125,9 +1179,10 @@ def attn_small_bwd(qkv, do, heads, scale):
         raise ValueError('attn_small_bwd: dout shape does not match qkv')
     B, T, D3 = qkv.shape
     dqkv = torch.empty_like(qkv)
-    _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
-          float(scale),
-          stream_ptr())
+    with _aux("attn_small_bwd", 10.0 * B * heads * T * T * 64, (2 * qkv.numel() + do.numel()) * qkv.element_size()):
+        _call("ffvc_attn_small_bwd", qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
+              float(scale),
+              stream_ptr())
     return dqkv
 
 
@@ -1196,7 +1251,8 @@ def attn_text_fwd(qkv, heads, scale, causal):
     _need_cuda(qkv)
     B, T, D3 = qkv.shape
     o = torch.empty(B, T, D3 // 3, dtype=torch.float32, device=qkv.device)
-    _call("ffvc_attn_text_fwd", qkv.data_ptr(), o.data_ptr(), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
+    with _aux("attn_text_fwd", 0.0, (qkv.numel() + o.numel()) * 4):      # exact-fp32 VALU attention: priced by its bytes
+        _call("ffvc_attn_text_fwd", qkv.data_ptr(), o.data_ptr(), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
     return o
 
 
@@ -1215,8 +1271,9 @@ def attn_flash_fwd(qkv, heads, scale, causal, f8=None):
         _call("ffvc_attn_flash_fwd_f8", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), o8.data_ptr(), f8.state.data_ptr(), f8.fmt,
               dtype_code(qkv.dtype), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
         return o, lse, o8
-    _call("ffvc_attn_flash_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
-          float(scale), int(bool(causal)), stream_ptr())
+    with _aux("attn_flash_fwd", 4.0 * B * heads * T * T * 64 * (0.5 if causal else 1.0), (qkv.numel() + o.numel()) * qkv.element_size()):
+        _call("ffvc_attn_flash_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64,
+              float(scale), int(bool(causal)), stream_ptr())
     return o, lse
 
 
@@ -1228,8 +1285,9 @@ def attn_flash_bwd(qkv, o, do, lse, heads, scale, causal):
         raise ValueError("attn_flash_bwd: shape mismatch")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    _call("ffvc_attn_flash_bwd", qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-          dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
+    with _aux("attn_flash_bwd", 10.0 * B * heads * T * T * 64 * (0.5 if causal else 1.0), (2 * qkv.numel() + 2 * o.numel()) * qkv.element_size()):
+        _call("ffvc_attn_flash_bwd", qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+              dqkv.data_ptr(), dtype_code(qkv.dtype), B, T, heads, 64, float(scale), int(bool(causal)), stream_ptr())
     return dqkv
 
 
@@ -1249,8 +1307,9 @@ def tokmix_fwd(xn, w1, b1, w2, b2, residual):
     if tuple(w1.shape) != (O, T) or tuple(w2.shape) != (T, O) or tuple(residual.shape) != (B, T, D):
         raise ValueError("tokmix_fwd: shape mismatch")
     y = torch.empty(B, T, D, dtype=torch.float32, device=xn.device)
-    _call("ffvc_tokmix_fwd", xn.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), residual.data_ptr(),
-          y.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
+    with _aux("tokmix_fwd", 4.0 * B * O * T * D, B * T * D * (xn.element_size() + 8)):
+        _call("ffvc_tokmix_fwd", xn.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), residual.data_ptr(),
+              y.data_ptr(), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
     return y
 
 
@@ -1283,8 +1342,9 @@ def tokmix_bwd_hidden(xn, dy, w1, b1, w2t, db1=None):
     dh = torch.empty_like(h)
     if db1 is not None and (db1.numel() != O or not db1.is_contiguous()):
         raise ValueError("tokmix_bwd_hidden: db1 must be a contiguous [O] tensor")
-    _call("ffvc_tokmix_bwd_hidden", xn.data_ptr(), dy.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), h.data_ptr(),
-          dh.data_ptr(), _ptr(db1), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
+    with _aux("tokmix_bwd_hidden", 4.0 * B * O * T * D, (2 * B * T * D + 2 * B * O * D) * xn.element_size()):
+        _call("ffvc_tokmix_bwd_hidden", xn.data_ptr(), dy.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2t.data_ptr(), h.data_ptr(),
+              dh.data_ptr(), _ptr(db1), dtype_code(xn.dtype), B, T, D, O, stream_ptr())
     return h, dh
 
 
@@ -1306,9 +1366,10 @@ def augment_fwd(pooled, pinv, ainv, cmat, erase, cutn, patch, mean, std, out_dty
     out = torch.empty(cutn * B, g * g, 3 * patch * patch, dtype=out_dtype, device=pooled.device)
     if seq and S != Ss:
         raise ValueError("augment_fwd(seq=True): source and output side must be equal")
-    _call("ffvc_augment_seq_fwd" if seq else "ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), _ptr(cj),
-          erase.data_ptr(), _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, Ss, cutn, patch, mean[0], mean[1],
-          mean[2], std[0], std[1], std[2], stream_ptr())
+    with _aux("augment_fwd", 0.0, pooled.numel() * 4 + out.numel() * out.element_size() + (noise.numel() * 4 if noise is not None else 0)):
+        _call("ffvc_augment_seq_fwd" if seq else "ffvc_augment_fwd", pooled.data_ptr(), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(), _ptr(coff), _ptr(cj),
+              erase.data_ptr(), _ptr(noise), _ptr(facs), out.data_ptr(), dtype_code(out_dtype), B, S, Ss, cutn, patch, mean[0], mean[1],
+              mean[2], std[0], std[1], std[2], stream_ptr())
     return out
 
 
@@ -1318,9 +1379,10 @@ def augment_bwd(gout, pinv, ainv, cmat, erase, B, S, cutn, patch, std, src_size=
     _need_cuda(gout)
     Ss = src_size or S
     dpooled = torch.empty(B, 3, Ss, Ss, dtype=torch.float32, device=gout.device)
-    _call("ffvc_augment_seq_bwd" if seq else "ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
-          erase.data_ptr(), _ptr(pooled), _ptr(coff), _ptr(cj), dpooled.data_ptr(), B, S, Ss, cutn, patch, std[0], std[1], std[2],
-          stream_ptr())
+    with _aux("augment_bwd", 0.0, gout.numel() * gout.element_size() + dpooled.numel() * 4 + (pooled.numel() * 4 if pooled is not None else 0)):
+        _call("ffvc_augment_seq_bwd" if seq else "ffvc_augment_bwd", gout.data_ptr(), dtype_code(gout.dtype), pinv.data_ptr(), ainv.data_ptr(), cmat.data_ptr(),
+              erase.data_ptr(), _ptr(pooled), _ptr(coff), _ptr(cj), dpooled.data_ptr(), B, S, Ss, cutn, patch, std[0], std[1], std[2],
+              stream_ptr())
     return dpooled
 
 

@@ -288,6 +288,25 @@ def flush_wgrad_groups():
         g.flush()
 
 
+def discard_wgrad_groups():
+    """Forget every queued group WITHOUT launching it.  Whatever is still queued when the gradients are about to be zeroed belongs
+    to a backward pass that never finished (an exception / OOM between add() and flush()): flushing it into the fresh bucket would
+    accumulate a stale gradient into the next step, the `_ffvc_deferred` marks would mute a gradient-ready listener, and the
+    operands (320 MB per waiting layer at cfg2) would stay pinned.  Returns the number of dropped entries."""
+    n = 0
+    for g in list(_PENDING_GROUPS):
+        pend, g.pending = g.pending, {}
+        n += len(pend)
+        for i in pend:
+            W = g.members[i]
+            W.weight._ffvc_deferred = False
+            if W.bias is not None:
+                W.bias._ffvc_deferred = False
+    del _PENDING_GROUPS[:]
+    _SIDE["cb"] = False
+    return n
+
+
 def _wgrad(dy2d, x2d, W, rows, ldy=None, bias_done=False):
     """weight.grad[N,K] += dy[rows,N]^T @ x[rows,K]; bias.grad += colsum(dy).  ldy: row stride of dy (default N).
     bias_done: the kernel that produced dy already accumulated its column sums into bias.grad."""

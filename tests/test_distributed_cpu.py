@@ -362,3 +362,82 @@ def test_sliced_buckets_and_overlapped_update_match_the_synchronous_path(wire, o
     # overlap_update: one optimizer launch per bucket (in launch order); synchronous path: one launch per step
     assert res[0][2] == (2 * 5 if overlap else 2) or (overlap and res[0][2] > 2), res[0][2]
     assert "second backward()" in res[0][3] and "weight shared" in res[0][3]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# world 4: deferred (grouped) weight gradients + the rank-agreement check with ONE permuted rank
+def _deferred_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from feed_forward_vqgan_clip_amd import distributed as hvd
+    from feed_forward_vqgan_clip_amd.arena import ParamArena
+    hvd.init(backend="gloo")
+    net = _model()
+    arena = ParamArena(net, torch.float32, allow_cpu=True)
+    opt = hvd.DistributedOptimizer(torch.optim.SGD(net.parameters(), lr=0.1), arena=arena, bucket_bytes=1024, tail_bytes=3000,
+                                   tail_bucket_bytes=512)
+    n0 = len(opt.buckets)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    idx = list(iter(hvd.DistributedSampler(8, shuffle=False)))
+    # what ops.WgradGroup does on the GPU: the weight gradients of a group of layers are written by ONE launch after the last member's
+    # backward -> autograd's own hooks for them must be ignored (`_ffvc_deferred`), the report comes from the flush, newest layer first
+    deferred = [net[0].weight, net[2].weight]
+    launch_orders = []
+    for _ in range(3):
+        opt.zero_grad()
+        for p in deferred:
+            p._ffvc_deferred = True
+        ((net(X[idx]) - Y[idx]) ** 2).mean().backward()
+        early = [b for b in opt._handles if any(i in opt.buckets[b][2] for i in (arena._index[id(p)] for p in deferred))]
+        for p in deferred:                         # the flush: marks cleared, then the reports in the order backward produces gradients
+            p._ffvc_deferred = False
+        for p in reversed(deferred):
+            opt._param_ready(p)
+        launch_orders.append(dict(opt._order))
+        opt.step()
+    order = list(range(len(opt.buckets)))
+    if rank == 2:                                  # ONE rank observed another launch order
+        order[0], order[1] = order[1], order[0]
+    try:
+        opt._retune_tail(order)
+        raised = ""
+    except RuntimeError as e:
+        raised = str(e)
+    q.put((rank, arena.params.detach().numpy().copy(), n0, len(opt.buckets), len(early), raised))
+
+
+def test_world4_deferred_weight_gradients_and_one_permuted_rank():
+    """Four ranks (gloo): the buckets that hold a deferred weight gradient go on the wire only after the flush reported it (never from
+    autograd's own hook), the replicas stay identical and equal the single-process result; the re-cut layout is rank 0's, and when ONE
+    of the four ranks observed a different launch order EVERY rank raises instead of pairing all-reduces wrongly."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deferred_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, procs, limit=240.0)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+    p0 = res[0][1]
+    for _, pr, n0, n1, early, raised in res:
+        assert (pr == p0).all()
+        assert early == 0                          # no bucket with a deferred gradient left before its flush
+        assert n1 > n0                             # the tail was re-cut after the first step
+        assert "different orders" in raised        # all four ranks, although only rank 2 was permuted
+    from feed_forward_vqgan_clip_amd.arena import ParamArena
+    net = _model()
+    arena = ParamArena(net, torch.float32, allow_cpu=True)
+    ref = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    for _ in range(3):
+        arena.zero_grad()
+        ((net(X) - Y) ** 2).mean().backward()
+        ref.step()
+    assert (torch.from_numpy(p0) - arena.params.detach()).abs().max().item() < 1e-6

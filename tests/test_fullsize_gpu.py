@@ -390,3 +390,99 @@ def test_cfg5_full_size_f16_step_matches_oracle(cuda):
     # (profiles/r02_error_budget_b4.txt): 1e-4 is NOT guaranteed here (measured 2.6e-4 at batch 4 with 3 flips of 1024, 2.9e-5 at
     # the benchmark's batch 64) — the bound below is what the f16 mapper's z error (rel-rms 9.6e-4) allows
     assert r["f16"]["flips"] <= 0.005 * r["f16"]["n"] + 1 and abs(r["f16"]["free"] - o) / o < 1e-4 + 4e-4 * r["f16"]["flips"] * 512 / r["f16"]["n"]
+
+
+# ----------------------------------------------------------------------------- gradients of the TIMED dtype at full model size vs the oracle
+def _grad_parity(cfg, mapper_fn, clip_arch, quick, Bn, cutn, seed, cdt=torch.float16, loss_scale=4096.0):
+    """The reference's step is zero_grad -> backward -> step (main.py:825-837) and 56 % of the step's FLOPs are backward: the CPU
+    oracle's mapper gradients (autograd through oracle/step.train_step_loss, fp32) against the HIP backward pass in the timed
+    dtype — same weights, prompts, augmentation draws and noise, the oracle's codes handed to the decoder (the VQ argmin is a
+    discontinuity of the reference itself), loss-scaled as the timed step is.  -> dict of metrics."""
+    from feed_forward_vqgan_clip_amd import augment as faug
+    from feed_forward_vqgan_clip_amd import ops
+    from oracle import step as ostep
+    torch.manual_seed(seed)
+    net0 = fmain.build_model(cfg, 256)
+    msd = {k: v.detach().clone() for k, v in net0.state_dict().items()}
+    vq_sd, clip_sd = fvq.random_state_dict(fvq.F16_16384, seed=seed), fclip.random_state_dict(clip_arch, seed=seed)
+    cb = vq_sd["quantize.embedding.weight"]
+    tok = fmain.synthetic_tokens(Bn, seed=seed + 2)
+    g = torch.Generator().manual_seed(seed + 6)
+    facs, noise = torch.rand(cutn * Bn, generator=g) * 0.1, torch.randn(cutn * Bn, 3, 224, 224, generator=g)
+    chain = faug.draw_chain(cutn * Bn, 224, generator=g)
+    segs = faug.to_device(faug.plan(chain, cutn * Bn, 224, sequential=True), "cuda")
+    params = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    oloss, omid = ostep.train_step_loss(mapper_fn, params, vq_sd, clip_sd, tok, cutn=cutn, cut_size=224, z_min=cb.min().item(),
+                                        z_max=cb.max().item(), facs=facs.view(-1, 1, 1, 1), noise=noise, aug_chain=chain, quick_gelu=quick)
+    ograds = dict(zip(params, torch.autograd.grad(oloss, list(params.values()))))
+    oidx = ostep.vq_indices(omid["z"].detach().movedim(1, 3), cb)
+    net = fmain.build_model(cfg, 256)
+    net.load_state_dict(msd)
+    net = net.cuda().prepare(cdt)
+    vq, perceptor = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt), fclip.CLIP(clip_sd, cdt, quick_gelu=quick)
+    opt = FusedAdam(net.parameters(), lr=cfg.lr)
+    ls = loss_scale if cdt == torch.float16 else 1.0
+    opt.loss_scale = ls
+    stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    loss, _ = stepper.forward_loss(tok.cuda(), facs=facs.cuda(), noise=noise.cuda(), aug_params=segs, force_idx=oidx.cuda())
+    opt.zero_grad()
+    (loss * ls).backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    named = dict(net.named_parameters())
+    assert set(named) == set(ograds)
+    dot = nh = no = 0.0
+    per = {}
+    for k, go in ograds.items():
+        gh = named[k].grad.detach().float().cpu().double() / ls
+        go = go.double()
+        assert torch.isfinite(gh).all(), k
+        dot += float((gh * go).sum())
+        nh += float(gh.pow(2).sum())
+        no += float(go.pow(2).sum())
+        per[k] = float((gh - go).pow(2).sum().sqrt() / go.pow(2).sum().sqrt().clamp_min(1e-30))
+    before = {k: p.detach().float().cpu().clone() for k, p in named.items()}
+    opt.step()
+    torch.cuda.synchronize()
+    agree = cnt = 0.0
+    for k, go in ograds.items():
+        d_h = named[k].detach().float().cpu() - before[k]
+        agree += float((torch.sign(d_h) == torch.sign(-go)).sum())
+        cnt += go.numel()
+    worst = max(per, key=per.get)
+    return dict(loss=float(loss), oloss=float(oloss), cosine=dot / (nh * no) ** 0.5, flat=(max(nh + no - 2 * dot, 0.0) / no) ** 0.5,
+                norm_ratio=(nh / no) ** 0.5, worst=worst, worst_rel=per[worst], median=sorted(per.values())[len(per) // 2],
+                sign_agreement=agree / cnt, per=per)
+
+
+def test_cfg2_full_size_f16_gradients_match_oracle(cuda):
+    """cfg2's models at full size (Mixer 32x1024: the grouped 16384-row weight gradients' kernels at a 512-row reduction, the 256x256
+    conv dgrads, the cutout attention backward, the loss-scaled f16 chain) — every mapper gradient against the CPU oracle's."""
+    from oracle import mappers as omap
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dim=1024, depth=32, dropout=0, cutn=2, batch_size=2, repeat=1, nb_noise=None,
+                       diversity_coef=0, clip_model="ViT-B/32", model_type="mlp_mixer", vq_image_size=16)
+    r = _grad_parity(cfg, lambda sd, f: omap.mixer_forward(sd, f, image_size=16, channels=256, depth=32), fclip.VIT_B32, True, 2, 2, 21)
+    print(f"[cfg2 f16 grads] loss hip {r['loss']:.7f} oracle {r['oloss']:.7f} | cosine {r['cosine']:.6f} flat rel-rms {r['flat']:.3e} "
+          f"norm ratio {r['norm_ratio']:.4f} | worst tensor {r['worst']} {r['worst_rel']:.3e} median {r['median']:.3e} | "
+          f"Adam step-1 sign agreement {r['sign_agreement']:.5f}")
+    assert abs(r["loss"] - r["oloss"]) / r["oloss"] < 1e-4
+    assert r["cosine"] >= 0.9995
+    assert r["worst_rel"] <= 3e-2
+    assert abs(r["norm_ratio"] - 1.0) < 1e-2
+    assert r["sign_agreement"] > 0.98
+
+
+@pytest.mark.parametrize("kind", ["cfg3", "cfg4"])
+def test_cfg3_cfg4_full_size_f16_step_matches_oracle(cuda, kind):
+    """BASELINE configs[2] / configs[3] at full model size in the dtype their bench lines time (f16), against the CPU oracle — the
+    fp32-mode comparison above pins the algorithm, this one the timed arithmetic (default augmentations, explicit draws)."""
+    cfg = fmain.Config(lr=1e-3, epochs=1, noise_dim=0, dropout=0, cutn=2, batch_size=2, repeat=1, nb_noise=None, diversity_coef=0,
+                       clip_model="ViT-B/32", **_other_cfg(kind))
+    r = _timed_dtype_vs_oracle(cfg, lambda sd, f: _oracle_mapper(kind, sd, f), fclip.VIT_B32, True, 2, 2, 31 if kind == "cfg3" else 33)
+    o = r["oracle"]
+    print(f"[{kind} f16] oracle {o:.7f} | fp32 same {abs(r['fp32']['same'] - o) / o:.2e} | f16 same {abs(r['f16']['same'] - o) / o:.2e} "
+          f"free {abs(r['f16']['free'] - o) / o:.2e} flips {r['f16']['flips']}/{r['f16']['n']} xr {r['f16']['xr']:.2e} embed {r['f16']['embed']:.2e}")
+    assert abs(r["fp32"]["same"] - o) / o < 1e-4
+    assert abs(r["f16"]["same"] - o) / o < 1e-4                      # the timed dtype, reference's codes: north_star tolerance
+    assert r["f16"]["xr"] < 3e-3 and r["f16"]["embed"] < 3e-3
+    assert r["f16"]["flips"] <= 0.005 * r["f16"]["n"] + 1 and abs(r["f16"]["free"] - o) / o < 1e-4 + 4e-4 * r["f16"]["flips"] * 512 / r["f16"]["n"]

@@ -978,3 +978,74 @@ def test_grouped_weight_gradients_in_one_launch(cuda, dt, G, M, N, rows):
     from feed_forward_vqgan_clip_amd import _lib
     with pytest.raises(_lib.FFVCError):
         K.gemm_grouped_wgrad([d[:, :200].contiguous() for d in dys[:2]], xs[:2], bucket, stride, 200, N, rows, 200, N)
+
+
+# ----------------------------------------------------------------------------- round 6: the two-workgroups-per-CU 256x128 ring kernel
+@pytest.fixture
+def gemm3_forced():
+    K.set_option("gemm3", 1)
+    yield
+    K.set_option("gemm3", 0)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,Kd", [(1024, 512, 256), (768, 384, 96), (300, 200, 64), (2048, 1024, 1056), (256, 128, 64)])
+def test_gemm3_every_epilogue_kind_matches_fp64(cuda, gemm3_forced, dt, M, N, Kd):
+    """csrc/gemm3.hip forced on (ffvc_set_option gemm3 = 1): plain 16-bit store, fp32 + fp32 residual (with and without bias),
+    GELU / QuickGELU forward (with pre-activation and with act' storage), aux-multiply dgrad with bias-gradient column sums —
+    interior and ragged tiles, odd and even numbers of 32-deep stages — against fp64 math on the same 16-bit operands."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, Kd, generator=g).to(dt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    tol = LOTOL[dt]
+    p = x.double() @ w.double().t()
+    sc = p.abs().max().item()
+    y = torch.empty(M, N, dtype=dt, device=cuda)
+    K.gemm(x, w, y, M, N, Kd, ldx=Kd, ldw=Kd)
+    assert (y.double() - p).abs().max().item() < tol * sc
+    y32 = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(x, w, y32, M, N, Kd, ldx=Kd, ldw=Kd, residual=res)
+    assert (y32.double() - (p + res.double())).abs().max().item() < 3e-5 * (sc + 4)
+    K.gemm(x, w, y32, M, N, Kd, ldx=Kd, ldw=Kd, residual=res, bias=b)
+    assert (y32.double() - (p + res.double() + b.double())).abs().max().item() < 3e-5 * (sc + 8)
+    pb = p + b.double()
+    for code, fn, dfn in ((K.ACT_GELU, lambda t: F.gelu(t), lambda t: 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * torch.pi) ** 0.5),
+                          (K.ACT_QUICKGELU, lambda t: t * torch.sigmoid(1.702 * t),
+                           lambda t: torch.sigmoid(1.702 * t) * (1 + 1.702 * t * (1 - torch.sigmoid(1.702 * t))))):
+        h, aux = torch.empty(M, N, dtype=dt, device=cuda), torch.empty(M, N, dtype=dt, device=cuda)
+        K.gemm(x, w, h, M, N, Kd, ldx=Kd, ldw=Kd, bias=b, act=code)
+        assert (h.double() - fn(pb)).abs().max().item() < tol * (sc + 4)
+        K.gemm(x, w, h, M, N, Kd, ldx=Kd, ldw=Kd, bias=b, act=code, aux=aux, ldaux=N, flags=K.F_WRITE_PREACT)
+        assert (h.double() - fn(pb)).abs().max().item() < tol * (sc + 4) and (aux.double() - pb).abs().max().item() < tol * (sc + 4)
+        K.gemm(x, w, h, M, N, Kd, ldx=Kd, ldw=Kd, bias=b, act=code, aux=aux, ldaux=N, flags=K.F_WRITE_PREACT | K.F_AUX_ACTGRAD)
+        assert (h.double() - fn(pb)).abs().max().item() < tol * (sc + 4)
+        assert (aux.double() - dfn(pb)).abs().max().item() < (2e-3 if dt == torch.float16 else 1.6e-2) * 1.2
+        d = torch.empty(M, N, dtype=dt, device=cuda)
+        cs = torch.zeros(N, dtype=torch.float32, device=cuda)
+        want = p * aux.double()
+        if K.colsum_fusable(dt, N, Kd, N, N):
+            K.gemm(x, w, d, M, N, Kd, ldx=Kd, ldw=Kd, act=code, aux=aux, ldaux=N, flags=K.F_MUL_ACT_GRAD | K.F_AUX_ACTGRAD, colsum=cs)
+            assert (cs.double() - want.sum(0)).abs().max().item() < 2e-3 * want.abs().sum(0).max().item() + 1e-3
+        else:
+            K.gemm(x, w, d, M, N, Kd, ldx=Kd, ldw=Kd, act=code, aux=aux, ldaux=N, flags=K.F_MUL_ACT_GRAD | K.F_AUX_ACTGRAD)
+        assert (d.double() - want).abs().max().item() < tol * want.abs().max().item() + 1e-6
+        K.gemm(x, w, d, M, N, Kd, ldx=Kd, ldw=Kd, act=code, aux=aux, ldaux=N, flags=K.F_MUL_ACT_GRAD)      # aux read as a pre-activation
+        assert (d.double() - p * dfn(aux.double())).abs().max().item() < 3 * tol * (p * dfn(aux.double())).abs().max().item() + 1e-6
+
+
+def test_gemm3_is_bit_identical_to_the_256x256_kernel_on_plain_launches(cuda):
+    """Same 16-bit operands, same fp32 accumulation order along K (32-deep MFMA steps in sequence): the two kernels must agree
+    exactly on a plain launch, whatever the tile."""
+    g = torch.Generator().manual_seed(6)
+    M, N, Kd = 4096, 1024, 512
+    x = torch.randn(M, Kd, generator=g).half().cuda()
+    w = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).half().cuda()
+    y0, y1 = torch.empty(M, N, dtype=torch.float16, device=cuda), torch.empty(M, N, dtype=torch.float16, device=cuda)
+    K.set_option("gemm3", -1)
+    K.gemm(x, w, y0, M, N, Kd, ldx=Kd, ldw=Kd)
+    K.set_option("gemm3", 1)
+    K.gemm(x, w, y1, M, N, Kd, ldx=Kd, ldw=Kd)
+    K.set_option("gemm3", 0)
+    assert torch.equal(y0, y1)
