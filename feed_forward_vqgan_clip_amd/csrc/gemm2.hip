@@ -32,6 +32,9 @@ int ffvc_gemm2_launch_tn(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, co
 int ffvc_gemm2_launch_tt(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, const uint16_t* zero, int cfg);
 // gemm3.hip: the 256x128 ring kernel with two workgroups per CU (epilogue-heavy K-major x K-major launches)
 int ffvc_gemm3_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok, int mode);
+// conv3.hip: the software-pipelined row-tile convolution, two workgroups per CU
+int ffvc_conv3_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok);
+int g_opt_conv_row3 = -100; // ffvc_set_option("conv_row3", v): 0 off | 1 on; unset -> FFVC_CONV_ROW3 (default 1)
 int g_opt_gemm3 = -100;     // ffvc_set_option("gemm3", v): -1 never | 0 heuristic | 1 every eligible launch; unset -> FFVC_GEMM3 (default 0)
 
 namespace {
@@ -646,7 +649,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       static int g3_env = -100;
       if (g3_env == -100) {
         const char* e = getenv("FFVC_GEMM3");
-        g3_env = e ? atoi(e) : 0;
+        g3_env = e ? atoi(e) : -1;   // default OFF: measured slower than the 256x256 kernel on every cfg2 shape (profiles/r06_gemm3_ab.txt)
       }
       const int r3 = ffvc_gemm3_try(d, st, vec_ok, g_opt_gemm3 != -100 ? g_opt_gemm3 : g3_env);
       if (r3 != 0) return r3;
@@ -660,7 +663,17 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
                          d.split_k <= 1 && (d.N % 128) == 0 && (d.M % 256) == 0 && d.act == FFVC_ACT_NONE &&
                          !(d.flags & (FFVC_F_MUL_ACT_GRAD | FFVC_F_WRITE_PREACT | FFVC_F_COLSUM));   // its epilogue class is GN-only
     const bool fills = (int64_t)(d.M / 256) * (d.N / 128) >= 256;
-    if (geom_ok && (env_row == 2 || (env_row == 1 && fills && cfg != 512))) {
+    // round 6: the pipelined row-tile kernel (conv3.hip) also beats the generic 256x256 implicit-GEMM tile on the 256-wide outputs
+    // (two column tiles per pixel tile; 128^2 256->256 1054 -> 1149 TFLOP/s, 64^2 1118 -> 1198; the 512-wide ones lose 5 %:
+    // profiles/r06_conv3_ab.txt), so with it the row tile takes every filling launch of up to 256 output channels
+    static int row3_env = -100;
+    if (row3_env == -100) {
+      const char* e = getenv("FFVC_CONV_ROW3");
+      row3_env = e ? atoi(e) : 1;
+    }
+    const int row3 = g_opt_conv_row3 != -100 ? g_opt_conv_row3 : row3_env;
+    const bool wide_ok = row3 > 0 && d.N <= 256 && (d.conv_Cin % 64) == 0 && d.in_dtype != FFVC_F32 && vec_ok == 2;
+    if (geom_ok && (env_row == 2 || (env_row == 1 && fills && (cfg != 512 || wide_ok)))) {
       const int tiles_n = d.N / 128, n_tiles = (d.M / 256) * tiles_n;
       constexpr int lds = 264 * 128 + 128 * 128 + 4 * 4096;
       static bool attr = false;
@@ -675,6 +688,12 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
         attr = true;
       }
       const bool buf = use_buf && g8_offsets_ok<FFVC_OP_CONV3X3>(d);
+      {
+        if (row3 > 0 && buf) {       // round 6: the pipelined kernel (conv3.hip) takes every launch whose channels come in blocks of 64
+          const int r3 = ffvc_conv3_try(d, st, vec_ok);
+          if (r3 != 0) return r3;
+        }
+      }
       // epilogue class: forward convolutions accumulate the next GroupNorm's moments, dgrad convolutions do not -> lean
       const bool gnv = (d.flags & FFVC_F_GN_SUMS) != 0;
       constexpr int EG = ffvc_gemm_detail::EPI_GN, EL = ffvc_gemm_detail::EPI_LEAN;
@@ -800,6 +819,10 @@ extern "C" int ffvc_set_option(const char* name, int value) {
   if (!name) return FFVC_E_BADARG;
   if (!strcmp(name, "gemm8")) {
     g_force_gemm8 = value;
+    return 0;
+  }
+  if (!strcmp(name, "conv_row3")) {
+    g_opt_conv_row3 = value;
     return 0;
   }
   if (!strcmp(name, "gemm3")) {

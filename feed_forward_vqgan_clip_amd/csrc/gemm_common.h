@@ -601,95 +601,115 @@ __device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f3
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[q][j] = 0.f;
   constexpr bool PRE = (EPI & (EPI_K_MULAUX | EPI_O_F32R)) != 0;        // kinds with exactly one streamed side input
-  constexpr int NIT = 2 * MT * 2;                                       // (b, p) groups of 16 rows x 32 columns
-  auto rowof = [&](int it, bool& mok, int64_t& yrow, int64_t& rrow, int64_t& arow) {
-    const int b = it >> 1;
-    const int m = m0 + wm * (32 * MT) + 16 * b + l15;
-    mok = m < p.M;
-    const int mm = mok ? m : 0;
-    yrow = ybz + (p.y_mi ? (int64_t)(mm / p.y_mi) * p.y_so + (int64_t)(mm % p.y_mi) * p.y_sm : (int64_t)mm * p.y_sm);
-    rrow = rbz + (p.r_mi ? (int64_t)(mm / p.r_mi) * p.r_so + (int64_t)(mm % p.r_mi) * p.r_sm : (int64_t)mm * p.r_sm);
-    arow = abz + (int64_t)mm * p.ldaux;
+  constexpr bool UNIT_ALPHA = (EPI & EPI_K_ANY) != 0;                   // the activation kinds are launched with alpha == 1 only
+  // Row offsets once per 16-row block (not per 8-column group): with the plain row maps (y_mi == r_mi == 0, every launch of the
+  // step) block b is block 0 plus b * 16 rows — one 64-bit add instead of three 64-bit multiplies
+  const bool plain_maps = p.y_mi == 0 && p.r_mi == 0;                   // wave-uniform
+  const int mrow0 = m0 + wm * (32 * MT) + l15;
+  const int64_t y_first = ybz + (int64_t)mrow0 * p.y_sm, r_first = rbz + (int64_t)mrow0 * p.r_sm, a_first = abz + (int64_t)mrow0 * p.ldaux;
+  const int64_t y_step = 16 * (int64_t)p.y_sm, r_step = 16 * (int64_t)p.r_sm, a_step = 16 * (int64_t)p.ldaux;
+  struct RowOff {
+    int64_t y, r, a;
+    bool ok;
   };
-  auto colof = [&](int it) { return n0 + wn * 64 + 32 * (it & 1) + cofs; };
-  auto side = [&](int it) -> f32x8 {
+  auto rows_of = [&](int b) -> RowOff {
+    RowOff o;
+    const int m = mrow0 + 16 * b;
+    o.ok = m < p.M;
+    if (plain_maps) {
+      o.y = y_first + b * y_step;          // rows beyond M are never dereferenced (o.ok guards every access)
+      o.r = r_first + b * r_step;
+    } else {
+      const int mm = o.ok ? m : 0;
+      o.y = ybz + (p.y_mi ? (int64_t)(mm / p.y_mi) * p.y_so + (int64_t)(mm % p.y_mi) * p.y_sm : (int64_t)mm * p.y_sm);
+      o.r = rbz + (p.r_mi ? (int64_t)(mm / p.r_mi) * p.r_so + (int64_t)(mm % p.r_mi) * p.r_sm : (int64_t)mm * p.r_sm);
+    }
+    o.a = a_first + b * a_step;
+    return o;
+  };
+  const int ncol0 = n0 + wn * 64 + cofs;
+  auto side = [&](const RowOff& ro, int pp) -> f32x8 {
     f32x8 r;
-    bool mok;
-    int64_t yrow, rrow, arow;
-    rowof(it, mok, yrow, rrow, arow);
-    const int n = colof(it);
-    if (mok && n < p.N) {
-      if constexpr ((EPI & EPI_K_MULAUX) != 0) r = load8((const T*)p.aux + arow + n);
-      else r = load8((const float*)p.residual + rrow + n);
+    const int n = ncol0 + 32 * pp;
+    if (ro.ok && n < p.N) {
+      if constexpr ((EPI & EPI_K_MULAUX) != 0) r = load8((const T*)p.aux + ro.a + n);
+      else r = load8((const float*)p.residual + ro.r + n);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) r.v[j] = 0.f;
     }
     return r;
   };
+  RowOff rcur = rows_of(0), rnxt = rcur;
   f32x8 pre_cur, pre_nxt;
-  if constexpr (PRE) pre_cur = side(0);
+  if constexpr (PRE) pre_cur = side(rcur, 0);
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int b = it >> 1, pp = it & 1;
-    if constexpr (PRE) {
-      if (it + 1 < NIT) pre_nxt = side(it + 1);
-    }
-    bool mok;
-    int64_t yrow, rrow, arow;
-    rowof(it, mok, yrow, rrow, arow);
-    const int n = colof(it);
+  for (int b = 0; b < 2 * MT; ++b) {
+    if (b + 1 < 2 * MT) rnxt = rows_of(b + 1);
     float bias_m = 0.0f;
-    if constexpr ((EPI & EPI_K_ANY) == 0)
-      if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(m0 + wm * (32 * MT) + 16 * b + l15, p.M - 1)];
-    f32x8 v;
+    if constexpr ((EPI & (EPI_K_ANY | EPI_O_T | EPI_O_F32R | EPI_O_F32)) == 0)
+      if (p.bias && (flags & FFVC_F_BIAS_ALONG_M)) bias_m = p.bias[min(mrow0 + 16 * b, p.M - 1)];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      // bias along M is a per-row constant: it may be added before the exchange (the row does not change, only the columns)
-      const float x0 = acc[2 * pp][b][e] * p.alpha + bias_m, x1 = acc[2 * pp + 1][b][e] * p.alpha + bias_m;
-      const u32x2_t s = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
-      v.v[e] = __uint_as_float(s[0]);
-      v.v[4 + e] = __uint_as_float(s[1]);
+    for (int pp = 0; pp < 2; ++pp) {
+      if constexpr (PRE) {
+        if (pp == 0) pre_nxt = side(rcur, 1);
+        else if (b + 1 < 2 * MT) pre_nxt = side(rnxt, 0);
+      }
+      const int n = ncol0 + 32 * pp;
+      f32x8 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // bias along M is a per-row constant: it may be added before the exchange (the row does not change, only the columns)
+        float x0 = acc[2 * pp][b][e], x1 = acc[2 * pp + 1][b][e];
+        if constexpr (!UNIT_ALPHA) {
+          x0 = x0 * p.alpha + bias_m;
+          x1 = x1 * p.alpha + bias_m;
+        }
+        const u32x2_t s = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+        v.v[e] = __uint_as_float(s[0]);
+        v.v[4 + e] = __uint_as_float(s[1]);
+      }
+      if (rcur.ok && n < p.N) {
+        if constexpr (PRE) epilogue_oct_pre<T, EPI>(p, v, n, rcur.y, pre_cur);
+        else epilogue_oct<T, EPI>(p, v, n, rcur.y, rcur.r, rcur.a, flags);
+        if constexpr ((EPI & EPI_O_F8) != 0) {
+          constexpr float LIM = (EPI & EPI_O_F8E4) ? 448.0f : 57344.0f;
+          float q[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f8_amax = fmaxf(f8_amax, fabsf(v.v[j]));
+            const float sq = v.v[j] * f8_scale;
+            q[j] = sq != sq ? sq : fminf(fmaxf(sq, -LIM), LIM);
+          }
+          int lo = 0, hi = 0;
+          if constexpr ((EPI & EPI_O_F8E4) != 0) {
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+          } else {
+            lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], lo, false);
+            lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], hi, false);
+            hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], hi, true);
+          }
+          *(u32x2_t*)((unsigned char*)p.y + rcur.y + n) = u32x2_t{(uint32_t)lo, (uint32_t)hi};
+        }
+        if (gn) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            gs1[pp][j >> 2] += v.v[j];
+            gs2[pp][j >> 2] += v.v[j] * v.v[j];
+          }
+        }
+        if (cs_on) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[pp][j] += v.v[j];
+        }
+      }
+      if constexpr (PRE) pre_cur = pre_nxt;
     }
-    if (mok && n < p.N) {
-      if constexpr (PRE) epilogue_oct_pre<T, EPI>(p, v, n, yrow, pre_cur);
-      else epilogue_oct<T, EPI>(p, v, n, yrow, rrow, arow, flags);
-      if constexpr ((EPI & EPI_O_F8) != 0) {
-        constexpr float LIM = (EPI & EPI_O_F8E4) ? 448.0f : 57344.0f;
-        float q[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f8_amax = fmaxf(f8_amax, fabsf(v.v[j]));
-          const float s = v.v[j] * f8_scale;
-          q[j] = s != s ? s : fminf(fmaxf(s, -LIM), LIM);
-        }
-        int lo = 0, hi = 0;
-        if constexpr ((EPI & EPI_O_F8E4) != 0) {
-          lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], lo, false);
-          lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
-          hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], hi, false);
-          hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
-        } else {
-          lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], lo, false);
-          lo = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], lo, true);
-          hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], hi, false);
-          hi = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], hi, true);
-        }
-        *(u32x2_t*)((unsigned char*)p.y + yrow + n) = u32x2_t{(uint32_t)lo, (uint32_t)hi};
-      }
-      if (gn) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          gs1[pp][j >> 2] += v.v[j];
-          gs2[pp][j >> 2] += v.v[j] * v.v[j];
-        }
-      }
-      if (cs_on) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cs[pp][j] += v.v[j];
-      }
-    }
-    if constexpr (PRE) pre_cur = pre_nxt;
+    rcur = rnxt;
   }
   if constexpr ((EPI & EPI_O_F8) != 0) {
 #pragma unroll
@@ -733,19 +753,26 @@ __device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f3
   }
 }
 
-// The epilogue the 16x16x32 kernels use: register exchange (default) or the LDS pads of rounds 1-5 (-DFFVC_EPI_PERM=0, A/B builds).
+// Which epilogue the 16x16x32 kernels use (measured, profiles/r06_epilogue_ab.txt): the register exchange wins on the convolution
+// kernels (+2.5-3 % isolated on every decoder level: plain store + GroupNorm moments, and no pads to alias), the LDS pads stay on the
+// K-major x K-major GEMMs (the exchange is faster on the forward activation kinds and the fp32 residual projections, slower on the
+// aux-multiply kinds, and the step as a whole was 0.6 ms slower with it).  -DFFVC_EPI_PERM=0: pads everywhere (rounds 1-5);
+// -DFFVC_EPI_PERM_NT=1: exchange everywhere (A/B builds).
 #ifndef FFVC_EPI_PERM
 #define FFVC_EPI_PERM 1
 #endif
-template <typename T, int MT, int EPI = EPI_ALL>
+#ifndef FFVC_EPI_PERM_NT
+#define FFVC_EPI_PERM_NT 0
+#endif
+template <typename T, int MT, int EPI = EPI_ALL, bool PERM = (FFVC_EPI_PERM != 0)>
 __device__ __forceinline__ void gemm_epilogue_out16(const ffvc_gemm_desc& p, f32x4_t (&acc)[4][2 * MT], int m0, int n0, int wm,
                                                     int wn, int lane, int zo, int zi, unsigned char* pad, int zs = -1) {
-#if FFVC_EPI_PERM
-  (void)pad;
-  gemm_epilogue_perm16<T, MT, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, zs);
-#else
-  gemm_epilogue_rows16<T, MT, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, pad, zs);
-#endif
+  if constexpr (PERM) {
+    (void)pad;
+    gemm_epilogue_perm16<T, MT, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, zs);
+  } else {
+    gemm_epilogue_rows16<T, MT, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, pad, zs);
+  }
 }
 
 }  // namespace ffvc_gemm_detail

@@ -54,19 +54,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XT* __restrict__ x, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float f8s = y8 ? f8_state[0] : 0.0f;
   float f8m = 0.0f;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const XT* xr = x + row * dim;
+  // Round 6: software-pipelined over the rows of a wave.  One wave per row with everything in lock step made the launch a sequence of
+  // chip-wide phases — load burst, two dependent wave reductions, store burst — with HBM idle in between (32 us for 100 MB = 3.1 TB/s,
+  // profiles/r05_kernel_trace_bench_cfg2.txt).  Now a wave owns several rows (the launcher caps the grid) and requests row i + 1
+  // before it reduces and stores row i: the next row's loads are in flight under the current row's arithmetic and stores.
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  float vn[LN_MAXE];
+  auto fetch = [&](int64_t r) {
+    const XT* xr = x + r * dim;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = (k * 64 + lane) * VEC;
+      if (idx < dim) ld_vec<VEC>(xr + idx, &vn[k * VEC]);
+    }
+  };
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
     float v[LN_MAXE];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int idx = (k * 64 + lane) * VEC;
       if (idx < dim) {
-        ld_vec<VEC>(xr + idx, &v[k * VEC]);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) s += v[k * VEC + j];
+        for (int j = 0; j < VEC; ++j) {
+          v[k * VEC + j] = vn[k * VEC + j];
+          s += v[k * VEC + j];
+        }
       }
     }
+    if (row + stride < rows) fetch(row + stride);
     const float mu = wave_sum(s) / dim;
     float q = 0.f;
 #pragma unroll
@@ -1056,6 +1074,20 @@ inline int grid_rows(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
+// LayerNorm forward: the kernel can pipeline several rows per wave (FFVC_LN_FWD_GRID = workgroups of 4 waves).  Measured (round 6,
+// profiles/r06_ln_fwd.txt, 16384 x 1024 fp32 -> f16): 24.6 us with one row per wave (4096 workgroups), 23.7 / 25.9 / 27.1 / 44.9 us at
+// 2048 / 1024 / 512 / 256, and the step 0.8 ms SLOWER at 1024 than at 4096 — at ~4 TB/s the kernel is not waiting on its own phases,
+// so the default stays one row per wave.
+inline int grid_rows_fwd(int64_t rows) {
+  static int cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("FFVC_LN_FWD_GRID");
+    cap = e ? atoi(e) : 4096;
+    if (cap < 1) cap = 1;
+  }
+  int64_t g = (rows + 3) / 4;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
 
 }  // namespace
 
@@ -1066,7 +1098,7 @@ extern "C" int ffvc_layernorm_fwd(const void* x, int x_dtype, const float* gamma
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_layernorm_fwd: dim=%d unsupported (max %d)", dim,
                  64 * LN_MAXE);
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_rows(rows);
+  const int grid = grid_rows_fwd(rows);
   const bool v4 = (dim % 4) == 0;
   DISPATCH_DT(x_dtype, XT, DISPATCH_DT(y_dtype, YT, {
                 if (v4)
@@ -1092,7 +1124,7 @@ extern "C" int ffvc_layernorm_fwd_f8(const void* x, int x_dtype, const float* ga
   FFVC_CHECK_ARG(f8_fmt == 0 || f8_fmt == 1, "ffvc_layernorm_fwd_f8: f8_fmt must be 0 (e4m3) or 1 (e5m2)");
   FFVC_CHECK_ARG(((uintptr_t)y8 % 4) == 0, "ffvc_layernorm_fwd_f8: misaligned y8");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_rows(rows);
+  const int grid = grid_rows_fwd(rows);
   DISPATCH_DT(x_dtype, XT, {
     if (y_dtype == FFVC_F16)
       hipLaunchKernelGGL((ln_fwd_kernel<4, XT, f16_t>), dim3(grid), dim3(256), 0, st, (const XT*)x, gamma, beta, (f16_t*)y, mean, rstd, rows,

@@ -985,7 +985,7 @@ def test_grouped_weight_gradients_in_one_launch(cuda, dt, G, M, N, rows):
 def gemm3_forced():
     K.set_option("gemm3", 1)
     yield
-    K.set_option("gemm3", 0)
+    K.set_option("gemm3", -100)       # back to "unset": FFVC_GEMM3 (default: off)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -1047,5 +1047,5 @@ def test_gemm3_is_bit_identical_to_the_256x256_kernel_on_plain_launches(cuda):
     K.gemm(x, w, y0, M, N, Kd, ldx=Kd, ldw=Kd)
     K.set_option("gemm3", 1)
     K.gemm(x, w, y1, M, N, Kd, ldx=Kd, ldw=Kd)
-    K.set_option("gemm3", 0)
+    K.set_option("gemm3", -100)       # back to "unset": FFVC_GEMM3 (default: off)
     assert torch.equal(y0, y1)

@@ -64,7 +64,7 @@ def main():
                 us = timeit(fn)
                 cells.append(f"g3={mode:2d}: {us:7.1f} us {2.0 * M * N * Kd / us / 1e6:7.1f} TF")
             try:
-                K.set_option("gemm3", 0)
+                K.set_option("gemm3", -100)
             except Exception:
                 pass
             print(f"{M:6d}x{N:5d}x{Kd:5d} {kind:11s} | " + " | ".join(cells), flush=True)
