@@ -26,6 +26,7 @@ F_ACCUM_OUT = 256
 F_GN_SUMS = 512
 F_COLSUM = 1024
 F_SPLITK_INKERNEL = 4096
+F_GNB_SUMS = 8192
 F_AUX_ACTGRAD = 2048
 
 
@@ -92,6 +93,13 @@ class GemmDesc(Structure):
         ("grp_n", c_int32),
         ("grp_xoff", c_int64 * 8),
         ("grp_woff", c_int64 * 8),
+        ("gnb_x", c_void_p),
+        ("gnb_mean", c_void_p),
+        ("gnb_rstd", c_void_p),
+        ("gnb_gamma", c_void_p),
+        ("gnb_beta", c_void_p),
+        ("gnb_sums", c_void_p),
+        ("gnb_swish", c_int32),
     ]
 
 
@@ -101,6 +109,7 @@ _lib = None
 # include/ffvc.h appears here and is exported by the shared object.
 _SIGNATURES = {
     "ffvc_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ffvc_gemm_gnb_probe": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ffvc_actgrad_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "ffvc_gemm_fp8": (c_int, [POINTER(GemmDesc), c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ffvc_fp8_quant": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
@@ -154,6 +163,8 @@ _SIGNATURES = {
                                         c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "ffvc_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ffvc_groupnorm_bwd_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ffvc_softmax_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_int, c_int,
                                  c_void_p]),
     "ffvc_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p]),

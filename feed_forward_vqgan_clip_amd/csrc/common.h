@@ -161,6 +161,30 @@ __device__ __forceinline__ f32x8 load8(const f16_t* p) {
   }
   return r;
 }
+// the same conversions on a 16-byte chunk that is already in registers
+template <typename T>
+__device__ __forceinline__ f32x8 unpack8(const u32x4_t& u);
+template <>
+__device__ __forceinline__ f32x8 unpack8<uint16_t>(const u32x4_t& u) {
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __uint_as_float(u[i] << 16);
+    r.v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+  }
+  return r;
+}
+template <>
+__device__ __forceinline__ f32x8 unpack8<f16_t>(const u32x4_t& u) {
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32pair_t a = unpack_f16x2(u[i]);
+    r.v[2 * i] = a[0];
+    r.v[2 * i + 1] = a[1];
+  }
+  return r;
+}
 __device__ __forceinline__ void store8(f16_t* p, const f32x8& r) {
   u32x4_t u;
 #pragma unroll

@@ -75,9 +75,11 @@ __global__ __launch_bounds__(256, 2) void conv_row3_kernel(const ffvc_gemm_desc 
     const int pc = wid + 4 * j;
     if (pc >= 17) return;                                                // wave-uniform
     if ((EXP & 1) && in_loop) return;
-    const int iy = oy0 + (colpart[j] & 3) + kh - 1;
-    const bool ok = colpart[j] >= 0 && (unsigned)iy < (unsigned)H;
-    const uint32_t off = (uint32_t)((colpart[j] & ~3) + (iy >> ups) * wincin) * 2u;
+    int cp = colpart[j];
+    asm volatile("" : "+v"(cp));          // opaque: keeps the compiler from hoisting the two unpacked halves out of the K loop (10 registers)
+    const int iy = oy0 + (cp & 3) + kh - 1;
+    const bool ok = cp >= 0 && (unsigned)iy < (unsigned)H;
+    const uint32_t off = (uint32_t)((cp & ~3) + (iy >> ups) * wincin) * 2u;
     dma16bs(rsx, ok ? off : DMA_OOB, (uint32_t)ci0 * 2u, xbuf + pc * 1024);
   };
   // ---- filter DMA: 8 pieces of 16 rows x 64 B per stage, two per wave
@@ -240,7 +242,11 @@ __global__ __launch_bounds__(256, 2) void conv_row3_kernel(const ffvc_gemm_desc 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // zero-fill pieces of the stages beyond the reduction must not outlive the workgroup
-  ffvc_gemm_detail::gemm_epilogue_perm16<L, 4, EPI>(p, acc, m0, n0, wm, wn, lane, 0, 0, 0);
+  // the epilogue's per-lane addressing starts from an OPAQUE copy of the lane id: otherwise the compiler computes it (row / column
+  // offsets, GroupNorm constants) in front of the K loop, keeps it alive through the loop and spills loop state instead
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  ffvc_gemm_detail::gemm_epilogue_perm16<L, 4, EPI>(p, acc, m0, n0, wm, wn, lane_e, 0, 0, 0);
 }
 
 template <typename L, int EPI>
@@ -286,12 +292,32 @@ int c3_launch(const ffvc_gemm_desc& d, hipStream_t st) {
 
 // The caller (gemm2.hip) has checked the row-tile geometry (W in {64, 128, 256 k}, H W % 256 == 0, N % 128 == 0, M % 256 == 0,
 // batch 1, no split-K, no activation).  0 = not taken.
+extern int g_gnb_probe;      // gemm.hip: ffvc_gemm_gnb_probe is asking whether the launch would be taken (nothing is launched)
+
 int ffvc_conv3_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   using namespace ffvc_gemm_detail;
   if (vec_ok != 2 || d.in_dtype == FFVC_F32 || (d.conv_Cin % 64) != 0 || d.alpha != 1.0f) return 0;
   if (d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_BIAS_ALONG_M | FFVC_F_OUT_F32)) return 0;
   if (!g8_offsets_ok<FFVC_OP_CONV3X3>(d)) return 0;
   const bool gnv = (d.flags & FFVC_F_GN_SUMS) != 0;
+  if (d.flags & FFVC_F_GNB_SUMS) {
+    // backward statistics of the GroupNorm node whose output gradient this dgrad stores: x is read through y's row offsets
+    const bool ok = !gnv && d.gnb_x && d.gnb_mean && d.gnb_rstd && d.gnb_gamma && d.gnb_beta && d.gnb_sums && d.gn_hw > 0 &&
+                    (d.gn_hw % 256) == 0 && d.gn_cpg >= 4 && (d.gn_cpg % 4) == 0 && (d.N % d.gn_cpg) == 0 && (d.M % d.gn_hw) == 0 &&
+                    d.y_mi == 0 && d.y_sm == d.N && d.batch == 1 && ((uintptr_t)d.gnb_x % 16) == 0;
+    if (!ok) return 0;
+    if (g_gnb_probe) return 3;
+    if (!d.residual) {         // a dgrad: plain 16-bit store, none of the generic epilogue's flag tests
+      if (d.in_dtype == FFVC_F16) return c3_launch<f16_t, EPI_LEAN | EPI_O_T | EPI_GNB>(d, st);
+      return c3_launch<uint16_t, EPI_LEAN | EPI_O_T | EPI_GNB>(d, st);
+    }
+    if (d.in_dtype == FFVC_F16) return c3_launch<f16_t, EPI_LEAN | EPI_GNB>(d, st);
+    return c3_launch<uint16_t, EPI_LEAN | EPI_GNB>(d, st);
+  }
+  if (!gnv && !d.residual) {   // dgrad convolutions without a GroupNorm in front (upsample levels, conv_in): the straight store
+    if (d.in_dtype == FFVC_F16) return c3_launch<f16_t, EPI_LEAN | EPI_O_T>(d, st);
+    return c3_launch<uint16_t, EPI_LEAN | EPI_O_T>(d, st);
+  }
   if (d.in_dtype == FFVC_F16) return gnv ? c3_launch<f16_t, EPI_GN>(d, st) : c3_launch<f16_t, EPI_LEAN>(d, st);
   return gnv ? c3_launch<uint16_t, EPI_GN>(d, st) : c3_launch<uint16_t, EPI_LEAN>(d, st);
 }

@@ -484,6 +484,16 @@ extern "C" int ffvc_actgrad_inplace(void* aux, int dtype, int act, int M, int N,
   return 0;
 }
 
+int g_gnb_probe = 0;
+
+extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream);
+extern "C" int ffvc_gemm_gnb_probe(const ffvc_gemm_desc* dp, void* stream) {
+  g_gnb_probe = 1;
+  const int rc = ffvc_gemm(dp, stream);
+  g_gnb_probe = 0;
+  return rc == 3 ? 1 : 0;
+}
+
 extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   FFVC_CHECK_ARG(dp != nullptr, "ffvc_gemm: null descriptor");
   ffvc_gemm_desc d = *dp;
@@ -573,12 +583,17 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   };
   {
     const int r2 = ffvc_gemm2_try(d, st, vec_ok);   // LDS-DMA fast path (bf16, 16-byte aligned operands)
+    if (r2 == 3) return 3;                          // ffvc_gemm_gnb_probe: the launch WOULD be taken by a kernel with FFVC_F_GNB_SUMS
     if (r2 == 2) return 0;                          // specialised epilogue: aux already holds act'(pre)
     if (r2 == 1) return fixup();
     if (r2 < 0) return r2;
   }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_SPLITK_INKERNEL) || d.split_k == 1,
                  "ffvc_gemm: FFVC_F_SPLITK_INKERNEL: this shape / alignment does not take an LDS-DMA kernel that implements it");
+  if (d.flags & FFVC_F_GNB_SUMS) {
+    ffvc_set_error("ffvc_gemm: FFVC_F_GNB_SUMS: this launch does not take the pipelined row-tile convolution (ask ffvc_gemm_gnb_probe first)");
+    return FFVC_E_UNSUPPORTED;
+  }
   if (d.grp_n != 0) {
     ffvc_set_error("ffvc_gemm: grouped launch: this shape / alignment does not take the 256x256 LDS-DMA weight-gradient kernel "
                    "(M=%d N=%d K=%d)", d.M, d.N, d.K);

@@ -516,6 +516,7 @@ inline bool m8(int64_t v) { return (v % 8) == 0; }
 // 1 = enqueued here, 0 = shape not eligible (caller falls back to gemm.hip), < 0 = launch error.
 int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if ((d.in_dtype != FFVC_BF16 && d.in_dtype != FFVC_F16) || (d.flags & FFVC_F_TR_SAFE)) return 0;
+  if ((d.flags & FFVC_F_GNB_SUMS) && !(d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR && d.N > 16)) return 0;   // conv3 only
   if (d.x_mode == FFVC_OP_CONV3X3 && d.w_mode == FFVC_OP_KMAJOR && d.N <= 16) {
     // a 3x3 conv with <= 16 output channels (conv_out): the narrow-N row-tile kernel
     static int n16 = -1;
@@ -693,6 +694,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
           const int r3 = ffvc_conv3_try(d, st, vec_ok);
           if (r3 != 0) return r3;
         }
+        if (d.flags & FFVC_F_GNB_SUMS) return 0;     // only conv3 folds the GroupNorm-backward statistics: never launch a kernel that would skip them
       }
       // epilogue class: forward convolutions accumulate the next GroupNorm's moments, dgrad convolutions do not -> lean
       const bool gnv = (d.flags & FFVC_F_GN_SUMS) != 0;
@@ -756,6 +758,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       }
       return 1;
     }
+    if (d.flags & FFVC_F_GNB_SUMS) return 0;
     return ffvc_gemm2_launch_conv(d, st, vec_ok, zero, cfg);
   }
   if (d.x_mode == FFVC_OP_TRANS && d.w_mode == FFVC_OP_TRANS) {

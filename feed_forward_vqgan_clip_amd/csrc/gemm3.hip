@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const ffvc_gemm_desc p, i
     step(t, s1, s2, P0{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill pieces of the stages beyond the reduction must not outlive the workgroup
-  ffvc_gemm_detail::gemm_epilogue_perm16<L, 4, EPI>(p, acc, m0, n0, wm, wn, lane, zo, zi, 0);
+  int lane_e = lane;                                   // (opaque copy: keeps the epilogue's addressing out of the K loop's live ranges)
+  asm volatile("" : "+v"(lane_e));
+  ffvc_gemm_detail::gemm_epilogue_perm16<L, 4, EPI>(p, acc, m0, n0, wm, wn, lane_e, zo, zi, 0);
 }
 
 template <typename L, int EPI>

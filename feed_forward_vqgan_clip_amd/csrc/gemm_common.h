@@ -240,6 +240,8 @@ constexpr int EPI_O_T = 512, EPI_O_F32R = 1024, EPI_O_F32 = 2048;
 // fp8 output of the MLP kinds (frozen towers, ffvc_gemm_fp8): y gets e4m3 / e5m2 bytes scaled by p.y8_state[0]; the running amax goes
 // to p.y8_state[1] (desc fields y8_state / y8_fmt)
 constexpr int EPI_O_F8E4 = 4096, EPI_O_F8E5 = 8192, EPI_O_F8 = EPI_O_F8E4 | EPI_O_F8E5;
+// GroupNorm-BACKWARD statistics of the node whose output gradient this launch stores (FFVC_F_GNB_SUMS, register-exchange epilogue only)
+constexpr int EPI_GNB = 16384;
 
 template <typename T, int EPI = EPI_ALL>
 __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,
@@ -600,6 +602,7 @@ __device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f3
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[q][j] = 0.f;
+  constexpr bool GNB = (EPI & EPI_GNB) != 0;
   constexpr bool PRE = (EPI & (EPI_K_MULAUX | EPI_O_F32R)) != 0;        // kinds with exactly one streamed side input
   constexpr bool UNIT_ALPHA = (EPI & EPI_K_ANY) != 0;                   // the activation kinds are launched with alpha == 1 only
   // Row offsets once per 16-row block (not per 8-column group): with the plain row maps (y_mi == r_mi == 0, every launch of the
@@ -640,6 +643,49 @@ __device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f3
     }
     return r;
   };
+  // GNB: per-lane constants of its 16 columns — gamma / beta per channel, (rstd, -mean * rstd) per 4-channel half (gn_cpg % 4 == 0: four
+  // aligned consecutive channels share a group); a tile lies inside one image (gn_hw % 256 == 0)
+  float gb_g[2][8], gb_b[2][8], gb_r[2][2], gb_c[2][2];
+  f32x2_t acc_a1[2][2], acc_a2[2][2];
+  if constexpr (GNB) {
+    const int groups = p.N / p.gn_cpg;
+    const int64_t img = (int64_t)(m0 / p.gn_hw) * groups;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = ncol0 + 32 * q;
+      const bool nok = n < p.N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gb_g[q][j] = nok ? p.gnb_gamma[n + j] : 0.f;
+        gb_b[q][j] = nok ? p.gnb_beta[n + j] : 0.f;
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int g = nok ? (n + 4 * hf) / p.gn_cpg : 0;
+        const float rs = p.gnb_rstd[img + g], mu = p.gnb_mean[img + g];
+        gb_r[q][hf] = rs;
+        gb_c[q][hf] = -mu * rs;
+        acc_a1[q][hf] = acc_a2[q][hf] = f32x2_t{0.f, 0.f};
+      }
+    }
+  }
+  // GNB: the wave's x chunks are requested GD groups ahead (16 bytes per lane and group, raw: the fragment registers are free now) —
+  // with a prefetch distance of one group every group waited ~1 us on its load and the fusion cost 230 us per 256^2 launch
+  constexpr int GD = 4;
+  u32x4_t gb_raw[GNB ? GD : 1];
+  auto gnb_fetch = [&](int it) -> u32x4_t {
+    if constexpr (GNB && sizeof(T) == 2) {
+      const RowOff ro = rows_of(it >> 1);
+      const int n = ncol0 + 32 * (it & 1);
+      return (ro.ok && n < p.N) ? *(const u32x4_t*)((const T*)p.gnb_x + ro.y + n) : u32x4_t{0u, 0u, 0u, 0u};
+    } else {
+      return u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  if constexpr (GNB) {
+#pragma unroll
+    for (int it = 0; it < GD; ++it) gb_raw[it] = gnb_fetch(it);
+  }
   RowOff rcur = rows_of(0), rnxt = rcur;
   f32x8 pre_cur, pre_nxt;
   if constexpr (PRE) pre_cur = side(rcur, 0);
@@ -670,7 +716,27 @@ __device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f3
         v.v[4 + e] = __uint_as_float(s[1]);
       }
       if (rcur.ok && n < p.N) {
-        if constexpr (PRE) epilogue_oct_pre<T, EPI>(p, v, n, rcur.y, pre_cur);
+        if constexpr (GNB && sizeof(T) == 2) {
+          epilogue_oct<T, EPI>(p, v, n, rcur.y, rcur.r, rcur.a, flags);      // the ordinary store of dy (bias / residual as asked)
+          pre_cur = unpack8<T>(gb_raw[(2 * b + pp) % GD]);
+          if (2 * b + pp + GD < 4 * MT) gb_raw[(2 * b + pp) % GD] = gnb_fetch(2 * b + pp + GD);
+          // two columns at a time on packed fp32 (v_pk_fma / v_pk_mul: the epilogue's VALU time is what the fusion costs — 4 cycles per
+          // wave instruction, 16 per transcendental); the fp32 value is used as it is (its 16-bit rounding moves a sum by ~1e-4 of
+          // the rounding noise of its terms)
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const f32x2_t xv = {pre_cur.v[j], pre_cur.v[j + 1]}, gm = {gb_g[pp][j], gb_g[pp][j + 1]}, bt = {gb_b[pp][j], gb_b[pp][j + 1]};
+            const f32x2_t xh = xv * gb_r[pp][j >> 2] + gb_c[pp][j >> 2];
+            f32x2_t d = f32x2_t{v.v[j], v.v[j + 1]} * gm;
+            if (p.gnb_swish) {
+              const f32x2_t yv = xh * gm + bt;
+              const f32x2_t sg = sigmoid_fast2(yv);
+              d *= sg * (1.0f + yv * (1.0f - sg));
+            }
+            acc_a1[pp][j >> 2] += d;
+            acc_a2[pp][j >> 2] += d * xh;
+          }
+        } else if constexpr (PRE) epilogue_oct_pre<T, EPI>(p, v, n, rcur.y, pre_cur);
         else epilogue_oct<T, EPI>(p, v, n, rcur.y, rcur.r, rcur.a, flags);
         if constexpr ((EPI & EPI_O_F8) != 0) {
           constexpr float LIM = (EPI & EPI_O_F8E4) ? 448.0f : 57344.0f;
@@ -715,6 +781,27 @@ __device__ __forceinline__ void gemm_epilogue_perm16(const ffvc_gemm_desc& p, f3
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) f8_amax = fmaxf(f8_amax, __shfl_xor(f8_amax, o, 64));
     if (lane == 0 && f8_amax > 0.0f) atomicMax((unsigned int*)(p.y8_state + 1), __float_as_uint(f8_amax));
+  }
+  if constexpr (GNB) {
+    const int groups = p.N / p.gn_cpg;
+    const int64_t img = (int64_t)(m0 / p.gn_hw) * groups;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float a = acc_a1[q][hf][0] + acc_a1[q][hf][1], b = acc_a2[q][hf][0] + acc_a2[q][hf][1];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        const int n = ncol0 + 32 * q + 4 * hf;
+        if (l15 == 0 && n < p.N) {
+          double* o2 = p.gnb_sums + (img + n / p.gn_cpg) * 2;
+          atomicAdd(o2, (double)a);
+          atomicAdd(o2 + 1, (double)b);
+        }
+      }
   }
   if (cs_on) {
     // column sums of everything this wave stored: the 16 lanes of a lane group own the same 8 columns -> fold them, one fp32

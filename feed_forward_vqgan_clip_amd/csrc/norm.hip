@@ -1500,6 +1500,27 @@ extern "C" int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* ga
   return 0;
 }
 
+// GroupNorm backward with the statistics already accumulated by the dgrad convolution that produced dy (FFVC_F_GNB_SUMS,
+// gnb_sums[B][G][2] fp64): the apply pass only — 3 reads + 1 write instead of 5 + 1.
+extern "C" int ffvc_groupnorm_bwd_sums(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                                       const float* rstd, const void* dres, void* dx, const double* sums, int B, int HW, int C, int G,
+                                       int swish, int dtype, void* stream) {
+  FFVC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && sums, "ffvc_groupnorm_bwd_sums: null pointer");
+  if (int e = gn_check(B, HW, C, G, dtype, "ffvc_groupnorm_bwd_sums")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  int bpi = 4096 / (B < 1 ? 1 : B);
+  if (bpi > HW / 64) bpi = HW / 64;
+  if (bpi < 1) bpi = 1;
+  const int rpb = (HW + bpi - 1) / bpi;
+  const int nblk = (HW + rpb - 1) / rpb;
+  DISPATCH_DT(dtype, T, {
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nblk, B), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd, sums,
+                       (const T*)dres, (T*)dx, HW, C, G, 1, swish, rpb);
+  });
+  FFVC_LAUNCH_CHECK();
+  return 0;
+}
+
 // GroupNorm (+ swish) whose output (also) leaves as fp8 bytes — the operand of the fp8 3x3 convolution that follows (see
 // ffvc_layernorm_fwd_f8 for the byte contract).  sums != NULL: the moments come from the producing GEMM (ffvc_groupnorm_fwd_sums), ws
 // is not used.  y may be NULL.  16-bit tensors only.

@@ -141,7 +141,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
          xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0, gn_sums=None,
-         colsum=None):
+         colsum=None, gnb=None, probe_only=False):
     """Enqueue `ffvc_gemm`. See include/ffvc.h for the index maps.
 
     y_map / r_map = (mi, so, sm): row offset(m) = (m // mi) * so + (m % mi) * sm (mi = 0: m * sm).
@@ -195,6 +195,16 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
             raise TypeError("gemm: gn_sums buffer must be a contiguous fp64 device tensor")
         d.gn_sums, d.gn_hw, d.gn_cpg = buf.data_ptr(), hw, cpg
         d.flags |= _lib.F_GN_SUMS
+    if gnb is not None:
+        # (x, mean, rstd, gamma, beta, sums fp64 [images, groups, 2] zeroed, swish, pixels per image, channels per group): the stored
+        # output is the gradient of act(GroupNorm(x)) -> the launch also accumulates that node's backward statistics (F_GNB_SUMS)
+        gx, gmean, grstd, ggamma, gbeta, gsums, gswish, ghw, gcpg = gnb
+        d.gnb_x, d.gnb_mean, d.gnb_rstd = gx.data_ptr(), gmean.data_ptr(), grstd.data_ptr()
+        d.gnb_gamma, d.gnb_beta, d.gnb_sums, d.gnb_swish = ggamma.data_ptr(), gbeta.data_ptr(), gsums.data_ptr(), int(bool(gswish))
+        d.gn_hw, d.gn_cpg = ghw, gcpg
+        d.flags |= _lib.F_GNB_SUMS
+    if probe_only:
+        return bool(_lib.load().ffvc_gemm_gnb_probe(byref(d), stream_ptr()))
     if colsum is not None:                        # fp32 [N]: += column sums of the stored output (colsum_fusable() first)
         if colsum.dtype != torch.float32 or not colsum.is_cuda or not colsum.is_contiguous() or colsum.numel() != N:
             raise TypeError("gemm: colsum must be a contiguous fp32 [N] device tensor")
@@ -227,7 +237,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     if REPLAY is not None:       # EVERY profiled launch has a replay entry (bench.attainable_leg aligns the two lists index by index)
         REPLAY.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
                        (M, N, K, max(1, batch), split_k, int(d.flags), int(act)), issue if skinny else d,
-                       (x, w, y, bias, residual, aux, colsum, gn_sums)))
+                       (x, w, y, bias, residual, aux, colsum, gn_sums, gnb)))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -641,7 +651,26 @@ def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None, f8=None
     return y, mean, rstd
 
 
-def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True, f8=None, f8_only=False):
+_GNB_OK = {}
+GNB_FUSE = os.environ.get("FFVC_GNB_FUSE", "1") != "0"      # A/B: GroupNorm-backward statistics inside the dgrad convolution
+
+
+def conv_gnb_ok(dy, wd, dx, x_gn, mean, rstd, gamma, beta, B, H, W, Cout_of_conv, Cin_of_conv):
+    """Will the dgrad convolution dx[B,H,W,Cin] = conv3x3(dy[B,H,W,Cout], wd) take the kernel that folds the GroupNorm-backward
+    statistics of the node that produced the convolution's input (ffvc_gemm_gnb_probe)?  Asked once per shape."""
+    if not GNB_FUSE or dy.dtype not in LOWP or x_gn.dtype != dy.dtype or Cin_of_conv % 32:
+        return False
+    key = (dy.dtype, B, H, W, Cout_of_conv, Cin_of_conv)
+    ok = _GNB_OK.get(key)
+    if ok is None:
+        sums = torch.zeros(B, 32, 2, dtype=torch.float64, device=dy.device)
+        ok = gemm(dy, wd, dx, B * H * W, Cin_of_conv, 9 * Cout_of_conv, ldw=9 * Cout_of_conv, x_mode=OP_CONV3X3, conv=(H, W, Cout_of_conv),
+                  gnb=(x_gn, mean, rstd, gamma, beta, sums, True, H * W, Cin_of_conv // 32), probe_only=True)
+        _GNB_OK[key] = ok
+    return ok
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True, f8=None, f8_only=False, sums=None):
     """f8 (an initialised Fp8Scale, 16-bit tensors): -> (dx, dx8), the gradient also as fp8 bytes in f8's scale (what fp8_quant(dx, f8)
     would give); f8_only: dx is not written (uninitialised)."""
     _req_f32(gamma, beta, mean, rstd)
@@ -662,6 +691,13 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=None, G=32, swish=True, f
                   _ptr(dres), 0 if f8_only else dx.data_ptr(), dx8.data_ptr(), f8.state.data_ptr(), f8.fmt, ws.data_ptr(), B, HW, C, G,
                   int(swish), dtype_code(x.dtype), stream_ptr())
         return _unwritten(dx, f8_only), dx8
+    if sums is not None:
+        # statistics already accumulated by the dgrad convolution that produced dy (gemm(gnb=...)): the apply pass only
+        nb1 = x.numel() * x.element_size() * (3 + (1 if dres is not None else 0))
+        with _hbm("groupnorm_bwd", nb1, min_bytes=nb1):
+            _call("ffvc_groupnorm_bwd_sums", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  _ptr(dres), dx.data_ptr(), sums.data_ptr(), B, HW, C, G, int(swish), dtype_code(x.dtype), stream_ptr())
+        return dx
     # algorithmic bytes of the two-pass backward: statistics (dy, x) + apply (dy, x, dres, dx)
     with _hbm("groupnorm_bwd", x.numel() * x.element_size() * (5 + (1 if dres is not None else 0)),
               min_bytes=x.numel() * x.element_size() * (3 + (1 if dres is not None else 0))):

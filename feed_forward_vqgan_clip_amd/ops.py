@@ -767,6 +767,10 @@ class _GNForkFn(Function):
             y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, 32, 1e-6, swish, sums=sums)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.swish = swish
+        if x.dtype in K.LOWP and x.dim() == 4 and f8 is None:
+            # the 3x3 convolution that consumes y can fold this node's BACKWARD statistics into its dgrad epilogue (round 6):
+            # what it needs rides on y (see _Conv3x3Fn)
+            y._ffvc_gnb = (x, gamma, beta, mean, rstd, bool(swish))
         # x came out of an fp8 convolution whose dgrad wants this node's gradient as e5m2 bytes
         ctx.gsc = getattr(x, "_ffvc_gsc", None) if _F8_PRODUCER else None
         ctx.grad_sole = bool(grad_sole)
@@ -784,6 +788,10 @@ class _GNForkFn(Function):
             _f8_twin(dres, None)
             dres = _as(_contig(dres), x.dtype)
         gsc = ctx.gsc
+        gnb_sums = getattr(dy, "_ffvc_gnb_sums", None)  # accumulated by the dgrad convolution that produced dy for THIS node
+        if gnb_sums is not None and gnb_sums[1].data_ptr() == mean.data_ptr() and not (gsc is not None and gsc.ready):
+            dx = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=dres, G=32, swish=ctx.swish, sums=gnb_sums[0])
+            return dx, None, None, None, None, None
         if gsc is not None and gsc.ready and x.dtype in K.LOWP:
             only = ctx.grad_sole and dres is None        # nothing but that dgrad reads the gradient: skip its 16-bit form
             dx, dx8 = K.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dres=dres, G=32, swish=ctx.swish, f8=gsc, f8_only=only)
@@ -864,6 +872,8 @@ class _Conv3x3Fn(Function):
                    gn_sums=None if sums is None else (sums, H * W, P.Cout // 32))
         ctx.P, ctx.upsample, ctx.geom, ctx.cdt = P, upsample, (B, H, W, Cin), x.dtype
         ctx.has_res = residual is not None
+        # x = act(GroupNorm(.)): that node's backward statistics can be folded into this convolution's dgrad (no upsample in between)
+        ctx.gnb = None if (upsample or ctx.f8) else getattr(x, "_ffvc_gnb", None)
         return y
 
     @staticmethod
@@ -886,8 +896,19 @@ class _Conv3x3Fn(Function):
             elif P.wd is not None:
                 _f8_twin(dy, None)
                 dyt = _as(dy, ctx.cdt)
-                K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3,
-                       conv=(H, W, P.Cout))
+                gnb = ctx.gnb
+                if gnb is not None and gnb[0].dtype == ctx.cdt and tuple(gnb[0].shape) == (B, H, W, Cin) and \
+                        K.conv_gnb_ok(dyt, P.wd, dxu, gnb[0], gnb[3], gnb[4], gnb[1], gnb[2], B, H, W, P.Cout, Cin):
+                    # the gradient this dgrad stores is the one GroupNorm's backward starts from: accumulate its statistics here
+                    # (2 of that backward's 5 reads and its first launch), hand them over on the tensor
+                    xg, gam, bet, mean, rstd, sw = gnb
+                    sums = torch.zeros(B, 32, 2, dtype=torch.float64, device=dy.device)
+                    K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3, conv=(H, W, P.Cout),
+                           gnb=(xg, mean, rstd, gam, bet, sums, sw, H * W, Cin // 32))
+                    dxu._ffvc_gnb_sums = (sums, mean)
+                else:
+                    K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3,
+                           conv=(H, W, P.Cout))
             else:
                 kp = P.wd_small.shape[1]
                 cols = K.im2col3x3(dy, ctx.cdt, kp)

@@ -65,6 +65,9 @@ extern "C" {
                                  * pass), with FFVC_F_MUL_ACT_GRAD the backward epilogue is a plain multiply.  16-bit dtypes,
                                  * batch 1. */
 #define FFVC_F_ACCUM_OUT 256    /* y += acc with plain read-modify-write (fp32 y, split_k == 1: one owner per element) */
+#define FFVC_F_GNB_SUMS 8192    /* the stored output is the gradient dy of a GroupNorm(+swish) output: also accumulate that node's BACKWARD
+                                 * statistics (see gnb_* below) — the statistics pass of ffvc_groupnorm_bwd folded into the dgrad convolution
+                                 * that produces dy.  conv3 row-tile kernel only (ffvc_gemm_gnb_probe says whether a launch takes it). */
 #define FFVC_F_SPLITK_INKERNEL 4096 /* split_k > 1 handled INSIDE the launch: every K slice parks its fp32 partial tile in library
                                   * scratch, the last slice to arrive on a tile sums them in slice order and runs the ordinary
                                   * epilogue (any epilogue, FFVC_F_ACCUM_OUT included): no slabs, no reduce launch.  16-bit LDS-DMA
@@ -166,9 +169,27 @@ typedef struct ffvc_gemm_desc {
    * 256x256 LDS-DMA weight-gradient kernel. */
   int32_t grp_n;
   int64_t grp_xoff[8], grp_woff[8];
+  /* FFVC_F_GNB_SUMS (round 6; reference: taming Decoder ResnetBlock backward): y = dy [M = images * gn_hw pixels,
+   * N channels] is the gradient w.r.t. act(GroupNorm(gnb_x)) (act = swish when gnb_swish).  With xh = (gnb_x - mean) * rstd,
+   * ds = round_16(dy) * act'(xh * gamma + beta) * gamma the launch adds, per (image, group of gn_cpg channels),
+   *     gnb_sums[image][group][0] += sum ds,   gnb_sums[image][group][1] += sum ds * xh          (fp64 atomics, buffer zeroed by the caller)
+   * — exactly what the statistics pass of ffvc_groupnorm_bwd computes from dy and x (2 of its 5 reads); ffvc_groupnorm_bwd_sums then
+   * only applies.  gnb_x: 16-bit, contiguous [M, N] like y (y_sm == N, no row map, batch 1); gnb_mean / gnb_rstd: fp32 [images, N / gn_cpg];
+   * gnb_gamma / gnb_beta: fp32 [N].  gn_hw % 256 == 0, gn_cpg % 4 == 0. */
+  const void* gnb_x;
+  const float* gnb_mean;
+  const float* gnb_rstd;
+  const float* gnb_gamma;
+  const float* gnb_beta;
+  double* gnb_sums;
+  int32_t gnb_swish;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);
+/* 1 if ffvc_gemm would run this descriptor (flags incl. FFVC_F_GNB_SUMS) on a kernel that implements FFVC_F_GNB_SUMS, 0 if not; nothing
+ * is launched.  (The fusion exists on the pipelined row-tile convolution only; callers ask once per shape and otherwise keep the
+ * separate statistics pass.) */
+int ffvc_gemm_gnb_probe(const ffvc_gemm_desc* d, void* stream);
 /* The plain Linear product for a handful of rows (M <= 64, N % 32 == 0, K % 256 == 0: ffvc_gemm_skinny_ok), 16-bit K-major operands with
  * row stride K: the K loop is split across the eight waves of a workgroup — the 64-row remainder of the ViT-L/14 tower's 64 x 257 rows
  * (cloob.py:199-205 at BASELINE configs[4]).  y (fp32 or in_dtype, row stride N) = X W^T (+ bias) (+ residual in fp32 or in_dtype). */
@@ -268,6 +289,12 @@ int ffvc_groupnorm_fwd_sums(const void* x, void* y, const float* gamma, const fl
 int ffvc_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                        const float* rstd, const void* dres, void* dx, void* ws, int B, int HW, int C, int G,
                        int swish, int dtype, void* stream);
+/* Same, with the backward statistics already accumulated by the dgrad convolution that produced dy (ffvc_gemm with FFVC_F_GNB_SUMS:
+ * sums[B][G][2] fp64): only the apply pass runs (reads dy, x, dres; writes dx).  Reference: taming ResnetBlock backward through
+ * Normalize + nonlinearity. */
+int ffvc_groupnorm_bwd_sums(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, const void* dres, void* dx, const double* sums, int B, int HW, int C, int G,
+                            int swish, int dtype, void* stream);
 
 /* The same two passes with the producer-side quantisation of ffvc_layernorm_fwd_f8 (16-bit tensors): the normalised (+ swish) tensor
  * is the operand of the fp8 3x3 convolution that follows (sums != NULL: moments from the producing GEMM, ws unused), the input gradient

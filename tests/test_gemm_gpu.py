@@ -1049,3 +1049,52 @@ def test_gemm3_is_bit_identical_to_the_256x256_kernel_on_plain_launches(cuda):
     K.gemm(x, w, y1, M, N, Kd, ldx=Kd, ldw=Kd)
     K.set_option("gemm3", -100)       # back to "unset": FFVC_GEMM3 (default: off)
     assert torch.equal(y0, y1)
+
+
+# ----------------------------------------------------------------------------- round 6: GroupNorm-backward statistics inside the dgrad convolution
+@pytest.fixture
+def row_tile_forced():
+    K.set_option("conv_row", 2)        # the row-tile kernels whatever the grid size (the heuristic wants >= 256 tiles: batch 64 in the step)
+    K._GNB_OK.clear()
+    yield
+    K.set_option("conv_row", 1)
+    K._GNB_OK.clear()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,C,Cd,swish", [(2, 128, 128, 128, True), (1, 256, 128, 128, True), (2, 64, 256, 256, True), (4, 64, 128, 256, False)])
+def test_dgrad_convolution_accumulates_the_groupnorm_backward_statistics(cuda, row_tile_forced, dt, B, H, C, Cd, swish):
+    """FFVC_F_GNB_SUMS (csrc/conv3.hip + gemm_epilogue_perm16): the dgrad convolution that produces dy = d(loss)/d(act(GN(x))) also
+    accumulates sum(ds) and sum(ds * xhat) per (image, group), ds = round_16(dy) * act'(.) * gamma — the statistics pass of
+    ffvc_groupnorm_bwd.  Checked against fp64 math on the stored dy, and the apply-only backward against the two-pass one.
+    (B, H, C, Cd): images, side, channels of the GroupNorm node (= dgrad output channels), channels of the convolution's output."""
+    g = torch.Generator().manual_seed(17)
+    G = 32
+    x = torch.randn(B, H, H, C, generator=g).to(dt).cuda()                       # the GroupNorm node's input
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.2 * torch.randn(C, generator=g)).cuda()
+    gout = (torch.randn(B, H, H, Cd, generator=g) * 0.1).to(dt).cuda()           # gradient of the convolution's output
+    wd = (torch.randn(C, 9 * Cd, generator=g) * (9 * Cd) ** -0.5).to(dt).cuda()  # the dgrad filter [Cin, kh, kw, Cout]
+    y, mean, rstd = K.groupnorm_fwd(x, gamma, beta, G, 1e-6, swish)
+    dy0 = torch.empty(B, H, H, C, dtype=dt, device=cuda)
+    K.gemm(gout, wd, dy0, B * H * H, C, 9 * Cd, ldw=9 * Cd, x_mode=K.OP_CONV3X3, conv=(H, H, Cd))
+    assert K.conv_gnb_ok(gout, wd, dy0, x, mean, rstd, gamma, beta, B, H, H, Cd, C)
+    sums = torch.zeros(B, G, 2, dtype=torch.float64, device=cuda)
+    dy1 = torch.empty_like(dy0)
+    K.gemm(gout, wd, dy1, B * H * H, C, 9 * Cd, ldw=9 * Cd, x_mode=K.OP_CONV3X3, conv=(H, H, Cd),
+           gnb=(x, mean, rstd, gamma, beta, sums, swish, H * H, C // G))
+    assert torch.equal(dy0, dy1)                                                  # the stored gradient itself is untouched
+    xd, dyd = x.double(), dy1.double()
+    xh = (xd.view(B, H * H, G, C // G) - mean.double().view(B, 1, G, 1)) * rstd.double().view(B, 1, G, 1)
+    yv = xh * gamma.double().view(1, 1, G, C // G) + beta.double().view(1, 1, G, C // G)
+    ds = dyd.view(B, H * H, G, C // G)
+    if swish:
+        sg = torch.sigmoid(yv)
+        ds = ds * (sg * (1 + yv * (1 - sg)))
+    ds = ds * gamma.double().view(1, 1, G, C // G)
+    want = torch.stack([ds.sum((1, 3)), (ds * xh).sum((1, 3))], dim=-1)
+    scale = ds.abs().sum((1, 3)).max().item()
+    assert (sums - want).abs().max().item() < 2e-4 * scale, ((sums - want).abs().max().item(), scale)
+    dres = torch.randn(B, H, H, C, generator=g).to(dt).cuda()
+    dx2 = K.groupnorm_bwd(dy1, x, gamma, beta, mean, rstd, dres=dres, G=G, swish=swish)
+    dx1 = K.groupnorm_bwd(dy1, x, gamma, beta, mean, rstd, dres=dres, G=G, swish=swish, sums=sums)
+    assert (dx1.float() - dx2.float()).abs().max().item() <= 2 * LOTOL[dt] * dx2.float().abs().max().item()
