@@ -371,6 +371,16 @@ def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_pat
     from feed_forward_vqgan_clip_amd import ops
     ops.set_wgrad_side_stream(False)
     stepper(tok)                                  # (untimed: the serialised order allocates differently, let the allocator settle)
+    # the serialised step WITHOUT per-launch events first: with ~3000 event records per step the host, not the GPU, paces the
+    # instrumented pass, and what it leaves idle must not be booked as "unmodelled" kernel time
+    evp0, evp1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    evp0.record()
+    stepper(tok)
+    stepper(tok)
+    evp1.record()
+    torch.cuda.synchronize()
+    wall_plain = evp0.elapsed_time(evp1) / 2.0
     K.PROFILE, K.HBM_PROFILE, K.AUX_PROFILE = [], [], []
     del K.HBM_MIN_BYTES[:]
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -388,7 +398,8 @@ def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_pat
     torch.cuda.synchronize()
     rep, K.REPLAY = K.REPLAY, None
     ops.set_wgrad_side_stream(True)
-    wall_b = ev0.elapsed_time(ev1)
+    wall_instr = ev0.elapsed_time(ev1)                              # the instrumented pass (host-paced: diagnostic only)
+    wall_b = min(wall_plain, wall_instr)
     gemm_b = [e0.elapsed_time(e1) for _, _, e0, e1, _ in prof_b]
     hbm_b_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in hbm_b)
     aux_b_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in aux_b)
@@ -487,7 +498,7 @@ def attainable_leg(stepper, tok, prof_instep, hbm_instep, ms_per_step, table_pat
     gaps.sort(key=lambda g: -g[0])
     return {"attainable_ms": att, "frac_of_attainable": att / ms_per_step,
             "attainable_parts_ms": {"gemm_isolated": gemm_iso_ms, "hbm_at_6.3TBps": hbm_model_ms, "rest_serialised": rest_ms},
-            "serialised_step_ms": wall_b, "attainable_aligned": aligned,
+            "serialised_step_ms": wall_b, "serialised_step_instrumented_ms": wall_instr, "attainable_aligned": aligned,
             "attainable_note": "every distinct GEMM launch of the step replayed alone (same descriptor), HBM kernels at bytes / 6.3 TB/s, "
                                "everything else at its time in a serialised step (rest_serialised: measured, i.e. self-referential by "
                                "construction); frac_of_attainable = attainable_ms / ms_per_step",

@@ -79,9 +79,21 @@ def set_wgrad_side_stream(enabled):
     _SIDE["enabled"] = bool(enabled)
 
 
+# HIP stream priority of the weight-gradient stream: -1 (high, default) | 0 (normal).  Measured (round 6, same box, two A/B rounds): high
+# 127.0 / 127.2 ms, normal 127.5 / 127.6 — the full-chip weight-gradient launches finish sooner when the dispatcher favours them, and
+# the main stream's kernels were going to share the chip with them anyway.
+_SIDE_PRIORITY = os.environ.get("FFVC_SIDE_PRIORITY", "-1")
+
+
 def _side_stream():
     if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
+        if _SIDE_PRIORITY is not None:
+            try:
+                _SIDE["stream"] = torch.cuda.Stream(priority=int(_SIDE_PRIORITY))
+            except (RuntimeError, ValueError):
+                _SIDE["stream"] = torch.cuda.Stream()
+        else:
+            _SIDE["stream"] = torch.cuda.Stream()
     return _SIDE["stream"]
 
 

@@ -156,3 +156,4 @@ def test_tolerant_load_does_not_execute_nested_pickles(tmp_path):
     with pytest.raises(Exception):
         cio.tolerant_load(q)
     assert not marker.exists()
+
