@@ -873,7 +873,10 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   }
   if constexpr (M16) {
     if (vec_ok == 2)
-      ffvc_gemm_detail::gemm_epilogue_out16<L, MT, EPI, (XMODE == FFVC_OP_CONV3X3 ? (FFVC_EPI_PERM != 0) : (FFVC_EPI_PERM != 0 && FFVC_EPI_PERM_NT != 0))>(
+      // register exchange on the convolutions and on the activation-forward kinds that also store act' (two 16-bit tensors out: 178 vs
+      // 189 us at 16384x4096x1024, profiles/r06_gemm3_ab.txt), LDS pads on the other K-major x K-major launches (gemm_common.h)
+      ffvc_gemm_detail::gemm_epilogue_out16<L, MT, EPI, (XMODE == FFVC_OP_CONV3X3 || (EPI & ffvc_gemm_detail::EPI_K_FWDG) != 0
+                                                             ? (FFVC_EPI_PERM != 0) : (FFVC_EPI_PERM != 0 && FFVC_EPI_PERM_NT != 0))>(
           p, acc16, m0, n0, wm, wn, lane, zo, zi, smem + (RING ? 2 : 1) * STAGE + wid * 4096);
     else
       ffvc_gemm_detail::gemm_epilogue16<L, MT, true>(p, acc16, m0, n0, wm, wn, lane, zo, zi, 1);
