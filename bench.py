@@ -80,6 +80,8 @@ def build(args, device):
                                        tail_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_tail", "fp32") == "bf16" else None)
         hvd.broadcast_parameters(net, root_rank=0)
     stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
+    if getattr(args, "reserve", True) and not os.environ.get("FFVC_SHARE_DEVICE"):      # (ranks sharing one GPU in the tests: no)
+        fmain.reserve_device_memory(device=device)      # one large block for the caching allocator (see its docstring); FFVC_RESERVE_GIB=0 off
     return cfg, stepper, (mixer_sd, vq_sd, clip_sd)
 
 
@@ -642,6 +644,7 @@ def main():
             raise SystemExit("--graph needs at least one eager warm-up step (scratch allocations happen there)")
         stepper.enable_graph(B, batches[it])          # one more (eager) warm-up step on the capture stream, then the capture
     sync()
+    mem0 = torch.cuda.memory_stats(device)
     clk0 = K.clock_sample()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU time (diagnostic only)
     # did any timed f16 step trip the non-finite guard?  The Adam kernel counts wavefront-level overflow events on the device
@@ -662,6 +665,7 @@ def main():
     clk1 = K.clock_sample()
     sync()
     dt = time.perf_counter() - t0
+    mem1 = torch.cuda.memory_stats(device)
     step_ms = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
     sclk_mhz = K.effective_clock_mhz(clk0, clk1)     # engine clock averaged over the timed region (and over the XCDs)
     if hvd.is_distributed():
@@ -694,6 +698,14 @@ def main():
                    "augmentation": "fused single resample (opt-in)" if args.augment_fused else "kornia order: one resample per warp (Af, then Pe+Ji+Er), both inside one launch",
                    "dp": hvd.describe()},
         "final_loss": float(loss.item()),
+        # did torch's caching allocator go back to hipMalloc inside the timed region (a one-off stall of tens of ms)?  segments it created
+        # and allocation retries between the first and the last timed step: both must be 0 for a clean line
+        "allocator_in_timed_region": {"new_segments": int(mem1.get("segment.all.allocated", 0) - mem0.get("segment.all.allocated", 0)),
+                                      "new_large_segments": int(mem1.get("segment.large_pool.allocated", 0) - mem0.get("segment.large_pool.allocated", 0)),
+                                      "new_segment_MiB": round((mem1.get("reserved_bytes.all.allocated", 0) - mem0.get("reserved_bytes.all.allocated", 0)) / 2 ** 20, 1),
+                                      "freed_segments": int(mem1.get("segment.all.freed", 0) - mem0.get("segment.all.freed", 0)),
+                                      "alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
+                                      "reserved_GiB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)},
         # timed steps whose backward produced a non-finite scaled gradient (the Adam kernel's device-side guard): must be 0 for the
         # line to be 20 real updates
         "overflow_steps": (int((bad_hist[1:] != bad_hist[:-1]).sum().item()) if bad_hist is not None else None),

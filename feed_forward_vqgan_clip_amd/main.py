@@ -414,6 +414,27 @@ def load_model(path, cdt=torch.float16, vq_channels=256):
     return net.cuda().prepare(cdt)
 
 
+def reserve_device_memory(gib=None, device=None):
+    """Hand torch's caching allocator ONE large free block before the first step (sized for 288 GB of HBM3E: 45 % of the device by
+    default, `FFVC_RESERVE_GIB` / config `reserve_gib` override, 0 = off).  The step's working set (~45 GB of saved activations at cfg2,
+    ~20 GB of it crossing to the weight-gradient stream every step) otherwise makes the allocator return to hipMalloc for hundreds of MB at a
+    time — 14 GB of new segments over 20 steps after the warm-up, measured — and a hipMalloc is an occasional 30-60 ms stall in the middle
+    of a step.  A block the allocator already owns is split and re-joined without the driver."""
+    if not torch.cuda.is_available():
+        return 0.0
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    if gib is None:
+        env = os.environ.get("FFVC_RESERVE_GIB")
+        gib = float(env) if env is not None else 0.45 * torch.cuda.get_device_properties(device).total_memory / 2 ** 30
+    free, _ = torch.cuda.mem_get_info(device)
+    gib = min(float(gib), 0.8 * free / 2 ** 30)
+    if gib < 1.0:
+        return 0.0
+    blk = torch.empty(int(gib * 2 ** 30), dtype=torch.uint8, device=device)
+    del blk                      # back to the allocator's free list (NOT to the driver): one segment of `gib` GiB
+    return gib
+
+
 class TrainStep:
     """One rank's state for the loop body of `train` (main.py:715-837): mapper, frozen VQGAN + CLIP, cutout
     parameters, optimizer.  `__call__(inp, out)` performs forward, loss, backward and the optimizer step."""
@@ -449,6 +470,12 @@ class TrainStep:
         self.l2_coef, self.tv_coef = config.get("l2_coef", 0.0), config.get("tv_coef", 0.0)
         self._prefetched, self._text_stream = None, None
         self._graph = None                                                      # captured step (enable_graph)
+        # Host run-ahead bound (round 6): the host enqueues a step in ~25 ms, the GPU runs it in ~128, so without a synchronisation point
+        # (bench.py's timed loop has none) the host is a dozen steps ahead within seconds.  At most `steps_in_flight` steps are queued;
+        # the GPU still never idles.  Measured neutral on the step time and on the allocator (the growth of torch's caching allocator
+        # inside the timed region — 14 GB of new segments per 20 steps — is fragmentation, fixed by reserve_device_memory above).
+        self.steps_in_flight = int(config.get("steps_in_flight", os.environ.get("FFVC_STEPS_IN_FLIGHT", "2")))
+        self._inflight = []
 
     def features(self, t):
         if t.dtype != torch.long:
@@ -633,7 +660,18 @@ class TrainStep:
         self.opt.step()                                                         # :835
         if self.scheduler is not None:
             self.scheduler.step()                                               # :836-837
+        self._throttle()
         return loss.detach(), mid
+
+    def _throttle(self):
+        """Wait (host side only) until at most `steps_in_flight` steps are queued on the GPU; see __init__."""
+        if self.steps_in_flight <= 0:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight.append(ev)
+        while len(self._inflight) > self.steps_in_flight:
+            self._inflight.pop(0).synchronize()
 
 
 def make_grid(images, nrow=8, padding=2):
@@ -736,6 +774,8 @@ def train(config_file):
     bs = config.batch_size
     sampler = hvd.DistributedSampler(len(data[0]), shuffle=True)
     stepper = TrainStep(config, net, vq, perceptor, opt, scheduler)
+    if config.get("reserve_gib") is not None:                                  # opt-in for training runs (bench.py reserves by default)
+        reserve_device_memory(float(config.get("reserve_gib")))
     first_sel = torch.tensor(list(iter(sampler))[:bs])
     first_batch = (data[0][first_sel], data[1][first_sel])                       # main.py:679
     log_f = open(os.path.join(config.folder, "scalars.jsonl"), "a") if rank_zero else None
