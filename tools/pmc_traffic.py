@@ -23,7 +23,7 @@ def per_kernel(d, counter):
 CLASSES = {   # bench.py's GEMM classes (dtype suffix stripped) -> kernel-name patterns, demangled or mangled (rocprofv3 does
     # not demangle the _Float16 instantiations: gemm2_kernelIDF16_Li0ELi0E...)
     "gemm_nt": r"gemm[28]p?_kernel<[^,]*, ?0, 0,|gemm2p?_kernelI(DF16_|t)Li0ELi0E|gemm8_kernelI(DF16_|t)Li0E",
-    "conv3x3": r"conv_row_kernel|gemm2p?_kernel<[^,]*, ?2, 0,|gemm2p?_kernelI(DF16_|t)Li2ELi0E",
+    "conv3x3": r"conv_row\d?_kernel|gemm2p?_kernel<[^,]*, ?2, 0,|gemm2p?_kernelI(DF16_|t)Li2ELi0E",
     "gemm_nn": r"gemm2p?_kernel<[^,]*, ?0, 1,|gemm2p?_kernelI(DF16_|t)Li0ELi1E",
     "gemm_tn": r"gemm_kernel<[^,]*, 1, 1|gemm_kernelI(DF16_|t)Li1ELi1E|gemm2p?_kernel<[^,]*, ?1, 1,|gemm2p?_kernelI(DF16_|t)Li1ELi1E",
     "tokmix": r"tokmix_(fwd|bwd_hidden)_kernel",
