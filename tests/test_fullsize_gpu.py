@@ -239,12 +239,9 @@ def test_cfg3_cfg4_throughput_mode_properties(cuda, kind):
     assert min(losses[2:] + [final.item()]) < losses[0], losses
 
 
-def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
-    """BASELINE.json configs[4] at full size (Mixer 1x1024 on a 32x32 latent grid, 512x512 decode, OpenCLIP ViT-L/14 LAION-2B
-    tower: erf-GELU, 257 tokens -> flash-style attention, 588-wide patch rows), two prompts x two cutouts: the throughput
-    modes (f16 storage; f16 + fp8 MFMA linears in the tower with delayed scaling) against the exact-fp32 HIP mode on the same
-    weights and draws (that mode is pinned to the oracle per component: Mixer / decoder / patch-14 tower tests), and a
-    training step in the fp8 mode."""
+def _cfg5_modes(modes, draw_seed):
+    """cfg5's step (two prompts x two cutouts) in the given modes on one set of draws -> {mode: loss / indices / embed / xr}; the modes
+    after "fp32" get its codes (compares arithmetic, not argmin ties)."""
     Bn, cutn = 2, 2
     name = "openclip/ViT-L-14/laion2b_s32b_b82k"
     cfg = fmain.Config(lr=1e-4, epochs=1, noise_dim=0, dropout=0, cutn=cutn, batch_size=Bn, repeat=1, nb_noise=None,
@@ -253,12 +250,11 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
     assert arch is fclip.VIT_L14 and quick is False and fmain.clip_dim_size(cfg) == (768, 224)
     vq_sd, clip_sd = fvq.random_state_dict(fvq.F16_16384, seed=3), fclip.random_state_dict(arch, seed=3)
     tok = fmain.synthetic_tokens(Bn, seed=5).cuda()
-    g = torch.Generator().manual_seed(9)
+    g = torch.Generator().manual_seed(draw_seed)
     facs, noise = (torch.rand(cutn * Bn, generator=g) * 0.1).cuda(), torch.randn(cutn * Bn, 3, 224, 224, generator=g).cuda()
     prm = None
     out = {}
-    for mode, cdt, fp8 in (("fp32", torch.float32, False), ("f16", torch.float16, False), ("fp8", torch.float16, True),
-                           ("fp8dec", torch.float16, True)):
+    for mode, cdt, fp8 in modes:
         torch.manual_seed(3)
         net = fmain.build_model(cfg, 256).cuda().prepare(cdt)
         vq = fvq.VQGAN(vq_sd, fvq.F16_16384, cdt, fp8=(mode == "fp8dec"))       # r4: + the decoder's large 3x3 convs on the fp8 row kernel
@@ -270,6 +266,7 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
         opt.loss_scale = 4096.0 if cdt == torch.float16 else 1.0
         stepper = fmain.TrainStep(cfg, net, vq, perceptor, opt)
         if prm is None:
+            torch.manual_seed(draw_seed)
             prm = stepper.make_cutouts.draw_aug_params(cutn * Bn, "cuda")
         idx = out["fp32"]["indices"] if "fp32" in out else None          # same codes as the fp32 run: compares arithmetic
         with torch.no_grad():
@@ -282,6 +279,17 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
             assert math.isfinite(l1.item()) and torch.isfinite(gr).all() and gr.abs().max().item() > 0
         del stepper, net, vq, perceptor, opt
         torch.cuda.empty_cache()
+    return out
+
+
+def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
+    """BASELINE.json configs[4] at full size (Mixer 1x1024 on a 32x32 latent grid, 512x512 decode, OpenCLIP ViT-L/14 LAION-2B
+    tower: erf-GELU, 257 tokens -> flash-style attention, 588-wide patch rows), two prompts x two cutouts: the throughput
+    modes (f16 storage; f16 + fp8 MFMA linears in the tower with delayed scaling) against the exact-fp32 HIP mode on the same
+    weights and draws (that mode is pinned to the oracle per component: Mixer / decoder / patch-14 tower tests), and a
+    training step in the fp8 mode."""
+    out = _cfg5_modes((("fp32", torch.float32, False), ("f16", torch.float16, False), ("fp8", torch.float16, True),
+                       ("fp8dec", torch.float16, True)), 9)
     ref = out["fp32"]
 
     def rr(a, b):
@@ -291,9 +299,15 @@ def test_cfg5_full_size_step_f16_and_fp8_against_fp32_mode(cuda):
     r16, r8 = abs(out["f16"]["loss"] - ref["loss"]) / ref["loss"], abs(out["fp8"]["loss"] - ref["loss"]) / ref["loss"]
     print(f"[cfg5] loss fp32 {ref['loss']:.7f} | f16 rel {r16:.2e} embed {e16:.2e} | fp8 rel {r8:.2e} embed {e8:.2e}")
     assert rr(out["f16"]["xr"], ref["xr"]) < 3e-3 and e16 < 3e-3 and r16 < 1e-4        # the north_star tolerance in f16 mode
-    # fp8 tower (opt-in, never the bench line): its own budget.  2.9e-3 on the draws of rounds 2-4; the round-5 default augmentation plan
-    # (kornia's two interpolations) changes the cutouts this seed produces: 3.0e-3 -> bound 4e-3 (e4m3 activations: 2^-4 relative each)
-    assert e8 < 6e-2 and r8 < 4e-3
+    # fp8 tower (opt-in, never the bench line): its own budget, asserted over TWO sets of draws (one seed had sat at 3.0e-3
+    # against a 3e-3 bound, and widening the bound to fit it left no margin).  e4m3 carries 3 mantissa bits = 2^-4 relative rounding per
+    # activation; through 24 blocks of a tower whose embedding error is e8 (a few 1e-2) the spherical loss moves by ~e8^2 ... e8 / 10:
+    # the MEAN over the draw sets must stay under 3e-3, a single set under 4.5e-3.
+    out2 = _cfg5_modes((("fp32", torch.float32, False), ("fp8", torch.float16, True)), 10)
+    r8b = abs(out2["fp8"]["loss"] - out2["fp32"]["loss"]) / out2["fp32"]["loss"]
+    e8b = rr(out2["fp8"]["embed"], out2["fp32"]["embed"])
+    print(f"[cfg5] second draw set: fp8 rel {r8b:.2e} embed {e8b:.2e}")
+    assert e8 < 6e-2 and e8b < 6e-2 and max(r8, r8b) < 4.5e-3 and 0.5 * (r8 + r8b) < 3e-3
     e8d = rr(out["fp8dec"]["embed"], ref["embed"])
     r8d = abs(out["fp8dec"]["loss"] - ref["loss"]) / ref["loss"]
     xd = rr(out["fp8dec"]["xr"], ref["xr"])
