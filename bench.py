@@ -14,7 +14,12 @@ seeded token batches and random-init weights of that architecture (no network). 
 mapper -> clamp -> VQ -> decoder -> cutouts(+noise) -> image tower -> spherical loss -> backward -> gradient
 all-reduce (N>1) -> fused Adam.  Weak scaling: the per-GPU batch is fixed (the reference's semantics, main.py:647,678).
 
-Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").  Round 6 added:
+`overflow_steps` (timed steps whose f16 backward tripped the non-finite guard: must be 0), `allocator_in_timed_region` (new segments of
+torch's caching allocator between the first and the last timed step: the line reserves one large block up front so that no hipMalloc
+stalls a timed step), `roofline.hw_bound_ms` + `top_gaps_ms` (the hardware bound beside the self-referential `attainable_ms`),
+`parity_full_size.grad_parity` (the oracle's gradients vs the HIP backward at full model size in the timed dtype) and, at N > 1,
+`dp_exposure.busbw_GBps`.
 """
 import argparse
 import json
