@@ -175,6 +175,7 @@ _SIGNATURES = {
     "ffvc_sln_fwd": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "ffvc_sln_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 14 + [c_int64, c_int, c_void_p]),
     "ffvc_sln_bwd_acc": (c_int, [c_void_p, c_int] + [c_void_p] * 14 + [c_int64, c_int, c_void_p]),
+    "ffvc_sln_bwd_acc2": (c_int, [c_void_p, c_int] + [c_void_p] * 11 + [c_int] + [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
     "ffvc_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
     "ffvc_clamp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
     "ffvc_clamp_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_float, c_float, c_float, c_float,

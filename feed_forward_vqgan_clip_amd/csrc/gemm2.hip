@@ -552,8 +552,10 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.x_mode != FFVC_OP_CONV3X3 && !m8(d.ldx)) return 0;
   if (d.x_mode == FFVC_OP_KMAJOR && (!m8(d.K) || (d.x_mi && !m8(d.x_so)))) return 0;
   if (d.w_mode == FFVC_OP_KMAJOR && !m8(d.K)) return 0;
-  if (d.x_mode == FFVC_OP_TRANS && !m8(d.M)) return 0;
-  if (d.w_mode == FFVC_OP_TRANS && !m8(d.N)) return 0;
+  // reduction-major operands: whole chunks along M / N — either the extent is a multiple of 8 or the row stride leaves room to read
+  // the last chunk in full (gemm2_kernels.h tr_cols)
+  if (d.x_mode == FFVC_OP_TRANS && !m8(d.M) && d.ldx < ((d.M + 7) & ~7)) return 0;
+  if (d.w_mode == FFVC_OP_TRANS && !m8(d.N) && d.ldw < ((d.N + 7) & ~7)) return 0;
   if (d.kseg && (!m8(d.xkso) || !m8(d.wkso))) return 0;
   const uint16_t* zero = zero_page();
   if (!zero) return 0;
@@ -793,7 +795,7 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
         smallm_tt = e ? atoi(e) : 1;
       }
       if (smallm_tt && env_bm == 1 && d.K <= 1024 && d.batch == 1 && d.split_k <= 1 && d.slab_stride == 0 && d.grp_n == 0 &&
-          (d.M % 8) == 0 && (d.N % 8) == 0 && (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) >= 16)
+          (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) >= 16)
         return ffvc_gemm2_launch_tt(d, st, vec_ok, zero, 128);
     }
     return 0;

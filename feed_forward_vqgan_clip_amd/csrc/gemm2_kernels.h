@@ -292,6 +292,14 @@ struct ConvRowDmaB {
 
 // ---- reduction-major operand: tile [64 k][128 cols]; position p: krow = p >> 4, slot = p & 15,
 // source column chunk = slot ^ ((krow & 3) << 2) ------------------------------------------------------------
+// Load bound of a reduction-major operand ([k][cols], row stride ld): the DMA moves whole 8-element chunks, so an extent that is not
+// a multiple of 8 is read up to the next multiple when the row stride has room for it (the padded qkv / w_out operands of the VitGAN
+// blocks: 3060 of 3064, 1020 of 1024).  The extra columns only reach accumulator rows / columns beyond M / N, which no epilogue stores.
+__device__ __forceinline__ int tr_cols(int cols, int64_t ld) {
+  const int up = (cols + 7) & ~7;
+  return (int64_t)up <= ld ? up : cols;
+}
+
 template <int ROWS, int NW>
 struct TransDma {
   static constexpr int NP = ROWS / (8 * NW);
@@ -648,11 +656,11 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
   if constexpr (XMODE == FFVC_OP_CONV3X3)
     sx.init(xb, m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
   else if constexpr (XMODE == FFVC_OP_TRANS)
-    sx.init(xb, p.ldx, m0, p.M, tid);
+    sx.init(xb, p.ldx, m0, tr_cols(p.M, p.ldx), tid);
   else
     sx.init(xb, p.ldx, m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
   if constexpr (WMODE == FFVC_OP_TRANS)
-    sw.init(wb, p.ldw, n0, p.N, tid);
+    sw.init(wb, p.ldw, n0, tr_cols(p.N, p.ldw), tid);
   else
     sw.init(wb, p.ldw, n0, p.N, p.kseg, p.wkso, tid, 0, 0);
 
@@ -1156,11 +1164,11 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
     if constexpr (XMODE == FFVC_OP_CONV3X3)
       sx.init(xb, it.m0, p.M, p.conv_H, p.conv_W, p.conv_Cin, (p.flags & FFVC_F_UPSAMPLE2X) ? 1 : 0, tid);
     else if constexpr (XMODE == FFVC_OP_TRANS)
-      sx.init(xb, p.ldx, it.m0, p.M, tid);
+      sx.init(xb, p.ldx, it.m0, tr_cols(p.M, p.ldx), tid);
     else
       sx.init(xb, p.ldx, it.m0, p.M, p.kseg, p.xkso, tid, p.x_mi, p.x_so);
     if constexpr (WMODE == FFVC_OP_TRANS)
-      sw.init(wb, p.ldw, it.n0, p.N, tid);
+      sw.init(wb, p.ldw, it.n0, tr_cols(p.N, p.ldw), tid);
     else
       sw.init(wb, p.ldw, it.n0, p.N, p.kseg, p.wkso, tid, 0, 0);
   };

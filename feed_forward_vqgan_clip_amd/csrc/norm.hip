@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
                                                       float* __restrict__ dhl, float* __restrict__ dw,
                                                       float* __restrict__ part_g, float* __restrict__ part_b,
                                                       float* __restrict__ part_s, int64_t rows, int dim,
-                                                      int rows_per_block, int acc_mode) {
+                                                      int rows_per_block, int acc_mode, float* __restrict__ part_s1,
+                                                      int dw_acc) {
   constexpr int NIT = LN_MAXE / VEC;
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [2][dim] + [2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -425,6 +426,12 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
           s2 += g[k * VEC + j] * h;
           ag[k * VEC + j] += dln * h;
           ab[k * VEC + j] += dln;
+        }
+        if (dw_acc) {     // every SLN of the network modulates with the same w: its gradient is one running sum (ffvc_sln_bwd_acc2)
+          float old[VEC];
+          ld_vec<VEC>(dw + row * dim + idx, old);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dwv[j] += old[j];
         }
         st_vec<VEC>(dw + row * dim + idx, dwv);
       }
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
       atomicAdd(part_g + i, ln_smem[i]);
       atomicAdd(part_b + i, ln_smem[dim + i]);
     }
-    if (threadIdx.x < 2) atomicAdd(part_s + threadIdx.x, ln_smem[2 * dim + threadIdx.x]);
+    if (threadIdx.x < 2) atomicAdd(threadIdx.x ? part_s1 : part_s, ln_smem[2 * dim + threadIdx.x]);
     return;
   }
   for (int i = threadIdx.x; i < dim; i += 256) {
@@ -1630,7 +1637,9 @@ extern "C" int ffvc_sln_fwd(const float* hl, const float* w, const float* gamma,
 static int sln_bwd_launch(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
                           const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
                           const float* rstd, const float* dres, float* dhl, float* dw, float* part_g, float* part_b,
-                          float* part_s, int64_t rows, int dim, void* stream, int acc_mode) {
+                          float* part_s, int64_t rows, int dim, void* stream, int acc_mode, float* part_s1 = nullptr,
+                          int dw_acc = 0) {
+  if (!part_s1 && part_s) part_s1 = part_s + 1;
   FFVC_CHECK_ARG(dy && hl && w && gamma && beta && gamma_s && beta_s && mean && rstd && dhl && dw && part_g && part_b &&
                      part_s, "ffvc_sln_bwd: null pointer");
   FFVC_CHECK_ARG(rows > 0 && dim > 0 && dim <= 64 * LN_MAXE, "ffvc_sln_bwd: dim=%d unsupported", dim);
@@ -1641,10 +1650,10 @@ static int sln_bwd_launch(const void* dy, int dy_dtype, const float* hl, const f
   DISPATCH_DT(dy_dtype, DYT, {
     if (dim % 4 == 0)
       hipLaunchKernelGGL((sln_bwd_kernel<4, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
-                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode);
+                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
     else
       hipLaunchKernelGGL((sln_bwd_kernel<1, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
-                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode);
+                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
   });
   FFVC_LAUNCH_CHECK();
   return 0;
@@ -1664,4 +1673,13 @@ extern "C" int ffvc_sln_bwd_acc(const void* dy, int dy_dtype, const float* hl, c
                                 float* dscalars, int64_t rows, int dim, void* stream) {
   return sln_bwd_launch(dy, dy_dtype, hl, w, gamma, beta, gamma_s, beta_s, mean, rstd, dres, dhl, dw, dgamma, dbeta,
                         dscalars, rows, dim, stream, 1);
+}
+
+extern "C" int ffvc_sln_bwd_acc2(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma,
+                                 const float* beta, const float* gamma_s, const float* beta_s, const float* mean,
+                                 const float* rstd, const float* dres, float* dhl, float* dw, int dw_accumulate, float* dgamma,
+                                 float* dbeta, float* dgamma_s, float* dbeta_s, int64_t rows, int dim, void* stream) {
+  FFVC_CHECK_ARG(dgamma_s && dbeta_s, "ffvc_sln_bwd_acc2: null pointer");
+  return sln_bwd_launch(dy, dy_dtype, hl, w, gamma, beta, gamma_s, beta_s, mean, rstd, dres, dhl, dw, dgamma, dbeta,
+                        dgamma_s, rows, dim, stream, 1, dbeta_s, dw_accumulate ? 1 : 0);
 }

@@ -607,8 +607,27 @@ def colsum_fusable(dtype, N, K, *lds):
             os.environ.get("FFVC_EPI_ROWS", "1") != "0")
 
 
+_SUMS_POOL = {}
+_SUMS_POOL_ELEMS = int(os.environ.get("FFVC_SUMS_POOL", str(1 << 18)))      # fp64 elements per pool block (2 MiB); 0: one fill per buffer
+
+
 def gn_sums_buffer(images, G, device):
-    return torch.zeros(images, G, 2, dtype=torch.float64, device=device)
+    """Zeroed fp64 [images, G, 2] accumulator for GroupNorm moments / backward statistics.  A decoder pass needs ~60 of them per step
+    (16 KiB each at batch 32): they are cut from a block that ONE fill zeroes, a fresh block when it is used up (the slices keep
+    their block alive for as long as a backward pass needs them).  Under stream capture every buffer gets its own fill, so that a
+    replay zeroes it again."""
+    n = images * G * 2
+    device = torch.device(device)
+    if _SUMS_POOL_ELEMS <= 0 or n > _SUMS_POOL_ELEMS // 4 or torch.cuda.is_current_stream_capturing():
+        return torch.zeros(images, G, 2, dtype=torch.float64, device=device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ent = _SUMS_POOL.get(key)
+    if ent is None or ent[1] + n > ent[0].numel():
+        ent = [torch.zeros(_SUMS_POOL_ELEMS, dtype=torch.float64, device=device), 0]
+        _SUMS_POOL[key] = ent
+    o = ent[1]
+    ent[1] = o + (n + 31) // 32 * 32                 # 256-byte aligned slices
+    return ent[0][o:o + n].view(images, G, 2)
 
 
 def groupnorm_fwd(x, gamma, beta, G=32, eps=1e-6, swish=True, sums=None, f8=None, f8_only=False):
@@ -663,7 +682,7 @@ def conv_gnb_ok(dy, wd, dx, x_gn, mean, rstd, gamma, beta, B, H, W, Cout_of_conv
     key = (dy.dtype, B, H, W, Cout_of_conv, Cin_of_conv)
     ok = _GNB_OK.get(key)
     if ok is None:
-        sums = torch.zeros(B, 32, 2, dtype=torch.float64, device=dy.device)
+        sums = gn_sums_buffer(B, 32, dy.device)
         ok = gemm(dy, wd, dx, B * H * W, Cin_of_conv, 9 * Cout_of_conv, ldw=9 * Cout_of_conv, x_mode=OP_CONV3X3, conv=(H, W, Cout_of_conv),
                   gnb=(x_gn, mean, rstd, gamma, beta, sums, True, H * W, Cin_of_conv // 32), probe_only=True)
         _GNB_OK[key] = ok
@@ -845,6 +864,25 @@ def sln_bwd_acc(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dgamma, dbeta, dscal
     _call("ffvc_sln_bwd_acc", dy.data_ptr(), dtype_code(dy.dtype), hl.data_ptr(), w.data_ptr(), gamma.data_ptr(),
           beta.data_ptr(), gs.data_ptr(), bs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dhl.data_ptr(),
           dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dscalars.data_ptr(), rows, dim, stream_ptr())
+    return dhl, dw
+
+
+def sln_bwd_acc2(dy, hl, w, gamma, beta, gs, bs, mean, rstd, dgamma, dbeta, dgs, dbs, dres=None, dw=None):
+    """-> (dhl, dw); dgamma / dbeta ([dim]) and the scalar gradients dgs / dbs ([1] each, anywhere) are accumulated in place; with
+    `dw` given the gradient of the modulation input is added to it (and it is returned)."""
+    _req_f32(hl, w, gamma, beta, gs, bs, mean, rstd, dgamma, dbeta, dgs, dbs, dres, dw)
+    _need_cuda(dy)
+    dim = hl.shape[-1]
+    rows = hl.numel() // dim
+    dhl = torch.empty_like(hl)
+    acc = dw is not None
+    if acc and (dw.shape != w.shape or not dw.is_contiguous()):
+        raise ValueError("sln_bwd_acc2: dw must be a contiguous tensor of w's shape")
+    if not acc:
+        dw = torch.empty_like(w)
+    _call("ffvc_sln_bwd_acc2", dy.data_ptr(), dtype_code(dy.dtype), hl.data_ptr(), w.data_ptr(), gamma.data_ptr(),
+          beta.data_ptr(), gs.data_ptr(), bs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dhl.data_ptr(),
+          dw.data_ptr(), int(acc), dgamma.data_ptr(), dbeta.data_ptr(), dgs.data_ptr(), dbs.data_ptr(), rows, dim, stream_ptr())
     return dhl, dw
 
 

@@ -432,6 +432,21 @@ def reserve_device_memory(gib=None, device=None):
         return 0.0
     blk = torch.empty(int(gib * 2 ** 30), dtype=torch.uint8, device=device)
     del blk                      # back to the allocator's free list (NOT to the driver): one segment of `gib` GiB
+    # Requests of up to 1 MiB live in a pool of their own, grown 2 MiB (one hipMalloc) at a time.  The 512-row mappers (VitGAN /
+    # x-transformer: cfg3 / cfg4) allocate thousands of such tensors per step, some of them released across streams, so that pool kept
+    # growing long after the warm-up: 2-83 new segments inside ten timed steps, and a step anywhere between 59 and 118 ms
+    # (profiles/r06_cfg3_launch_diet.txt).  Pre-grow it on the stream of the step and on the weight-gradient stream.
+    small = os.environ.get("FFVC_RESERVE_SMALL_MIB")
+    small = 1024 if small is None else int(small)
+    if small > 0:
+        streams = [(torch.cuda.current_stream(device), small)]
+        if ops._SIDE["enabled"]:
+            with torch.cuda.device(device):
+                streams.append((ops._side_stream(), small // 4))
+        for st, mib in streams:
+            with torch.cuda.stream(st):
+                hold = [torch.empty(1 << 20, dtype=torch.uint8, device=device) for _ in range(mib)]
+            del hold
     return gib
 
 

@@ -5,6 +5,8 @@ state_dict key layout as the reference classes, so released `
 checkpoints load unchanged; the arithmetic runs in ffvc HIP kernels (ops.py).  torch.nn
 layers are used ONLY as parameter holders / default initialisers — their forward is never called.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -181,18 +183,23 @@ class _VitGANBase(_MapperBase):
                              mk(blk.mlp.linear2.weight, blk.mlp.linear2.bias), blk.attn))
         self._w_mlp = mk(self.mlp.weight, self.mlp.bias)
         self._w_outp = mk(self.w_out[0].weight, self.w_out[0].bias)
+        # 16 tokens x a per-GPU batch of 32 = 512 rows: a weight gradient is 64 tiles with an 8-step reduction, a launch that never
+        # fills the chip.  The MLP's two gradients of 8 consecutive blocks go out as one grouped launch (ops.WgradGroup)
+        g = int(os.environ.get("FFVC_VIT_WGRAD_GROUP", "8"))
+        ops.group_weights([b[4] for b in self._bp], g)
+        ops.group_weights([b[5] for b in self._bp], g)
 
-    def _encode(self, hl, x):
-        """GTransformerEncoder (vitgan.py:120-164): hl, x fp32 (B, T, dim)."""
+    def _encode(self, hl, x, share=None):
+        """GTransformerEncoder (vitgan.py:120-164): hl, x fp32 (B, T, dim).  share: ops.SharedGrad collecting x's gradient."""
         cdt, f32 = self.cdt, torch.float32
         drop = self.dropout if self.training else 0.0      # after attention (:133) and inside MLP (:36-41)
         B, T, dim = x.shape
         align = 2 if cdt != torch.float32 else 1          # GEMM operands need 4-byte aligned head blocks
-        for (n1, Wqkv, Wout, n2, W1, W2, att) in self._bp:
+        for bi, (n1, Wqkv, Wout, n2, W1, W2, att) in enumerate(self._bp):
             H, dh = att.num_heads, att.dim_head
             dhp = (dh + align - 1) // align * align
             tiny = dh != 64 and K.attn_tiny_ok(T, dh)
-            y, hid = ops.sln_fork(hl, x, n1.ln.weight, n1.ln.bias, n1.gamma, n1.beta, cdt)       # vitgan.py:132
+            y, hid = ops.sln_fork(hl, x, n1.ln.weight, n1.ln.bias, n1.gamma, n1.beta, cdt, share, bi == 0)   # vitgan.py:132
             qkv = ops.linear(y, Wqkv)                                                            # (B,T,(d k h) + pad) :81
             if tiny:       # a handful of tokens: one launch per direction, read in the projection's own (d k h) order
                 o = ops.attention_tiny(qkv, H, dh, float(dim) ** -0.5, "dkh", out_ld=Wout.K)     # :82-93, scale = dim^-0.5 :65
@@ -206,7 +213,7 @@ class _VitGANBase(_MapperBase):
                     if Wout.K != H * dh:
                         o = ops.copy2d(o, B * T, H * dh, H * dh, Wout.K)
             hl = ops.linear(o.view(B, T, Wout.K), Wout, residual=hid, out_dtype=f32, drop=drop)  # w_out + hl :97,132
-            y, hid = ops.sln_fork(hl, x, n2.ln.weight, n2.ln.bias, n2.gamma, n2.beta, cdt)
+            y, hid = ops.sln_fork(hl, x, n2.ln.weight, n2.ln.bias, n2.gamma, n2.beta, cdt, share)
             hl = ops.mlp(y, W1, W2, ACT_GELU, residual=hid, out_dtype=f32, drop=drop)            # :133
         return hl
 
@@ -233,9 +240,10 @@ class Generator(_VitGANBase):
         T = self.initialize_size * 8
         B = noise.shape[0]
         x = ops.linear(ops.cast(noise.float(), cdt), self._w_mlp, out_dtype=f32).view(B, T, self.dim)   # vitgan.py:254
-        hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B), x)                                      # :255
+        share = ops.SharedGrad() if self._bp else None
+        hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B), x, share)                               # :255
         s = self.sln_norm
-        y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt)                        # :256
+        y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt, share)                 # :256
         out = ops.linear(y, self._w_outp, out_dtype=f32)                                                # :257
         return out.view(B, self.out_channels, T, T)                                                     # raw view :258-259
 
@@ -266,9 +274,10 @@ class SimpleGenerator(_VitGANBase):
         inp = ops.linear(nz, self._w_inp, out_dtype=f32)                                                # vitgan.py:297
         x = ops.linear(nz, self._w_mlp, out_dtype=f32).view(B, N, self.dim)                             # :298
         inp_emb = ops.transpose_last2(inp.view(B, self.dim, N))                                         # :299
-        hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B, inp_emb), x)                            # :300
+        share = ops.SharedGrad() if self._bp else None
+        hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B, inp_emb), x, share)                      # :300
         s = self.sln_norm
-        y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt)
+        y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt, share)
         out = ops.linear(y, self._w_outp, out_dtype=f32)
         return out.view(B, self.size, self.size, self.out_channels).permute(0, 3, 1, 2)                 # :303
 

@@ -914,7 +914,7 @@ class _Conv3x3Fn(Function):
                     # the gradient this dgrad stores is the one GroupNorm's backward starts from: accumulate its statistics here
                     # (2 of that backward's 5 reads and its first launch), hand them over on the tensor
                     xg, gam, bet, mean, rstd, sw = gnb
-                    sums = torch.zeros(B, 32, 2, dtype=torch.float64, device=dy.device)
+                    sums = K.gn_sums_buffer(B, 32, dy.device)
                     K.gemm(dyt, P.wd, dxu, B * H * W, Cin, 9 * P.Cout, ldw=9 * P.Cout, x_mode=K.OP_CONV3X3, conv=(H, W, P.Cout),
                            gnb=(xg, mean, rstd, gam, bet, sums, sw, H * W, Cin // 32))
                     dxu._ffvc_gnb_sums = (sums, mean)
@@ -1382,7 +1382,8 @@ class _SLNForkFn(Function):
     """Self-modulated LayerNorm (vitgan.py:8-21), fork form: -> (gamma_s*w*LN(hl) + beta_s*w, identity alias of hl)."""
 
     @staticmethod
-    def forward(ctx, hl, w, gamma, beta, gs, bs, out_dtype):
+    def forward(ctx, hl, w, gamma, beta, gs, bs, out_dtype, share=None, last=False):
+        ctx.share, ctx.last = share, last
         hl, w = _contig(hl), _contig(w)
         g, b, gsd, bsd = gamma.detach(), beta.detach(), gs.detach().reshape(1), bs.detach().reshape(1)
         y, mean, rstd = K.sln_fwd(hl, w, g, b, gsd, bsd, out_dtype)
@@ -1398,24 +1399,38 @@ class _SLNForkFn(Function):
     def backward(ctx, dy, dres):
         hl, w, g, b, gsd, bsd, mean, rstd = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None, None, None, None
+            return dres, None, None, None, None, None, None, None, None
         if dres is not None:
             dres = _as(_contig(dres), torch.float32)
         if ctx.params is not None:              # gradients straight into the flat bucket (see _LNForkFn)
             gamma, beta, gs, bs = ctx.params
-            sc = torch.zeros(2, dtype=torch.float32, device=hl.device)
-            dhl, dw = K.sln_bwd_acc(_contig(dy), hl, w, g, b, gsd, bsd, mean, rstd, _grad_buf(gamma), _grad_buf(beta), sc,
-                                    dres=dres)
-            _grad_buf(gs).view(-1).add_(sc[0:1])          # the two scalar parameters live apart in the bucket
-            _grad_buf(bs).view(-1).add_(sc[1:2])
+            sh = ctx.share
+            # (the two scalar parameters live apart in the bucket: ffvc_sln_bwd_acc2 takes one address each)
+            dhl, dw = K.sln_bwd_acc2(_contig(dy), hl, w, g, b, gsd, bsd, mean, rstd, _grad_buf(gamma), _grad_buf(beta),
+                                     _grad_buf(gs).view(-1), _grad_buf(bs).view(-1), dres=dres, dw=None if sh is None else sh.buf)
             gamma._ffvc_arena.grad_written(gamma, beta, gs, bs)
-            return dhl, dw, None, None, None, None, None
+            if sh is not None:                  # one running sum for the modulation input; the consumer whose backward runs last hands it on
+                sh.buf = None if ctx.last else dw
+                if not ctx.last:
+                    dw = None
+            return dhl, dw, None, None, None, None, None, None, None
         dhl, dw, dg, db, dgs, dbs = K.sln_bwd(_contig(dy), hl, w, g, b, gsd, bsd, mean, rstd, dres=dres)
-        return dhl, dw, dg, db, dgs.view(ctx.sshape), dbs.view(ctx.sshape), None
+        return dhl, dw, dg, db, dgs.view(ctx.sshape), dbs.view(ctx.sshape), None, None, None
 
 
-def sln_fork(hl, w, ln_weight, ln_bias, gamma_s, beta_s, out_dtype):
-    return _SLNForkFn.apply(hl, w, ln_weight, ln_bias, gamma_s, beta_s, out_dtype)
+class SharedGrad:
+    """Running gradient sum of a tensor that many nodes of one forward pass consume (the modulation input of every SLN in a VitGAN
+    generator, vitgan.py:132,256).  A fresh holder per forward pass; the consumers' backward kernels add into `buf`, and the one
+    that autograd runs LAST (`last=True`: the first consumer of the forward pass, which everything later depends on) returns it."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+def sln_fork(hl, w, ln_weight, ln_bias, gamma_s, beta_s, out_dtype, share=None, last=False):
+    return _SLNForkFn.apply(hl, w, ln_weight, ln_bias, gamma_s, beta_s, out_dtype, share, last)
 
 
 class _TransposePadFn(Function):

@@ -273,6 +273,13 @@ int ffvc_sln_bwd_acc(const void* dy, int dy_dtype, const float* hl, const float*
                      const float* gamma_s, const float* beta_s, const float* mean, const float* rstd, const float* dres,
                      float* dhl, float* dw, float* dgamma, float* dbeta, float* dscalars, int64_t rows, int dim,
                      void* stream);
+/* Same, for parameters that live apart in a flat gradient bucket: the two scalar gradients go to separate addresses, and with
+ * dw_accumulate != 0 the gradient of the modulation input is ADDED to dw (vitgan.py:132,256: every SLN of the generator is
+ * modulated by the same w, so its gradient is one running sum instead of 65 tensors + 64 additions). */
+int ffvc_sln_bwd_acc2(const void* dy, int dy_dtype, const float* hl, const float* w, const float* gamma, const float* beta,
+                      const float* gamma_s, const float* beta_s, const float* mean, const float* rstd, const float* dres,
+                      float* dhl, float* dw, int dw_accumulate, float* dgamma, float* dbeta, float* dgamma_s, float* dbeta_s,
+                      int64_t rows, int dim, void* stream);
 
 /* GroupNorm(G groups, affine) on NHWC [B, HW, C] with optional fused swish x*sigmoid(x):
  * taming Normalize()/nonlinearity() [upstream taming-transformers 0.0.6, SURVEY.md App. A.1].

@@ -227,6 +227,27 @@ def test_dword_aligned_leading_dims(cuda, dt):
     assert _rel(S.view(2, H, T, T), torch.einsum("bthd,bshd->bhts", q, k)) < 2e-5
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,ldx,ldw", [(3060, 1024, 3064, 1024), (1024, 1020, 1024, 1024), (3060, 1020, 3064, 1024), (3060, 1024, 3060, 1024)])
+def test_padded_reduction_major_operands(cuda, dt, M, N, ldx, ldw):
+    """The VitGAN blocks' qkv / w_out weight gradients (vitgan.py:62-97: 6 heads x 170): un-padded fp32 gradients [3060, 1024] /
+    [1024, 1020] from operands whose ROWS are padded to 3064 / 1024.  The LDS-DMA kernel reads the last 8-column chunk in full
+    (pad columns hold garbage here: NaN, to prove they reach no stored output); without room in the row stride the launch takes
+    the register-staged kernel.  Both must agree with fp64."""
+    rows = 512
+    dy = _mk((rows, ldx), dt, cuda, 1)
+    x = _mk((rows, ldw), dt, cuda, 2)
+    if ldx > M:
+        dy[:, M:] = float("nan")
+    if ldw > N:
+        x[:, N:] = float("nan")
+    wg = torch.ones(M, N, dtype=torch.float32, device=cuda)
+    K.gemm(dy, x, wg, M, N, rows, ldx=ldx, ldw=ldw, x_mode=K.OP_TRANS, w_mode=K.OP_TRANS, flags=K.F_ACCUM_OUT)
+    ref = dy[:, :M].double().T @ x[:, :N].double() + 1.0
+    assert torch.isfinite(wg).all()
+    assert _rel(wg, ref) < 2e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_splitk_slabs(cuda, dt):
     M, N, K_ = 256, 384, 4096

@@ -679,6 +679,41 @@ def test_grouped_weight_gradients_equal_the_per_layer_launches(cuda):
         assert _relrms(g4[k], g0[k]) < 2e-5, (k, _relrms(g4[k], g0[k]))
 
 
+def _vitgan_grads(group, seed=7):
+    """Full-width VitGAN generator (vitgan.py:221-260 at cfg3's geometry: dim 1024, 6 heads x 170, 16 tokens, 32 samples = 512 rows),
+    9 blocks: gradients of loss = sum(out * r)."""
+    from feed_forward_vqgan_clip_amd import ops
+    old = ops._WGRAD_GROUP
+    ops._WGRAD_GROUP = group
+    try:
+        torch.manual_seed(seed)
+        net = Generator(initialize_size=2, out_channels=4, input_dim=64, dim=1024, num_heads=6, blocks=9).cuda().prepare(F16)
+        x = torch.randn(32, 64, generator=torch.Generator().manual_seed(seed + 1)).cuda().requires_grad_(True)
+        out = net(x)
+        r = torch.randn(*out.shape, generator=torch.Generator().manual_seed(seed + 2)).cuda()
+        net._ffvc_arena.zero_grad()
+        (out * r).sum().backward()
+        torch.cuda.synchronize()
+        grouped = sum(1 for b in net._bp for W in (b[4], b[5]) if W.group is not None)
+        g = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        g["__dx"] = x.grad.detach().clone()
+        return g, grouped
+    finally:
+        ops._WGRAD_GROUP = old
+
+
+def test_vitgan_grouped_weight_gradients_equal_the_per_layer_launches(cuda):
+    """The MLP weight gradients of 8 consecutive VitGAN blocks in one launch (a ninth block stays alone) against one launch per layer:
+    same products, different fp32 summation order; every other gradient (the shared modulation input's running sum, the scalar
+    SLN parameters written straight into the bucket) is produced by the same kernels in both runs and must be identical."""
+    g8, n8 = _vitgan_grads(4)
+    g0, n0 = _vitgan_grads(0)
+    assert n8 == 16 and n0 == 16          # marked either way; FFVC_WGRAD_GROUP <= 1 only stops ops._wgrad from deferring
+    for k in g0:
+        assert torch.isfinite(g8[k]).all(), k
+        assert _relrms(g8[k], g0[k]) < 2e-5, (k, _relrms(g8[k], g0[k]))
+
+
 def test_partly_filled_weight_gradient_group_is_flushed(cuda):
     """A group that does not fill (a backward pass that misses some of its layers, or direct calls outside autograd) goes out when
     the side stream is joined: consecutive members as a smaller grouped launch, a gap in the run as per-layer launches."""
