@@ -834,27 +834,35 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
                                                           int Ss, int cutn, int P, float m0, float m1, float m2, float s0,
                                                           float s1, float s2) {
   const int gw = S / P;
-  const int64_t n_px = (int64_t)cutn * B * S * S;
   const int64_t per_img = (int64_t)3 * S * S;
   const float mean[3] = {m0, m1, m2}, istd[3] = {1.0f / s0, 1.0f / s1, 1.0f / s2};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_px; i += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(i % S);
-    int64_t t = i / S;
-    const int oy = (int)(t % S);
-    const int n = (int)(t / S);
-    const int b = n % B;
+  // one cutout per blockIdx.y: its 39 parameters (two warps, colour matrix + offset, jitter, erase box) are wave-uniform, so they
+  // travel in scalar registers and the jitter's operator order is a scalar branch (r6: 1.19 -> 0.86 ms isolated at cfg2's 512 cutouts)
+  const int n = blockIdx.y;
+  const int b = n % B;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < S * S; i += gridDim.x * 256) {
+    const int oy = i / S;
+    const int ox = i - oy * S;
     AugTaps taps;
     aug_taps<SEQ>(pinv + n * 9, ainv + n * 6, ox, oy, Ss, taps);
     const int* er = erase + n * 4;
     const bool erased = ox >= er[0] && ox < er[2] && oy >= er[1] && oy < er[3];
     float rgb[3];
+#if defined(FFVC_AUGF_EXP) && FFVC_AUGF_EXP == 6      // timing experiment (wrong results): no source gathers
+    rgb[0] = taps.w[0] + taps.s[0].wx; rgb[1] = taps.w[1] + taps.s[1].wy; rgb[2] = taps.w[2] + taps.w[3] + taps.s[3].wx;
+#else
     aug_gather<SEQ>(pooled + (int64_t)b * 3 * Ss * Ss, Ss, taps, rgb);
+#endif
     const float* cm = cmat + n * 9;
     const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
     float col[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) col[c] = cm[c * 3] * rgb[0] + cm[c * 3 + 1] * rgb[1] + cm[c * 3 + 2] * rgb[2] + (coff ? coff[n * 3 + c] : 0.0f);
+#if defined(FFVC_AUGF_EXP) && FFVC_AUGF_EXP == 5      // timing experiment (wrong results): no colour jitter
+    if (cj && cj[n * 8] == 12345.0f && !erased) {
+#else
     if (cj && cj[n * 8] != 0.0f && !erased) {      // kornia ColorJitter (hsv round trips, clamps, random order): augment_cj.h
+#endif
       float J[3][3], o[3];
       ffvc_cj::color_jitter(cj + n * 8, col, o, J);
       col[0] = o[0];
@@ -864,8 +872,13 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float v = erased ? 0.0f : col[c];
+#if !(defined(FFVC_AUGF_EXP) && FFVC_AUGF_EXP == 7)   // 7: timing experiment (wrong results): no noise read
       if (noise) v += facs[n] * noise[(int64_t)n * per_img + ((int64_t)c * S + oy) * S + ox];
+#endif
       const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)c * P * P + ky * P + kx;
+#if defined(FFVC_AUGF_EXP) && FFVC_AUGF_EXP == 8      // timing experiment (wrong results): no store
+      if (v == 12345.678f)
+#endif
       ElemTraits<OT>::store(out + (int64_t)n * per_img + prow, (v - mean[c]) * istd[c]);
     }
   }
@@ -937,7 +950,12 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const GT* __restrict__
 // footprint (bounding box of the taps, ds_add_f32) and then issues ONE global atomic per touched source pixel and channel instead
 // of four per output pixel and channel (~3x fewer L2 atomics; 308 M per step at cfg2 before).  Tiles whose footprint does not
 // fit the LDS image (strong perspective) fall back to direct global atomics.
-constexpr int AUGT = 16, AUG_CAP = 2048;      // tile side; source pixels of the LDS image (x 3 channels x 4 B = 24 KiB)
+// Tile shape: 16 x 16 output pixels.  (32 x 8 — a half-wave per output row, consecutive LDS words — measured 1 % faster at cfg2, r6:
+// the 48 accumulations per thread are bound by their VALU / exec-mask work, not by bank conflicts; -DFFVC_AUGT_X=32 rebuilds it)
+#ifndef FFVC_AUGT_X
+#define FFVC_AUGT_X 16
+#endif
+constexpr int AUGTX = FFVC_AUGT_X, AUGTY = 256 / AUGTX, AUG_CAP = 2048;      // source pixels of the LDS image (x 3 channels x 4 B = 24 KiB)
 template <typename GT, bool SEQ = false>
 __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __restrict__ gout, const float* __restrict__ pinv,
                                                                 const float* __restrict__ ainv, const float* __restrict__ cmat,
@@ -949,9 +967,9 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
   __shared__ int bb[4];
   constexpr int NK = SEQ ? 4 : 1;
   const int n = blockIdx.y, b = n % B;
-  const int tiles_x = (S + AUGT - 1) / AUGT;
+  const int tiles_x = (S + AUGTX - 1) / AUGTX;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int ox = tx * AUGT + (threadIdx.x & (AUGT - 1)), oy = ty * AUGT + (threadIdx.x >> 4);
+  const int ox = tx * AUGTX + (threadIdx.x & (AUGTX - 1)), oy = ty * AUGTY + (threadIdx.x / AUGTX);
   const int gw = S / P;
   const int64_t per_img = (int64_t)3 * S * S;
   const float istd[3] = {1.0f / s0, 1.0f / s1, 1.0f / s2};
@@ -987,7 +1005,11 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
       g[c] = ElemTraits<GT>::load(gout + (int64_t)n * per_img + prow) * istd[c];
     }
     const float* cm = cmat + n * 9;
+#if defined(FFVC_AUGB_EXP) && FFVC_AUGB_EXP == 3      // timing experiment (wrong results): no colour-jitter recompute
+    if (cj && cj[n * 8] == 12345.0f) {
+#else
     if (cj && cj[n * 8] != 0.0f) {
+#endif
       float rgb[3], col[3];
       aug_gather<SEQ>(pooled + (int64_t)b * 3 * Ss * Ss, Ss, taps, rgb);
 #pragma unroll
@@ -1000,13 +1022,33 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) gc[c] = cm[c] * g[0] + cm[3 + c] * g[1] + cm[6 + c] * g[2];          // transpose of the colour matrix
+  }
+  {
+    // bounding box of the tile's source footprint: reduced inside each wave first, ONE LDS atomic per wave and bound.  (Per-lane
+    // atomics on the four shared words serialise 64 lanes x 4 taps each: 0.6 of the kernel's 1.9 ms at cfg2, r6)
+    int mnx = 1 << 30, mny = 1 << 30, mxx = -1, mxy = -1;
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      if (taps.w[k] == 0.0f) continue;
-      atomicMin(&bb[0], taps.s[k].x0);
-      atomicMin(&bb[1], taps.s[k].y0);
-      atomicMax(&bb[2], taps.s[k].x0 + 1);
-      atomicMax(&bb[3], taps.s[k].y0 + 1);
+      for (int k = 0; k < NK; ++k) {
+        if (taps.w[k] == 0.0f) continue;
+        mnx = min(mnx, taps.s[k].x0);
+        mny = min(mny, taps.s[k].y0);
+        mxx = max(mxx, taps.s[k].x0 + 1);
+        mxy = max(mxy, taps.s[k].y0 + 1);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mnx = min(mnx, __shfl_xor(mnx, o));
+      mny = min(mny, __shfl_xor(mny, o));
+      mxx = max(mxx, __shfl_xor(mxx, o));
+      mxy = max(mxy, __shfl_xor(mxy, o));
+    }
+    if ((threadIdx.x & 63) == 0 && mxx >= 0) {
+      atomicMin(&bb[0], mnx);
+      atomicMin(&bb[1], mny);
+      atomicMax(&bb[2], mxx);
+      atomicMax(&bb[3], mxy);
     }
   }
   __syncthreads();
@@ -1014,7 +1056,11 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
   if (bb[2] < 0) return;                                   // nothing live in this tile
   float* dimg = dpooled + (int64_t)b * 3 * Ss * Ss;
   if (bw * bh <= AUG_CAP) {
+#if defined(FFVC_AUGB_EXP) && FFVC_AUGB_EXP == 4      // timing experiment (wrong results): no LDS accumulation
+    if (live && gc[0] == 12345.0f) {
+#else
     if (live) {
+#endif
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         if (taps.w[k] == 0.0f) continue;
@@ -1040,7 +1086,13 @@ __global__ __launch_bounds__(256) void augment_bwd_tiled_kernel(const GT* __rest
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float v = img[c * AUG_CAP + i];
+#if defined(FFVC_AUGB_EXP) && FFVC_AUGB_EXP == 1      // timing experiment (wrong results): plain stores instead of the global atomics
+        if (v != 0.0f) dimg[(int64_t)c * Ss * Ss + (int64_t)(by0 + yy) * Ss + bx0 + xx] = v;
+#elif defined(FFVC_AUGB_EXP) && FFVC_AUGB_EXP == 2    // timing experiment (wrong results): no flush at all
+        if (v == 12345.678f) dimg[(int64_t)c * Ss * Ss + (int64_t)(by0 + yy) * Ss + bx0 + xx] = v;
+#else
         if (v != 0.0f) atomicAdd(dimg + (int64_t)c * Ss * Ss + (int64_t)(by0 + yy) * Ss + bx0 + xx, v);
+#endif
       }
     }
   } else if (live) {
@@ -1542,13 +1594,14 @@ static int augment_fwd_impl(bool seq, const float* pooled, const float* pinv, co
   FFVC_CHECK_ARG(B > 0 && S > 1 && S_src > 1 && cutn > 0 && patch > 0 && S % patch == 0, "ffvc_augment_fwd: bad geometry");
   FFVC_CHECK_ARG((noise == nullptr) == (facs == nullptr), "ffvc_augment_fwd: noise and facs go together");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t n = (int64_t)cutn * B * S * S;
+  FFVC_CHECK_ARG((int64_t)cutn * B <= 65535, "ffvc_augment_fwd: more than 65535 cutouts per launch");
+  const dim3 grid((S * S + 255) / 256, cutn * B);
   if (seq) {
-    DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT, true>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
+    DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT, true>), grid, dim3(256), 0, st, pooled,
                                                   pinv, ainv, cmat, erase, noise, facs, coff, cj, (OT*)out, B, S, S_src, cutn, patch, mean_r,
                                                   mean_g, mean_b, std_r, std_g, std_b));
   } else {
-    DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT, false>), dim3(ew_grid(n, 256)), dim3(256), 0, st, pooled,
+    DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((augment_fwd_kernel<OT, false>), grid, dim3(256), 0, st, pooled,
                                                   pinv, ainv, cmat, erase, noise, facs, coff, cj, (OT*)out, B, S, S_src, cutn, patch, mean_r,
                                                   mean_g, mean_b, std_r, std_g, std_b));
   }
@@ -1591,7 +1644,7 @@ static int augment_bwd_impl(bool seq, const void* gout, int g_dtype, const float
     const char* e = getenv("FFVC_AUG_BWD_TILED");
     tiled = e ? atoi(e) : 1;
   }
-  const int tiles = ((S + AUGT - 1) / AUGT) * ((S + AUGT - 1) / AUGT);
+  const int tiles = ((S + AUGTX - 1) / AUGTX) * ((S + AUGTY - 1) / AUGTY);
   if (tiled && (int64_t)cutn * B <= 65535) {
     if (seq) {
       DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((augment_bwd_tiled_kernel<GT, true>), dim3(tiles, cutn * B), dim3(256), 0, st, (const GT*)gout, pinv,
