@@ -427,7 +427,8 @@ int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, float* dxr,
  * ViT patch rows.  All random draws are explicit per-cutout parameters (N = cutn*B rows, cut-major like repeat()):
  * pinv [N,9] inverse perspective homography, ainv [N,6] inverse affine (pixel units), cmat [N,9] RGB colour matrix,
  * erase [N,4] int32 rectangle x0,y0,x1,y1 (x1 <= x0: none).  kornia 0.5.10 itself is absent: parity unpinned.
- * The backward scatters into dpooled [B,3,S,S] (zeroed inside); chain it with ffvc_cutouts_bwd(cutn 1, patch S). */
+ * The backward scatters into dpooled [B,3,S,S] (zeroed inside); chain it with ffvc_cutouts_bwd(cutn 1, patch S).
+ * One launch covers at most 65535 cutouts (cutn * B; one cutout per grid row): FFVC_E_BADARG beyond that — split the batch. */
 int ffvc_augment_fwd(const float* pooled, const float* pinv, const float* ainv, const float* cmat, const float* coff /* (N,3) colour offset added after cmat, may be NULL */,
                      const float* cj /* (N,8) kornia ColorJitter parameters [on, brightness, contrast, saturation, hue (turns), order code, -, -] applied after cmat, may be NULL */,
                      const int32_t* erase, const float* noise, const float* facs, void* out, int out_dtype, int B, int S, int S_src, int cutn,
