@@ -27,6 +27,7 @@ F_GN_SUMS = 512
 F_COLSUM = 1024
 F_SPLITK_INKERNEL = 4096
 F_GNB_SUMS = 8192
+F_VQ_ARGMIN = 16384
 F_AUX_ACTGRAD = 2048
 
 
@@ -100,6 +101,9 @@ class GemmDesc(Structure):
         ("gnb_beta", c_void_p),
         ("gnb_sums", c_void_p),
         ("gnb_swish", c_int32),
+        ("vq_xn", c_void_p),
+        ("vq_cn", c_void_p),
+        ("vq_out", c_void_p),
     ]
 
 

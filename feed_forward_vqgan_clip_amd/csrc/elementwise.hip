@@ -321,8 +321,13 @@ __global__ __launch_bounds__(64) void eot_gather_kernel(const XT* __restrict__ x
 // and written directly as ViT patch rows: out[n, py*gw+px, ch*P*P + ky*P + kx] (the im2col of the
 // stride-P patch-embedding conv, cloob.py:224,237), so the patch GEMM reads it K-major.
 // xr is NHWC fp32 [B, H, W, 3]; noise is NCHW [cutn*B, 3, cut, cut] fp32 or NULL.
-__device__ __forceinline__ int apool_start(int o, int in, int out) { return (int)(((int64_t)o * in) / out); }
-__device__ __forceinline__ int apool_end(int o, int in, int out) { return (int)((((int64_t)(o + 1)) * in + out - 1) / out); }
+// (32-bit unsigned arithmetic: a 64-bit division is ~150 instructions on this ISA and the backward does two dozen of them per input element;
+// exact for in, out <= 32768 — the launchers check)
+__device__ __forceinline__ int apool_start(int o, int in, int out) { return (int)(((uint32_t)o * (uint32_t)in) / (uint32_t)out); }
+__device__ __forceinline__ int apool_end(int o, int in, int out) {
+  return (int)(((uint32_t)(o + 1) * (uint32_t)in + (uint32_t)out - 1u) / (uint32_t)out);
+}
+constexpr int APOOL_MAX = 32768;
 
 template <typename OT>
 __global__ __launch_bounds__(256) void cutouts_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ noise,
@@ -332,13 +337,25 @@ __global__ __launch_bounds__(256) void cutouts_fwd_kernel(const float* __restric
   const int gw = cut / P;
   const int64_t n = (int64_t)B * 3 * cut * cut;
   const int64_t per_img = (int64_t)3 * cut * cut;
+  const bool small = n <= 0x7fffffffll;      // 32-bit index arithmetic whenever the tensor allows it
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(i % cut);
-    int64_t t = i / cut;
-    const int oy = (int)(t % cut);
-    t /= cut;
-    const int ch = (int)(t % 3);
-    const int b = (int)(t / 3);
+    int ox, oy, ch, b;
+    if (small) {
+      uint32_t t = (uint32_t)i;
+      ox = (int)(t % (uint32_t)cut);
+      t /= (uint32_t)cut;
+      oy = (int)(t % (uint32_t)cut);
+      t /= (uint32_t)cut;
+      ch = (int)(t % 3u);
+      b = (int)(t / 3u);
+    } else {
+      ox = (int)(i % cut);
+      int64_t t = i / cut;
+      oy = (int)(t % cut);
+      t /= cut;
+      ch = (int)(t % 3);
+      b = (int)(t / 3);
+    }
     const int y0 = apool_start(oy, H, cut), y1 = apool_end(oy, H, cut);
     const int x0 = apool_start(ox, W, cut), x1 = apool_end(ox, W, cut);
     float sum = 0.f, mx = -INFINITY;
@@ -371,22 +388,49 @@ __global__ __launch_bounds__(256) void cutouts_bwd_kernel(const float* __restric
   const int gw = cut / P;
   const int64_t n = (int64_t)B * H * W * 3;
   const int64_t per_img = (int64_t)3 * cut * cut;
+  const bool small = n <= 0x7fffffffll;      // 32-bit index arithmetic whenever the tensor allows it
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int ch = (int)(i % 3);
-    int64_t t = i / 3;
-    const int x = (int)(t % W);
-    t /= W;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
+    int ch, x, y, b;
+    if (small) {
+      uint32_t t = (uint32_t)i;
+      ch = (int)(t % 3u);
+      t /= 3u;
+      x = (int)(t % (uint32_t)W);
+      t /= (uint32_t)W;
+      y = (int)(t % (uint32_t)H);
+      b = (int)(t / (uint32_t)H);
+    } else {
+      ch = (int)(i % 3);
+      int64_t t = i / 3;
+      x = (int)(t % W);
+      t /= W;
+      y = (int)(t % H);
+      b = (int)(t / H);
+    }
     const float istd = 1.0f / (ch == 0 ? s0 : (ch == 1 ? s1 : s2));
     float acc = 0.f;
-    const int oyc = (int)(((int64_t)y * cut) / H), oxc = (int)(((int64_t)x * cut) / W);
+    const int oyc = (int)(((uint32_t)y * (uint32_t)cut) / (uint32_t)H), oxc = (int)(((uint32_t)x * (uint32_t)cut) / (uint32_t)W);
+    // the (up to three) candidate windows per axis; the column candidates once, not once per row candidate
+    int cx0[3], cx1[3], cpx[3], ckx[3];
+    bool cin[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ox = oxc - 1 + j;
+      const bool ok = ox >= 0 && ox < cut;
+      cx0[j] = ok ? apool_start(ox, W, cut) : 0;
+      cx1[j] = ok ? apool_end(ox, W, cut) : 0;
+      cin[j] = ok && x >= cx0[j] && x < cx1[j];
+      cpx[j] = ok ? ox / P : 0;
+      ckx[j] = ox - cpx[j] * P;
+    }
     for (int oy = max(0, oyc - 1); oy <= min(cut - 1, oyc + 1); ++oy) {
       const int y0 = apool_start(oy, H, cut), y1 = apool_end(oy, H, cut);
       if (y < y0 || y >= y1) continue;
-      for (int ox = max(0, oxc - 1); ox <= min(cut - 1, oxc + 1); ++ox) {
-        const int x0 = apool_start(ox, W, cut), x1 = apool_end(ox, W, cut);
-        if (x < x0 || x >= x1) continue;
+      const int py = oy / P, ky = oy - py * P;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (!cin[j]) continue;
+        const int x0 = cx0[j], x1 = cx1[j];
         // locate the (first) argmax of this window
         float mx = -INFINITY;
         int ay = y0, ax = x0;
@@ -401,8 +445,7 @@ __global__ __launch_bounds__(256) void cutouts_bwd_kernel(const float* __restric
           }
         float w = 0.5f / (float)((y1 - y0) * (x1 - x0));
         if (ay == y && ax == x) w += 0.5f;
-        const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
-        const int64_t prow = (int64_t)(py * gw + px) * (3 * P * P) + (int64_t)ch * P * P + ky * P + kx;
+        const int64_t prow = (int64_t)(py * gw + cpx[j]) * (3 * P * P) + (int64_t)ch * P * P + ky * P + ckx[j];
         float g = 0.f;
         for (int c = 0; c < cutn; ++c) g += ElemTraits<GT>::load(gout + ((int64_t)c * B + b) * per_img + prow);
         acc += g * w;
@@ -1353,6 +1396,7 @@ extern "C" int ffvc_cutouts_fwd(const float* xr, const float* noise, const float
   FFVC_CHECK_ARG(xr && out, "ffvc_cutouts_fwd: null pointer");
   FFVC_CHECK_ARG(B > 0 && H > 0 && W > 0 && cut > 0 && cutn > 0 && patch > 0 && cut % patch == 0,
                  "ffvc_cutouts_fwd: bad geometry cut=%d patch=%d", cut, patch);
+  FFVC_CHECK_ARG(H <= APOOL_MAX && W <= APOOL_MAX && cut <= APOOL_MAX, "ffvc_cutouts_fwd: sides above 32768 are not supported");
   FFVC_CHECK_ARG((noise == nullptr) == (facs == nullptr), "ffvc_cutouts_fwd: noise and facs go together");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)B * 3 * cut * cut;
@@ -1368,6 +1412,7 @@ extern "C" int ffvc_cutouts_bwd(const float* xr, const void* gout, int g_dtype, 
   FFVC_CHECK_ARG(xr && gout && dxr, "ffvc_cutouts_bwd: null pointer");
   FFVC_CHECK_ARG(B > 0 && H > 0 && W > 0 && cut > 0 && cutn > 0 && patch > 0 && cut % patch == 0 && H >= cut && W >= cut,
                  "ffvc_cutouts_bwd: bad geometry");
+  FFVC_CHECK_ARG(H <= APOOL_MAX && W <= APOOL_MAX && cut <= APOOL_MAX, "ffvc_cutouts_bwd: sides above 32768 are not supported");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)B * H * W * 3;
   DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((cutouts_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0, st, xr,
@@ -1684,6 +1729,7 @@ extern "C" int ffvc_augment_seq_bwd(const void* gout, int g_dtype, const float* 
 extern "C" int ffvc_avgpool_patches_fwd(const float* x, void* out, int out_dtype, int N, int S, int So, int patch, float mean_r,
                                         float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream) {
   FFVC_CHECK_ARG(x && out && N > 0 && S > 0 && So > 0 && patch > 0 && So % patch == 0, "ffvc_avgpool_patches_fwd: bad args");
+  FFVC_CHECK_ARG(S <= APOOL_MAX && So <= APOOL_MAX, "ffvc_avgpool_patches_fwd: sides above 32768 are not supported");
   const int64_t n = (int64_t)N * 3 * So * So;
   DISPATCH_DT(out_dtype, OT, hipLaunchKernelGGL((avgpool_patches_fwd_kernel<OT>), dim3(ew_grid(n, 256)), dim3(256), 0,
                                                 (hipStream_t)stream, x, (OT*)out, N, S, So, patch, mean_r, mean_g, mean_b,
@@ -1695,6 +1741,7 @@ extern "C" int ffvc_avgpool_patches_fwd(const float* x, void* out, int out_dtype
 extern "C" int ffvc_avgpool_patches_bwd(const void* gout, int g_dtype, float* dx, int N, int S, int So, int patch, float std_r,
                                         float std_g, float std_b, void* stream) {
   FFVC_CHECK_ARG(gout && dx && N > 0 && S > 0 && So > 0 && patch > 0 && So % patch == 0, "ffvc_avgpool_patches_bwd: bad args");
+  FFVC_CHECK_ARG(S <= APOOL_MAX && So <= APOOL_MAX, "ffvc_avgpool_patches_bwd: sides above 32768 are not supported");
   const int64_t n = (int64_t)N * 3 * S * S;
   DISPATCH_DT(g_dtype, GT, hipLaunchKernelGGL((avgpool_patches_bwd_kernel<GT>), dim3(ew_grid(n, 256)), dim3(256), 0,
                                               (hipStream_t)stream, (const GT*)gout, dx, N, S, So, patch, std_r, std_g, std_b));

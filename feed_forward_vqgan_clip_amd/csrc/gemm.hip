@@ -590,6 +590,11 @@ extern "C" int ffvc_gemm(const ffvc_gemm_desc* dp, void* stream) {
   }
   FFVC_CHECK_ARG(!(d.flags & FFVC_F_SPLITK_INKERNEL) || d.split_k == 1,
                  "ffvc_gemm: FFVC_F_SPLITK_INKERNEL: this shape / alignment does not take an LDS-DMA kernel that implements it");
+  if (d.flags & FFVC_F_VQ_ARGMIN) {
+    ffvc_set_error("ffvc_gemm: FFVC_F_VQ_ARGMIN: needs 16-bit K-major operands on the 256x256 LDS-DMA kernel (16-byte aligned rows, K %% 8 == 0, "
+                   "batch 1, split_k 1, alpha 1, no bias / residual / aux / activation) and vq_xn, vq_cn, vq_out (M=%d N=%d K=%d)", d.M, d.N, d.K);
+    return FFVC_E_UNSUPPORTED;
+  }
   if (d.flags & FFVC_F_GNB_SUMS) {
     ffvc_set_error("ffvc_gemm: FFVC_F_GNB_SUMS: this launch does not take the pipelined row-tile convolution (ask ffvc_gemm_gnb_probe first)");
     return FFVC_E_UNSUPPORTED;

@@ -593,6 +593,15 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
       return FFVC_E_BADARG;
     }
   }
+  if (d.flags & FFVC_F_VQ_ARGMIN) {
+    // vector-quantisation distances with the argmin folded in: the 256x256 ring kernel only, whatever tile the heuristic would pick
+    // (launch2 refuses — 0 — when the operands cannot take its buffer-descriptor form)
+    const bool ok = d.x_mode == FFVC_OP_KMAJOR && d.w_mode == FFVC_OP_KMAJOR && d.batch == 1 && d.split_k <= 1 && d.slab_stride == 0 &&
+                    d.alpha == 1.0f && !d.bias && !d.residual && !d.aux && d.act == FFVC_ACT_NONE && d.kseg == 0 && d.x_mi == 0 &&
+                    d.vq_xn && d.vq_cn && d.vq_out &&
+                    !(d.flags & ~(FFVC_F_VQ_ARGMIN | FFVC_F_OUT_F32));
+    return ok ? ffvc_gemm2_launch_kk(d, st, vec_ok, zero, 512) : 0;
+  }
   // tile selection: FFVC_GEMM2_BM = 0 (disable this path) | 128 | 256 | 512 (= 256x256) | unset (heuristic)
   const int env_bm = opt_value(g_opt_gemm2_tile, "FFVC_GEMM2_BM", 1);
   if (env_bm == 0) return 0;

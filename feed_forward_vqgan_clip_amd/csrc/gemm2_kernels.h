@@ -879,7 +879,9 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), (BM == 256 ? 2 : 1)) void gemm2
       __syncthreads();
     }
   }
-  if constexpr (M16) {
+  if constexpr (M16 && (EPI & ffvc_gemm_detail::EPI_K_VQ) != 0) {
+    ffvc_gemm_detail::gemm_epilogue_vq16<MT>(p, acc16, m0, n0, wm, wn, lane);      // FFVC_F_VQ_ARGMIN: nothing is stored
+  } else if constexpr (M16) {
     if (vec_ok == 2)
       // register exchange on the convolutions and on the activation-forward kinds that also store act' (two 16-bit tensors out: 178 vs
       // 189 us at 16384x4096x1024, profiles/r06_gemm3_ab.txt), LDS pads on the other K-major x K-major launches (gemm_common.h)
@@ -1374,7 +1376,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
       const char* e = getenv("FFVC_SK_FIXUP");
       fix256 = e ? atoi(e) : 1;
     }
-    if (fix256 && split == 1 && !(d.flags & FFVC_F_SPLITK_INKERNEL) && d.slab_stride == 0 && d.batch == 1 && n_tiles >= 24 && n_tiles <= 100 &&
+    if (fix256 && split == 1 && !(d.flags & (FFVC_F_SPLITK_INKERNEL | FFVC_F_VQ_ARGMIN)) && d.slab_stride == 0 && d.batch == 1 && n_tiles >= 24 && n_tiles <= 100 &&
         ksteps >= 32 && dma_operand_ok<XMODE>(d, true) && dma_operand_ok<WMODE>(d, false)) {
       int want = 200 / n_tiles;
       if (want > 4) want = 4;
@@ -1467,7 +1469,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
     // gemm2p_kernel has no in-kernel split-K combine: a launch whose K slices meet through sk_ws (or that would store unsynchronised
     // partial tiles) stays on gemm2_kernel
     const bool p_split_ok = d.sk_ws == nullptr && !(split > 1 && d.slab_stride == 0 && !(d.flags & FFVC_F_ATOMIC_OUT));
-    if (p_split_ok && (persist == 1 || (persist == 2 && d.K <= 512 && interior && (int64_t)n_tiles * d.batch * split > n_cu))) {
+    if (p_split_ok && !(d.flags & FFVC_F_VQ_ARGMIN) && (persist == 1 || (persist == 2 && d.K <= 512 && interior && (int64_t)n_tiles * d.batch * split > n_cu))) {
       const int64_t total = (int64_t)n_tiles * d.batch * split;
       const int slots = n_cu * ((BM == 256) ? 1 : 2);
       int pgrid = total < slots ? (int)total : slots;
@@ -1504,7 +1506,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
     const bool pays = XMODE == FFVC_OP_KMAJOR && d.K >= 2048;
     // gemm8_kernel has no ticket / combine either: the auto split-K above (24..100 tiles, K >= 2048) must not reach it
     const bool g8_split_ok = d.sk_ws == nullptr && !(split > 1 && d.slab_stride == 0 && !(d.flags & FFVC_F_ATOMIC_OUT));
-    if (g8_split_ok && (use8 == 2 || (use8 == 1 && pays) || g_force_gemm8) && d.kseg == 0 && d.x_mi == 0 && g8_offsets_ok<XMODE>(d)) {
+    if (g8_split_ok && !(d.flags & FFVC_F_VQ_ARGMIN) && (use8 == 2 || (use8 == 1 && pays) || g_force_gemm8) && d.kseg == 0 && d.x_mi == 0 && g8_offsets_ok<XMODE>(d)) {
       static bool attr8 = false;
       if (!attr8) {
         (void)hipFuncSetAttribute((const void*)gemm8_kernel<L, XMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1551,7 +1553,8 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
           const char* e = getenv("FFVC_SK_TAIL");
           tail_opt = e ? atoi(e) : 1;
         }
-        if (tail_opt && split == 1 && d.batch == 1 && d.slab_stride == 0 && d.sk_ws == nullptr && n_tiles > n_cu && ksteps >= 32) {
+        if (tail_opt && split == 1 && d.batch == 1 && d.slab_stride == 0 && d.sk_ws == nullptr && n_tiles > n_cu && ksteps >= 32 &&
+            !(d.flags & FFVC_F_VQ_ARGMIN)) {
           const int full = (n_tiles / n_cu) * n_cu, tail = n_tiles - full;
           if (tail > 0 && 2 * tail <= n_cu) {
             int S = n_cu / tail;
@@ -1595,6 +1598,10 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
           return go(std::integral_constant<int, EPI_LEAN | EPI_O_F32>{});          // weight-gradient slabs
         if (!wants_act && !wants_gn) return go(std::integral_constant<int, EPI_LEAN>{});
       } else if constexpr (XMODE == FFVC_OP_KMAJOR) {
+        if constexpr (FFVC_MFMA16 && WMODE == FFVC_OP_KMAJOR && BM == 256 && BN == 256) {
+          if (d.flags & FFVC_F_VQ_ARGMIN) return split == 1 ? go(std::integral_constant<int, EPI_K_VQ>{}) : 0;
+        }
+        if (d.flags & FFVC_F_VQ_ARGMIN) return 0;
         if constexpr (WMODE == FFVC_OP_KMAJOR) {
           if (lean_opt >= 1 && !wants_act && !wants_gn && !(d.flags & (FFVC_F_ATOMIC_OUT | FFVC_F_ACCUM_OUT | FFVC_F_BIAS_ALONG_M)) &&
               d.slab_stride == 0) {
@@ -1638,6 +1645,7 @@ int launch2(const ffvc_gemm_desc& d_in, hipStream_t st, int vec_ok, const uint16
       // a convolution / weight gradient that does ask for an activation falls through to the global-address kernel below
     }
   }
+  if (d.flags & FFVC_F_VQ_ARGMIN) return 0;      // the argmin epilogue exists on the buffer-descriptor 256x256 kernel only
   hipLaunchKernelGGL((gemm2_kernel<L, XMODE, WMODE, BM, BN>), grid, dim3(nthreads), lds, st, d, tiles_n, n_tiles, ksplit_len,
                      vec_ok, zero, gm);
   hipError_t e = hipGetLastError();

@@ -168,6 +168,59 @@ __device__ __forceinline__ void gemm_epilogue16(const ffvc_gemm_desc& p, f32x4_t
   }
 }
 
+// FFVC_F_VQ_ARGMIN (main.py:133-139): acc16[a][b] as in gemm_epilogue16 — the lane owns row m = 16 b + (lane & 15) and the columns
+// n = 16 a + 4 (lane >> 4) + j.  d = (xn[m] + cn[n]) - 2 acc is the expression of vq_argmin_kernel (elementwise.hip) on the value the
+// plain fp32 epilogue would have stored (alpha = 1), so the winner is the same index bit for bit.  Per row: 16 columns in the lane
+// (ascending n, strict < keeps the first), the other 48 of the wave in three lanes (two exchanges), then one 64-bit atomic minimum of
+// (order-preserving bits of d) << 32 | n — the unsigned order of that word is (d, n) lexicographic, so the first minimum over all
+// column tiles wins however the atomics arrive.
+__device__ __forceinline__ unsigned long long vq_pack(float d, int n) {
+  const uint32_t u = __float_as_uint(d);
+  const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)key << 32) | (uint32_t)n;
+}
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue_vq16(const ffvc_gemm_desc& p, f32x4_t (&acc)[4][2 * MT], int m0, int n0, int wm, int wn,
+                                                   int lane) {
+  const int l15 = lane & 15, g4 = lane >> 4;
+  float cn[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + a * 16 + 4 * g4 + j;
+      cn[a][j] = n < p.N ? p.vq_cn[n] : 0.0f;
+    }
+#pragma unroll
+  for (int b = 0; b < 2 * MT; ++b) {
+    const int m = m0 + wm * (32 * MT) + b * 16 + l15;
+    const float x2 = p.vq_xn[m < p.M ? m : 0];
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + a * 16 + 4 * g4 + j;
+        const float d = (x2 + cn[a][j]) - 2.0f * acc[a][b][j];
+        if (n < p.N && d < best) {
+          best = d;
+          bi = n;
+        }
+      }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob < best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (g4 == 0 && m < p.M && bi != 0x7fffffff) atomicMin((unsigned long long*)p.vq_out + m, vq_pack(best, bi));
+  }
+}
+
 // ---- row-store epilogue --------------------------------------------------------------------------------------------
 // The MFMA C layout gives a lane 4 consecutive n of ONE row per register quad, 32 rows per wave instruction: stored
 // directly, every store touches 32 lines with 16 bytes each and the epilogue is store-issue bound (~7 B/clk/CU
@@ -242,6 +295,7 @@ constexpr int EPI_O_T = 512, EPI_O_F32R = 1024, EPI_O_F32 = 2048;
 constexpr int EPI_O_F8E4 = 4096, EPI_O_F8E5 = 8192, EPI_O_F8 = EPI_O_F8E4 | EPI_O_F8E5;
 // GroupNorm-BACKWARD statistics of the node whose output gradient this launch stores (FFVC_F_GNB_SUMS, register-exchange epilogue only)
 constexpr int EPI_GNB = 16384;
+constexpr int EPI_K_VQ = 32768;          // FFVC_F_VQ_ARGMIN: no store, per-row argmin of the distance (gemm_epilogue_vq16)
 
 template <typename T, int EPI = EPI_ALL>
 __device__ __forceinline__ void epilogue_oct(const ffvc_gemm_desc& p, f32x8& v, int n, int64_t yrow, int64_t rrow,

@@ -141,7 +141,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
          residual=None, aux=None, ldaux=0, act=ACT_NONE, flags=0, split_k=1, alpha=1.0,
          kseg=0, xkso=0, wkso=0, y_map=None, r_map=None, batch=1, batch_inner=1,
          xb=(0, 0), wb=(0, 0), yb=(0, 0), rb=(0, 0), ab=(0, 0), conv=None, x_map=None, slab_stride=0, gn_sums=None,
-         colsum=None, gnb=None, probe_only=False):
+         colsum=None, gnb=None, probe_only=False, vq=None):
     """Enqueue `ffvc_gemm`. See include/ffvc.h for the index maps.
 
     y_map / r_map = (mi, so, sm): row offset(m) = (m // mi) * so + (m % mi) * sm (mi = 0: m * sm).
@@ -156,7 +156,9 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     d.in_dtype = dtype_code(x.dtype)
     if w.dtype != x.dtype:
         raise TypeError(f"gemm operand dtypes differ: {x.dtype} vs {w.dtype}")
-    if y.dtype == torch.float32 and x.dtype != torch.float32:
+    if vq is not None:
+        pass                                      # nothing is stored: y is the packed (distance, index) word per row
+    elif y.dtype == torch.float32 and x.dtype != torch.float32:
         flags |= F_OUT_F32
     elif y.dtype != x.dtype:
         raise TypeError(f"gemm output dtype {y.dtype} incompatible with input {x.dtype}")
@@ -203,6 +205,13 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
         d.gnb_gamma, d.gnb_beta, d.gnb_sums, d.gnb_swish = ggamma.data_ptr(), gbeta.data_ptr(), gsums.data_ptr(), int(bool(gswish))
         d.gn_hw, d.gn_cpg = ghw, gcpg
         d.flags |= _lib.F_GNB_SUMS
+    if vq is not None:                            # (xn fp32 [M], cn fp32 [N], packed int64 [M] = all ones): FFVC_F_VQ_ARGMIN
+        vxn, vcn, vout = vq
+        _req_f32(vxn, vcn)
+        if vout.dtype != torch.int64 or not vout.is_contiguous() or vout.numel() != M or vxn.numel() != M or vcn.numel() != N:
+            raise TypeError("gemm: vq = (xn fp32 [M], cn fp32 [N], packed int64 [M])")
+        d.vq_xn, d.vq_cn, d.vq_out = vxn.data_ptr(), vcn.data_ptr(), vout.data_ptr()
+        d.flags |= _lib.F_VQ_ARGMIN
     if probe_only:
         return bool(_lib.load().ffvc_gemm_gnb_probe(byref(d), stream_ptr()))
     if colsum is not None:                        # fp32 [N]: += column sums of the stored output (colsum_fusable() first)
@@ -218,7 +227,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     M0 = M - M % 256
     tail = M - M0
     skinny = (_GEMM_ROWSPLIT and x.dtype in LOWP and x_mode == OP_KMAJOR and w_mode == OP_KMAJOR and M0 >= 8192 and 0 < tail <= 64 and
-              batch == 1 and split_k == 1 and act == ACT_NONE and aux is None and colsum is None and gn_sums is None and conv is None and
+              batch == 1 and split_k == 1 and act == ACT_NONE and aux is None and colsum is None and gn_sums is None and conv is None and vq is None and
               x_map is None and y_map is None and r_map is None and kseg == 0 and slab_stride == 0 and alpha == 1.0 and
               (flags & ~(F_OUT_F32 | F_RES_F32)) == 0 and (ldx in (0, K)) and (ldw in (0, K)) and
               bool(lib.ffvc_gemm_skinny_ok(tail, N, K)))
@@ -237,7 +246,7 @@ def gemm(x, w, y, M, N, K, *, ldx=0, ldw=0, x_mode=OP_KMAJOR, w_mode=OP_KMAJOR, 
     if REPLAY is not None:       # EVERY profiled launch has a replay entry (bench.attainable_leg aligns the two lists index by index)
         REPLAY.append((_GEMM_CLASS[(x_mode, w_mode)] + {torch.float32: "_f32", torch.float16: "_f16"}.get(x.dtype, "_bf16"),
                        (M, N, K, max(1, batch), split_k, int(d.flags), int(act)), issue if skinny else d,
-                       (x, w, y, bias, residual, aux, colsum, gn_sums, gnb)))
+                       (x, w, y, bias, residual, aux, colsum, gn_sums, gnb, vq)))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -944,6 +953,24 @@ def rownorm_sq(x):
     out = torch.empty(rows, dtype=torch.float32, device=x.device)
     _call("ffvc_rownorm_sq", x.data_ptr(), out.data_ptr(), rows, dim, stream_ptr())
     return out
+
+
+VQ_FUSE = os.environ.get("FFVC_VQ_FUSE", "1") != "0"       # A/B: the argmin inside the distance GEMM (FFVC_F_VQ_ARGMIN)
+
+
+def vq_fused_ok(dtype, ncodes, depth):
+    """Can the distance GEMM of `vector_quantize` keep the argmin itself?  16-bit K-major operands on the 256x256 LDS-DMA kernel."""
+    return VQ_FUSE and dtype in LOWP and depth % 8 == 0 and ncodes % 4 == 0 and os.environ.get("FFVC_GEMM2_BM", "1") != "0"
+
+
+def vq_argmin_fused(x, cb, xnorm, cnorm):
+    """idx[r] = argmin_j (xnorm[r] + cnorm[j]) - 2 x[r] . cb[j]  (main.py:133-139; first minimum) without the [rows, codes] distance
+    matrix: x [rows, K], cb [codes, K] 16-bit K-major (e.g. split3 operands).  Bit-identical to gemm(fp32 out) + vq_argmin."""
+    rows, depth = x.shape
+    ncodes = cb.shape[0]
+    packed = torch.full((rows,), -1, dtype=torch.int64, device=x.device)
+    gemm(x, cb, packed, rows, ncodes, depth, ldx=depth, ldw=depth, vq=(xnorm, cnorm, packed))
+    return packed & 0xFFFFFFFF
 
 
 def vq_argmin(dot, xnorm, cnorm):

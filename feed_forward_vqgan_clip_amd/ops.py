@@ -1090,14 +1090,19 @@ class _VQFn(Function):
         rows = z.numel() // C
         n = codebook.shape[0]
         if force_idx is None:
-            dot = torch.empty(rows, n, dtype=torch.float32, device=z.device)
-            if cb3 is not None and _VQ_SPLIT:
-                # fp32-grade products on the f16 matrix pipes (ffvc_split3: [hi|lo|hi] . [hi|hi|lo], every term but lo x lo,
-                # ~2^-22 relative): 16384 x 16384 x 256 in exact-fp32 MFMA is 1.4 ms of the step, this form a third of it
-                K.gemm(K.split3(z.view(rows, C)), cb3, dot, rows, n, 3 * C, ldx=3 * C, ldw=3 * C)
+            if cb3 is not None and _VQ_SPLIT and K.vq_fused_ok(cb3.dtype, n, 3 * C):
+                # the same split-precision products, the argmin folded into the GEMM's epilogue: the 1 GB distance matrix of a
+                # 16384-row batch is neither written nor read back (r6: 0.97 -> 0.42 ms, bit-identical indices)
+                idx = K.vq_argmin_fused(K.split3(z.view(rows, C), cb3.dtype), cb3, K.rownorm_sq(z), cnorm)
             else:
-                K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
-            idx = K.vq_argmin(dot, K.rownorm_sq(z), cnorm)
+                dot = torch.empty(rows, n, dtype=torch.float32, device=z.device)
+                if cb3 is not None and _VQ_SPLIT:
+                    # fp32-grade products on the f16 matrix pipes (ffvc_split3: [hi|lo|hi] . [hi|hi|lo], every term but lo x lo,
+                    # ~2^-22 relative): 16384 x 16384 x 256 in exact-fp32 MFMA is 1.4 ms of the step, this form a third of it
+                    K.gemm(K.split3(z.view(rows, C)), cb3, dot, rows, n, 3 * C, ldx=3 * C, ldw=3 * C)
+                else:
+                    K.gemm(z, codebook, dot, rows, n, C, ldx=C, ldw=C)
+                idx = K.vq_argmin(dot, K.rownorm_sq(z), cnorm)
         else:
             idx = force_idx.reshape(rows).to(torch.int64).contiguous()
         ctx.zdtype = z.dtype

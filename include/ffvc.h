@@ -68,6 +68,8 @@ extern "C" {
 #define FFVC_F_GNB_SUMS 8192    /* the stored output is the gradient dy of a GroupNorm(+swish) output: also accumulate that node's BACKWARD
                                  * statistics (see gnb_* below) — the statistics pass of ffvc_groupnorm_bwd folded into the dgrad convolution
                                  * that produces dy.  conv3 row-tile kernel only (ffvc_gemm_gnb_probe says whether a launch takes it). */
+#define FFVC_F_VQ_ARGMIN 16384  /* nothing is stored: the launch keeps, per row m, the first n that minimises (vq_xn[m] + vq_cn[n]) - 2 * acc[m, n]
+                                 * (see vq_* below) */
 #define FFVC_F_SPLITK_INKERNEL 4096 /* split_k > 1 handled INSIDE the launch: every K slice parks its fp32 partial tile in library
                                   * scratch, the last slice to arrive on a tile sums them in slice order and runs the ordinary
                                   * epilogue (any epilogue, FFVC_F_ACCUM_OUT included): no slabs, no reduce launch.  16-bit LDS-DMA
@@ -183,6 +185,16 @@ typedef struct ffvc_gemm_desc {
   const float* gnb_beta;
   double* gnb_sums;
   int32_t gnb_swish;
+  /* FFVC_F_VQ_ARGMIN (round 6; reference main.py:133-139 `vector_quantize`: d = x.pow(2).sum + codebook.pow(2).sum - 2 x @ codebook.T,
+   * indices = d.argmin(-1)): x = the rows to quantise [M, K], w = the codebook [N, K] (both K-major, 16-bit — e.g. the split-precision
+   * operands of ffvc_split3), vq_xn[M] / vq_cn[N] the fp32 squared norms.  The distance matrix is never stored: every wave folds its
+   * 64 columns in registers — same fp32 expression, same order as ffvc_vq_argmin — and sends one 64-bit atomic minimum per row to
+   * vq_out[m] = (order-preserving bits of d) << 32 | n, which the caller initialises to all ones; afterwards the low 32 bits are the
+   * index (first minimum, as torch.argmin).  256x256 LDS-DMA kernel only: batch 1, split_k 1, alpha 1, no bias / residual / aux /
+   * activation; y is ignored (pass vq_out).  ffvc_gemm fails with FFVC_E_UNSUPPORTED when the operands do not take that kernel. */
+  const float* vq_xn;
+  const float* vq_cn;
+  uint64_t* vq_out;
 } ffvc_gemm_desc;
 
 int ffvc_gemm(const ffvc_gemm_desc* d, void* stream);

@@ -40,7 +40,7 @@ def test_gemm_desc_layout_matches_header():
         line = line.strip().rstrip(";")
         if not line:
             continue
-        decl = re.sub(r"^(const\s+)?(void|float|double|int32_t|int64_t|uint32_t)\s*\*?\s*", "", line)
+        decl = re.sub(r"^(const\s+)?(void|float|double|int32_t|int64_t|uint32_t|uint64_t)\s*\*?\s*", "", line)
         names += [re.sub(r"\[\d+\]$", "", n.strip().lstrip("*")) for n in decl.split(",")]      # (fixed-size arrays: name[8])
     assert names == [f[0] for f in GemmDesc._fields_]
 

@@ -129,6 +129,40 @@ def test_sumpool(cuda, dt):
     assert _rel(y, ref) < _tol(dt)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,codes,C", [(300, 1000, 64), (1000, 260, 24), (4096, 16384, 256), (513, 16384, 256)])
+def test_vq_argmin_inside_the_distance_gemm(cuda, dt, rows, codes, C):
+    """FFVC_F_VQ_ARGMIN (main.py:133-139): the split-precision distance GEMM keeps the argmin itself — every index must equal the
+    two-launch form (fp32 distance matrix + ffvc_vq_argmin) bit for bit, ragged row / column tiles and exact ties included
+    (duplicated codebook rows: the first one wins, as torch.argmin)."""
+    x, cb = _mk((rows, C), torch.float32, cuda, 1), _mk((codes, C), torch.float32, cuda, 2)
+    cb[codes // 2] = cb[3]
+    cb[codes - 1] = cb[0]
+    x[5] = cb[3]                                  # row 5 sits exactly on a duplicated code
+    xn, cn = K.rownorm_sq(x), K.rownorm_sq(cb)
+    x3, cb3 = K.split3(x, dt), K.split3(cb, dt, weight_order=True)
+    assert K.vq_fused_ok(dt, codes, 3 * C)
+    dot = torch.empty(rows, codes, dtype=torch.float32, device=cuda)
+    K.gemm(x3, cb3, dot, rows, codes, 3 * C, ldx=3 * C, ldw=3 * C)
+    ref = K.vq_argmin(dot, xn, cn)
+    idx = K.vq_argmin_fused(x3, cb3, xn, cn)
+    assert idx.dtype == torch.int64 and idx.shape == ref.shape
+    assert int(idx.min()) >= 0 and int(idx.max()) < codes
+    assert torch.equal(idx, ref), f"{int((idx != ref).sum())} of {rows} indices differ"
+    assert int(idx[5]) == 3 and (idx != codes // 2).all() and (idx != codes - 1).all()
+    d = x.double().pow(2).sum(-1, keepdim=True) + cb.double().pow(2).sum(1) - 2 * x.double() @ cb.double().T
+    assert (idx == d.argmin(-1)).float().mean() > 0.995
+
+
+def test_vq_argmin_flag_is_refused_where_no_kernel_implements_it(cuda):
+    """fp32 operands (or an odd reduction depth) do not take the 256x256 LDS-DMA kernel: the launch must fail loudly, not store nothing."""
+    x, cb = _mk((64, 32), torch.float32, cuda, 1), _mk((128, 32), torch.float32, cuda, 2)
+    packed = torch.full((64,), -1, dtype=torch.int64, device=cuda)
+    with pytest.raises(RuntimeError):
+        K.gemm(x, cb, packed, 64, 128, 32, ldx=32, ldw=32, vq=(K.rownorm_sq(x), K.rownorm_sq(cb), packed))
+    assert (packed == -1).all()
+
+
 def test_vq_and_gather(cuda):
     x, cb = _mk((300, 64), torch.float32, cuda, 1), _mk((1000, 64), torch.float32, cuda, 2)
     xn, cn = K.rownorm_sq(x), K.rownorm_sq(cb)
