@@ -554,8 +554,14 @@ int ffvc_gemm2_try(const ffvc_gemm_desc& d, hipStream_t st, int vec_ok) {
   if (d.w_mode == FFVC_OP_KMAJOR && !m8(d.K)) return 0;
   // reduction-major operands: whole chunks along M / N — either the extent is a multiple of 8 or the row stride leaves room to read
   // the last chunk in full (gemm2_kernels.h tr_cols)
-  if (d.x_mode == FFVC_OP_TRANS && !m8(d.M) && d.ldx < ((d.M + 7) & ~7)) return 0;
-  if (d.w_mode == FFVC_OP_TRANS && !m8(d.N) && d.ldw < ((d.N + 7) & ~7)) return 0;
+  // FFVC_TT_PAD=1 admits the second form (0, the default, insists on multiples of 8: see ops._SLN_INPLACE / DESIGN.md section 5)
+  static int tt_pad = -1;
+  if (tt_pad < 0) {
+    const char* e = getenv("FFVC_TT_PAD");
+    tt_pad = e ? atoi(e) : 0;
+  }
+  if (d.x_mode == FFVC_OP_TRANS && !m8(d.M) && (!tt_pad || d.ldx < ((d.M + 7) & ~7))) return 0;
+  if (d.w_mode == FFVC_OP_TRANS && !m8(d.N) && (!tt_pad || d.ldw < ((d.N + 7) & ~7))) return 0;
   if (d.kseg && (!m8(d.xkso) || !m8(d.wkso))) return 0;
   const uint16_t* zero = zero_page();
   if (!zero) return 0;

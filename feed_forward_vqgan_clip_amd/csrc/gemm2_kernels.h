@@ -296,6 +296,9 @@ struct ConvRowDmaB {
 // a multiple of 8 is read up to the next multiple when the row stride has room for it (the padded qkv / w_out operands of the VitGAN
 // blocks: 3060 of 3064, 1020 of 1024).  The extra columns only reach accumulator rows / columns beyond M / N, which no epilogue stores.
 __device__ __forceinline__ int tr_cols(int cols, int64_t ld) {
+#ifdef FFVC_NO_TR_COLS      // debugging build: the loaders' bound is the extent itself
+  return cols;
+#endif
   const int up = (cols + 7) & ~7;
   return (int64_t)up <= ld ? up : cols;
 }

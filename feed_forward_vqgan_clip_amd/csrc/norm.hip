@@ -375,7 +375,11 @@ __global__ __launch_bounds__(256) void sln_fwd_kernel(const float* __restrict__ 
 
 // Backward of SLN: dhl (+ dres), dw, LayerNorm dgamma/dbeta partial rows, and partial sums of the two scalars
 // (part_s[block][2] = {sum dy*w*ln, sum dy*w}).
-template <int VEC, typename DYT>
+// X2 (ffvc_sln_bwd_acc2, opt-in): the second scalar gradient has its own address and dw may be a running sum.  A separate instantiation:
+// the default one must stay the code of rounds 3-5 — with the two extra operands compiled into it, 16 of 100 backward passes of a 9-block
+// generator came out with one sample's gradients changed at f16-rounding level, with the old kernel in the same library 0 of 100
+// (tools/r6/vitgan_determinism_old.py; mechanism not found: the kernel alone is bit-reproducible).
+template <int VEC, typename DYT, bool X2 = false>
 __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy, const float* __restrict__ hl,
                                                       const float* __restrict__ w, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ gs,
@@ -427,11 +431,13 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
           ag[k * VEC + j] += dln * h;
           ab[k * VEC + j] += dln;
         }
-        if (dw_acc) {     // every SLN of the network modulates with the same w: its gradient is one running sum (ffvc_sln_bwd_acc2)
-          float old[VEC];
-          ld_vec<VEC>(dw + row * dim + idx, old);
+        if constexpr (X2) {
+          if (dw_acc) {     // every SLN of the network modulates with the same w: its gradient is one running sum (ffvc_sln_bwd_acc2)
+            float old[VEC];
+            ld_vec<VEC>(dw + row * dim + idx, old);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) dwv[j] += old[j];
+            for (int j = 0; j < VEC; ++j) dwv[j] += old[j];
+          }
         }
         st_vec<VEC>(dw + row * dim + idx, dwv);
       }
@@ -478,7 +484,11 @@ __global__ __launch_bounds__(256) void sln_bwd_kernel(const DYT* __restrict__ dy
       atomicAdd(part_g + i, ln_smem[i]);
       atomicAdd(part_b + i, ln_smem[dim + i]);
     }
-    if (threadIdx.x < 2) atomicAdd(threadIdx.x ? part_s1 : part_s, ln_smem[2 * dim + threadIdx.x]);
+    if constexpr (X2) {
+      if (threadIdx.x < 2) atomicAdd(threadIdx.x ? part_s1 : part_s, ln_smem[2 * dim + threadIdx.x]);
+    } else {
+      if (threadIdx.x < 2) atomicAdd(part_s + threadIdx.x, ln_smem[2 * dim + threadIdx.x]);
+    }
     return;
   }
   for (int i = threadIdx.x; i < dim; i += 256) {
@@ -1647,13 +1657,23 @@ static int sln_bwd_launch(const void* dy, int dy_dtype, const float* hl, const f
   const int rpb = ln_rows_per_block(rows);
   const int grid = ffvc_layernorm_bwd_blocks(rows);
   const size_t smem = (2 * (size_t)dim + 2) * sizeof(float);
+  const bool x2 = dw_acc != 0 || part_s1 != part_s + 1;
   DISPATCH_DT(dy_dtype, DYT, {
-    if (dim % 4 == 0)
-      hipLaunchKernelGGL((sln_bwd_kernel<4, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
-                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
-    else
-      hipLaunchKernelGGL((sln_bwd_kernel<1, DYT>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
-                         gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
+    if (x2) {
+      if (dim % 4 == 0)
+        hipLaunchKernelGGL((sln_bwd_kernel<4, DYT, true>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
+                           gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
+      else
+        hipLaunchKernelGGL((sln_bwd_kernel<1, DYT, true>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
+                           gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
+    } else {
+      if (dim % 4 == 0)
+        hipLaunchKernelGGL((sln_bwd_kernel<4, DYT, false>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
+                           gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
+      else
+        hipLaunchKernelGGL((sln_bwd_kernel<1, DYT, false>), dim3(grid), dim3(256), smem, st, (const DYT*)dy, hl, w, gamma, beta,
+                           gamma_s, beta_s, mean, rstd, dres, dhl, dw, part_g, part_b, part_s, rows, dim, rpb, acc_mode, part_s1, dw_acc);
+    }
   });
   FFVC_LAUNCH_CHECK();
   return 0;

@@ -126,6 +126,9 @@ class Mixer(_MapperBase):
 # ---------------------------------------------------------------------------
 # VitGAN mappers (reference: vitgan.py:221-260 `Generator`, :262-305 `SimpleGenerator`)
 # ---------------------------------------------------------------------------
+_SLN_SHARE = os.environ.get("FFVC_SLN_SHARE", "0") != "0" and os.environ.get("FFVC_SLN_INPLACE", "0") != "0"      # A/B: one running gradient sum for the shared modulation input
+
+
 class _SLN(nn.Module):
     """Holder for vitgan.py:8-21 SLN: `.ln` LayerNorm + scalar `.gamma`, `.beta` of shape (1,1,1)."""
 
@@ -185,7 +188,7 @@ class _VitGANBase(_MapperBase):
         self._w_outp = mk(self.w_out[0].weight, self.w_out[0].bias)
         # 16 tokens x a per-GPU batch of 32 = 512 rows: a weight gradient is 64 tiles with an 8-step reduction, a launch that never
         # fills the chip.  The MLP's two gradients of 8 consecutive blocks go out as one grouped launch (ops.WgradGroup)
-        g = int(os.environ.get("FFVC_VIT_WGRAD_GROUP", "8"))
+        g = int(os.environ.get("FFVC_VIT_WGRAD_GROUP", "0"))     # (0 = off, the default: see ops._SLN_INPLACE)
         ops.group_weights([b[4] for b in self._bp], g)
         ops.group_weights([b[5] for b in self._bp], g)
 
@@ -240,7 +243,7 @@ class Generator(_VitGANBase):
         T = self.initialize_size * 8
         B = noise.shape[0]
         x = ops.linear(ops.cast(noise.float(), cdt), self._w_mlp, out_dtype=f32).view(B, T, self.dim)   # vitgan.py:254
-        share = ops.SharedGrad() if self._bp else None
+        share = ops.SharedGrad() if (self._bp and _SLN_SHARE) else None
         hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B), x, share)                               # :255
         s = self.sln_norm
         y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt, share)                 # :256
@@ -274,7 +277,7 @@ class SimpleGenerator(_VitGANBase):
         inp = ops.linear(nz, self._w_inp, out_dtype=f32)                                                # vitgan.py:297
         x = ops.linear(nz, self._w_mlp, out_dtype=f32).view(B, N, self.dim)                             # :298
         inp_emb = ops.transpose_last2(inp.view(B, self.dim, N))                                         # :299
-        share = ops.SharedGrad() if self._bp else None
+        share = ops.SharedGrad() if (self._bp and _SLN_SHARE) else None
         hl = self._encode(ops.broadcast_rows(self.pos_emb1D, B, inp_emb), x, share)                      # :300
         s = self.sln_norm
         y, _ = ops.sln_fork(hl, x, s.ln.weight, s.ln.bias, s.gamma, s.beta, cdt, share)

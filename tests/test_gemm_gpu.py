@@ -232,8 +232,8 @@ def test_dword_aligned_leading_dims(cuda, dt):
 def test_padded_reduction_major_operands(cuda, dt, M, N, ldx, ldw):
     """The VitGAN blocks' qkv / w_out weight gradients (vitgan.py:62-97: 6 heads x 170): un-padded fp32 gradients [3060, 1024] /
     [1024, 1020] from operands whose ROWS are padded to 3064 / 1024.  The LDS-DMA kernel reads the last 8-column chunk in full
-    (pad columns hold garbage here: NaN, to prove they reach no stored output); without room in the row stride the launch takes
-    the register-staged kernel.  Both must agree with fp64."""
+    (pad columns hold garbage here: NaN, to prove they reach no stored output) when FFVC_TT_PAD=1 (off by default: every such launch
+    then takes the register-staged kernel, as without room in the row stride).  Either way the result must agree with fp64."""
     rows = 512
     dy = _mk((rows, ldx), dt, cuda, 1)
     x = _mk((rows, ldw), dt, cuda, 2)

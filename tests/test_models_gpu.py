@@ -2,6 +2,8 @@
 against (a) the golden vectors produced by the reference's own code and (b) the oracle on seeded
 inputs.  fp32 ("parity") mode must agree to fp32 round-off; bf16 mode to the stated stage tolerances.
 """
+import os
+
 import pytest
 import torch
 
@@ -683,8 +685,9 @@ def _vitgan_grads(group, seed=7):
     """Full-width VitGAN generator (vitgan.py:221-260 at cfg3's geometry: dim 1024, 6 heads x 170, 16 tokens, 32 samples = 512 rows),
     9 blocks: gradients of loss = sum(out * r)."""
     from feed_forward_vqgan_clip_amd import ops
-    old = ops._WGRAD_GROUP
+    old, old_env = ops._WGRAD_GROUP, os.environ.get("FFVC_VIT_WGRAD_GROUP")
     ops._WGRAD_GROUP = group
+    os.environ["FFVC_VIT_WGRAD_GROUP"] = "8"            # mark the packs (off by default); ops._WGRAD_GROUP <= 1 still launches per layer
     try:
         torch.manual_seed(seed)
         net = Generator(initialize_size=2, out_channels=4, input_dim=64, dim=1024, num_heads=6, blocks=9).cuda().prepare(F16)
@@ -700,18 +703,40 @@ def _vitgan_grads(group, seed=7):
         return g, grouped
     finally:
         ops._WGRAD_GROUP = old
+        if old_env is None:
+            os.environ.pop("FFVC_VIT_WGRAD_GROUP", None)
+        else:
+            os.environ["FFVC_VIT_WGRAD_GROUP"] = old_env
 
 
 def test_vitgan_grouped_weight_gradients_equal_the_per_layer_launches(cuda):
-    """The MLP weight gradients of 8 consecutive VitGAN blocks in one launch (a ninth block stays alone) against one launch per layer:
-    same products, different fp32 summation order; every other gradient (the shared modulation input's running sum, the scalar
-    SLN parameters written straight into the bucket) is produced by the same kernels in both runs and must be identical."""
+    """The MLP weight gradients of 8 consecutive VitGAN blocks in one launch (opt-in: FFVC_VIT_WGRAD_GROUP=8; a ninth block stays alone)
+    against one launch per layer: same products.  Tolerance: with these launches a few percent of backward passes come out with ONE
+    sample's gradients changed at f16-rounding level (relrms up to 1e-4 in a weight gradient; tools/r6/vitgan_determinism_old.py,
+    DESIGN.md section 5) — the reason the grouped form is off by default; anything structural would be orders of magnitude above."""
     g8, n8 = _vitgan_grads(4)
     g0, n0 = _vitgan_grads(0)
     assert n8 == 16 and n0 == 16          # marked either way; FFVC_WGRAD_GROUP <= 1 only stops ops._wgrad from deferring
     for k in g0:
         assert torch.isfinite(g8[k]).all(), k
-        assert _relrms(g8[k], g0[k]) < 2e-5, (k, _relrms(g8[k], g0[k]))
+        # (the one-element SLN scalars are sums of 512 x 1024 products through fp32 atomics: their own run-to-run spread is ~1e-3)
+        assert _relrms(g8[k], g0[k]) < (5e-4 if g0[k].numel() > 1 else 1e-2), (k, _relrms(g8[k], g0[k]))
+
+
+@pytest.mark.parametrize("which", ["vitgan", "simple_vitgan"])
+def test_vitgan_golden_with_in_place_sln_gradients(cuda, which, monkeypatch):
+    """FFVC_SLN_INPLACE=1 + FFVC_SLN_SHARE=1 (opt-in): ffvc_sln_bwd_acc2 writes the scalar SLN gradients straight to their bucket slots and
+    keeps one running sum for the shared modulation input — same golden vectors, forward and every gradient."""
+    from feed_forward_vqgan_clip_amd import mappers as fmap
+    from feed_forward_vqgan_clip_amd import ops
+    monkeypatch.setattr(ops, "_SLN_INPLACE", True)
+    monkeypatch.setattr(fmap, "_SLN_SHARE", True)
+    if which == "vitgan":
+        _check_mapper_golden("vitgan.npz", Generator(initialize_size=1, out_channels=8, input_dim=24, dim=12, num_heads=6,
+                                                     blocks=2), (3, 8, 8, 8))
+    else:
+        _check_mapper_golden("simple_vitgan.npz", SimpleGenerator(size=4, dim=12, num_heads=6, blocks=2, out_channels=8,
+                                                                  input_dim=24), (3, 8, 4, 4))
 
 
 def test_partly_filled_weight_gradient_group_is_flushed(cuda):
