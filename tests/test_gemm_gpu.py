@@ -248,6 +248,20 @@ def test_padded_reduction_major_operands(cuda, dt, M, N, ldx, ldw):
     assert _rel(wg, ref) < 2e-5
 
 
+def test_padded_reduction_major_operands_on_the_lds_dma_kernel(cuda):
+    """FFVC_TT_PAD=1 (opt-in, read once per process -> a child process): the same launches on the LDS-DMA kernel, which reads the last
+    8-column chunk of a padded row in full — 10 repetitions x 2 dtypes x 4 shapes with NaN in the pad columns and a NaN-poisoned
+    allocator cache (tools/r6/tt_pad_stress.py), every result against fp64."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFVC_TT_PAD="1", STRESS_REPS="10")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "r6", "tt_pad_stress.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "mismatches: 0" in out.stdout, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_splitk_slabs(cuda, dt):
     M, N, K_ = 256, 384, 4096

@@ -1,5 +1,5 @@
 """Round 6: stress of the padded reduction-major operands (tests/test_gemm_gpu.py::test_padded_reduction_major_operands) — poisoned
-allocator cache, many repetitions, location of the worst element on a mismatch.  usage (GPU box): python tools/r6/tt_pad_stress.py"""
+allocator cache, many repetitions, location of the worst element on a mismatch.  usage (GPU box): FFVC_TT_PAD=1 python tools/r6/tt_pad_stress.py   (without FFVC_TT_PAD=1 the launches take the register-staged kernel)"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ from feed_forward_vqgan_clip_amd import kernels as K  # noqa: E402
 
 dev = torch.device("cuda:0")
 bad = 0
-for rep in range(40):
+for rep in range(int(os.environ.get('STRESS_REPS', '40'))):
     for dt in (torch.bfloat16, torch.float16):
         for (M, N, ldx, ldw) in [(3060, 1024, 3064, 1024), (1024, 1020, 1024, 1024), (3060, 1020, 3064, 1024), (3060, 1024, 3060, 1024)]:
             junk = torch.full((8 << 20,), float("nan"), device=dev)      # poison what the next allocations may reuse
